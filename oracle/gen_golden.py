@@ -1,0 +1,189 @@
+"""Generate ``tests/golden/*`` from the UNMODIFIED reference, and pin the oracle against it.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (needs
+``/root/reference``); the GPU box never runs it.  Usage:
+
+    python -m oracle.gen_golden            # from the repo root
+
+It (1) imports reference ``model.py`` / ``misc/panostretch.py`` / ``inference.py``
+with the stand-ins under ``oracle/standins`` on ``sys.path``, (2) loads seeded
+weights (``oracle/weights.py``) into the reference ``HorizonNet``, (3) checks the
+restatements in ``oracle/*.py`` against the reference outputs (prints max-abs and
+asserts), and (4) writes small fixtures.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+sys.path.insert(0, os.path.join(HERE, "standins"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from oracle import horizonnet_ref, panostretch_ref, peaks_ref   # noqa: E402
+from oracle.weights import make_state_dict, state_dict_spec      # noqa: E402
+
+
+def load_demo_u8():
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(REF, "assets", "demo.png")))[..., :3]
+    assert img.shape == (512, 1024, 3) and img.dtype == np.uint8
+    return img
+
+
+def sample(t, step):
+    """Strided sample of an NCHW tensor for a compact fixture."""
+    t = t.detach().cpu().numpy()
+    if t.ndim == 4:
+        return t[:, ::step[0], ::step[1], ::step[2]].copy()
+    return t
+
+
+TAP_STEPS = {"stem": (8, 16, 32), "pool": (8, 8, 16), "c1": (16, 8, 16), "c2": (32, 4, 8),
+             "c3": (64, 2, 4), "c4": (128, 1, 2)}
+
+
+def gen_model():
+    import model as ref_model                      # the reference's model.py, unmodified
+    net = ref_model.HorizonNet("resnet50", True).eval()
+    ref_sd = net.state_dict()
+    spec = state_dict_spec()
+    assert list(ref_sd.keys()) == list(spec.keys()), "state_dict key order mismatch"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k][0]) and v.dtype == spec[k][1], k
+    nparam = sum(p.numel() for p in net.parameters())
+    assert len(ref_sd) == 448 and nparam == 81570348, (len(ref_sd), nparam)
+    with open(os.path.join(GOLD, "state_dict_spec.json"), "w") as f:
+        json.dump({"n_tensors": len(ref_sd), "n_params": nparam,
+                   "keys": [[k, list(v.shape), str(v.dtype)] for k, v in ref_sd.items()]}, f)
+
+    demo = load_demo_u8()
+    np.savez_compressed(os.path.join(GOLD, "demo_input_u8.npz"), img=demo)
+    x_demo = torch.from_numpy(demo.transpose(2, 0, 1)[None].astype(np.float32) / 255.0)  # inference.py:196-200
+    g = torch.Generator().manual_seed(1234)
+    x_rand = torch.rand(2, 3, 512, 1024, generator=g)
+
+    cases = [("demo_seed0_bnrandom", 0, "random", x_demo),
+             ("demo_seed1_bnidentity", 1, "identity", x_demo),
+             ("rand2_seed2_bnrandom", 2, "random", x_rand)]
+    for name, seed, bn, x in cases:
+        sd = make_state_dict(seed, bn)
+        net.load_state_dict(sd, strict=True)
+        feats = {}
+        with torch.no_grad():
+            bon, cor = net(x)
+            xn = net._prepare_x(x)
+            c = net.feature_extractor(xn)
+            feature = net.reduce_height_module(c, 256)
+            lstm_out, _ = net.bi_rnn(feature.permute(2, 0, 1))
+        taps = {}
+        obon, ocor = horizonnet_ref.forward(x, sd, taps)
+        d_bon = (obon - bon).abs().max().item()
+        d_cor = (ocor - cor).abs().max().item()
+        d_feat = (taps["feature"] - feature).abs().max().item()
+        d_lstm = (taps["lstm"] - lstm_out).abs().max().item()
+        rel_c = [((taps["c%d" % (i + 1)] - c[i]).abs().max() / c[i].abs().max()).item() for i in range(4)]
+        print("%-24s oracle-vs-reference: bon %.2e cor %.2e feature %.2e lstm %.2e c1..4(rel) %s |bon|max %.3f |cor|max %.3f |feature|max %.2f cmax %s" % (
+            name, d_bon, d_cor, d_feat, d_lstm, ["%.1e" % r for r in rel_c], bon.abs().max().item(),
+            cor.abs().max().item(), feature.abs().max().item(), ["%.1f" % t.abs().max().item() for t in c]))
+        assert d_bon < 2e-5 and d_cor < 2e-5, "oracle restatement deviates from the reference"
+        sig = torch.sigmoid(cor)[:, 0].numpy()
+        out = {"bon": bon.numpy(), "cor": cor.numpy(), "feature": feature.numpy()[:, ::8],
+               "lstm": lstm_out.numpy()[::8], "seed": seed, "bn": bn,
+               "w_checksum": np.float64(sd["feature_extractor.encoder.conv1.1.weight"].double().sum().item()),
+               "w_checksum_lstm": np.float64(sd["bi_rnn.weight_hh_l1_reverse"].double().sum().item())}
+        for k, st in TAP_STEPS.items():
+            src = taps[k] if k in ("stem", "pool") else c[int(k[1]) - 1]
+            out["tap_" + k] = sample(src, st)
+        np.savez_compressed(os.path.join(GOLD, "forward_%s.npz" % name), **out)
+        del sig
+
+
+def gen_panostretch():
+    from misc import panostretch as ref_ps
+    demo = load_demo_u8().astype(np.float32) / 255.0                # dataset.py:51-54
+    corners = np.array([[100.5, 150.0], [100.5, 400.0], [400.0, 160.0], [400.0, 380.0],
+                        [700.0, 140.0], [700.0, 410.0], [950.0, 170.0], [950.0, 370.0]], np.float32)
+    out = {"corners_in": corners}
+    params = [(1.0, 1.0), (1.7, 1.2), (0.55, 1.9), (2.0, 0.5), (1.3, 1.3)]
+    out["params"] = np.array(params, np.float64)
+    for i, (kx, ky) in enumerate(params):
+        ref_img, ref_cor = ref_ps.pano_stretch(demo, corners, kx, ky)
+        o_img, o_cor = panostretch_ref.pano_stretch(demo, corners, kx, ky)
+        d = np.abs(o_img - ref_img)
+        print("pano_stretch kx=%.2f ky=%.2f oracle-vs-reference img max %.2e (n>1e-6: %d) corners max %.2e" % (
+            kx, ky, d.max(), int((d > 1e-6).sum()), np.abs(o_cor - ref_cor).max()))
+        assert d.max() < 1e-6 or kx == ky
+        assert np.abs(o_cor - ref_cor).max() < 1e-9
+        out["rows_%d" % i] = np.concatenate([ref_img[0:4], ref_img[254:258], ref_img[508:512]], 0)
+        out["cols_%d" % i] = np.concatenate([ref_img[:, 0:4], ref_img[:, 1020:1024]], 1)
+        out["grid_%d" % i] = ref_img[::8, ::8].copy()
+        out["corners_%d" % i] = ref_cor
+    # small full-size-independent cases: random images, odd sizes, C=1 and C=4
+    rng = np.random.RandomState(7)
+    small = []
+    for j, (h, w, c, kx, ky) in enumerate([(64, 128, 3, 1.5, 0.8), (32, 64, 1, 0.6, 1.4),
+                                            (48, 96, 4, 1.0, 1.9), (17, 40, 3, 1.25, 1.1)]):
+        img = rng.rand(h, w, c).astype(np.float32)
+        ref_img, _ = ref_ps.pano_stretch(img, corners[:2], kx, ky)
+        o_img, _ = panostretch_ref.pano_stretch(img, corners[:2], kx, ky)
+        print("pano_stretch small %dx%dx%d max %.2e" % (h, w, c, np.abs(o_img - ref_img).max()))
+        assert np.abs(o_img - ref_img).max() < 1e-6
+        out["small_in_%d" % j] = img
+        out["small_out_%d" % j] = ref_img
+        small.append((kx, ky))
+    out["small_params"] = np.array(small, np.float64)
+    np.savez_compressed(os.path.join(GOLD, "panostretch.npz"), **out)
+
+
+def gen_peaks():
+    import inference as ref_inf                    # reference inference.py (shapely stubbed)
+    rng = np.random.RandomState(11)
+    sigs, outs = [], {}
+    for j in range(12):
+        base = rng.rand(1024).astype(np.float32)
+        k = np.exp(-0.5 * (np.arange(-20, 21) / (2.0 + j)) ** 2).astype(np.float32)
+        s = np.convolve(np.tile(base, 3), k / k.sum(), mode="same")[1024:2048].astype(np.float32)
+        s = (s - s.min()) / (s.max() - s.min())
+        if j % 3 == 0:                              # plateaus / exact ties
+            s = np.round(s * 16) / 16
+        if j % 4 == 1:                              # sparse peaky signal like a trained cor head
+            s = (s ** 8).astype(np.float32)
+        sigs.append(s.astype(np.float32))
+    sigs = np.stack(sigs)
+    outs["signals"] = sigs
+    cfgs = [(26, 0.05, None), (26, 0.0, 4), (29, 0.05, None), (5, 0.3, None), (26, 0.5, 4)]
+    outs["cfgs"] = np.array([[r, mv, -1 if n is None else n] for r, mv, n in cfgs], np.float64)
+    for ci, (r, mv, n) in enumerate(cfgs):
+        for j in range(sigs.shape[0]):
+            loc, val = ref_inf.find_N_peaks(sigs[j], r=r, min_v=mv, N=n)
+            oloc, oval = peaks_ref.find_N_peaks(sigs[j], r=r, min_v=mv, N=n)
+            assert np.array_equal(loc, oloc) and np.array_equal(val, oval), (ci, j)
+            outs["loc_%d_%d" % (ci, j)] = loc.astype(np.int64)
+    print("find_N_peaks: oracle == reference on %d signals x %d configs" % (sigs.shape[0], len(cfgs)))
+    # sigmoid restatement vs torch (inference.py:80)
+    x = torch.linspace(-12, 12, 4097)
+    d = np.abs(peaks_ref.sigmoid_f32(x.numpy()) - torch.sigmoid(x).numpy()).max()
+    print("sigmoid_f32 vs torch.sigmoid max %.2e" % d)
+    np.savez_compressed(os.path.join(GOLD, "peaks.npz"), **outs)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    which = sys.argv[1:] or ["model", "panostretch", "peaks"]
+    if "panostretch" in which:
+        gen_panostretch()
+    if "peaks" in which:
+        gen_peaks()
+    if "model" in which:
+        gen_model()

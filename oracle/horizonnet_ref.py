@@ -1,0 +1,151 @@
+"""CPU restatement of ``HorizonNet.forward`` (resnet50 backbone, use_rnn=True, eval mode).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Functional torch fp32 on
+the host cores, driven directly by a reference-format state_dict; it does not
+need the reference tree or torchvision, so it travels to the GPU box.  Each step
+cites the reference lines it follows.  Validated against the unmodified
+reference module by ``oracle/gen_golden.py`` (max-abs printed there).
+"""
+import torch
+import torch.nn.functional as F
+
+from .weights import BN_EPS
+
+X_MEAN = (0.485, 0.456, 0.406)   # reference model.py:186
+X_STD = (0.229, 0.224, 0.225)    # reference model.py:187
+
+
+def lr_pad(x, p):
+    """Circular left/right padding -- reference model.py:27-29."""
+    return torch.cat([x[..., -p:], x, x[..., :p]], dim=3)
+
+
+def _bn(x, sd, k):
+    return F.batch_norm(x, sd[k + ".running_mean"], sd[k + ".running_var"],
+                        sd[k + ".weight"], sd[k + ".bias"], False, 0.0, BN_EPS)
+
+
+def _conv(x, sd, k, stride, ks):
+    """Conv2d with H zero-pad ks//2 and W circular-pad ks//2 (reference model.py:42-55)."""
+    w = sd[k + ".weight"]
+    b = sd.get(k + ".bias")
+    p = ks // 2
+    if p:
+        x = lr_pad(x, p)
+    return F.conv2d(x, w, b, stride=stride, padding=(p, 0))
+
+
+def _bottleneck(x, sd, p, stride, down):
+    """torchvision Bottleneck v1.5 as called from reference model.py:78-81."""
+    y = F.relu(_bn(_conv(x, sd, p + "conv1", 1, 1), sd, p + "bn1"))
+    y = F.relu(_bn(_conv(y, sd, p + "conv2.1", stride, 3), sd, p + "bn2"))
+    y = _bn(_conv(y, sd, p + "conv3", 1, 1), sd, p + "bn3")
+    if down:
+        x = _bn(_conv(x, sd, p + "downsample.0", stride, 1), sd, p + "downsample.1")
+    return F.relu(y + x)
+
+
+def prepare_x(x):
+    """reference model.py:248-252."""
+    mean = torch.tensor(X_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(X_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    return (x[:, :3] - mean) / std
+
+
+def backbone(x, sd, taps=None):
+    """reference model.py:71-82: stem + maxpool + layer1..4 -> [C1..C4]."""
+    enc = "feature_extractor.encoder."
+    y = F.relu(_bn(_conv(x, sd, enc + "conv1.1", 2, 7), sd, enc + "bn1"))
+    if taps is not None:
+        taps["stem"] = y
+    y = F.max_pool2d(y, 3, 2, 1)          # ordinary padding, NOT circular (model.py:44 skips it)
+    if taps is not None:
+        taps["pool"] = y
+    feats = []
+    for li, n in enumerate((3, 4, 6, 3)):
+        for j in range(n):
+            p = "%slayer%d.%d." % (enc, li + 1, j)
+            y = _bottleneck(y, sd, p, 2 if (j == 0 and li > 0) else 1, j == 0)
+        feats.append(y)
+    return feats
+
+
+def global_height_conv(x, sd, s, out_w):
+    """reference model.py:138-156."""
+    for k in range(4):
+        p = "reduce_height_module.ghc_lst.%d.layer.%d.layers." % (s, k)
+        x = F.relu(_bn(_conv(x, sd, p + "0.1", (2, 1), 3), sd, p + "1"))
+    factor = out_w // x.shape[3]
+    x = torch.cat([x[..., -1:], x, x[..., :1]], 3)
+    x = F.interpolate(x, size=(x.shape[2], out_w + 2 * factor), mode="bilinear", align_corners=False)
+    return x[..., factor:-factor]
+
+
+def lstm_ref(feature_tbc, sd):
+    """2-layer bi-LSTM, gates i,f,g,o -- explicit loops (reference model.py:222-227,263-264).
+
+    Written out instead of calling nn.LSTM so the arithmetic being matched is visible.
+    """
+    T, B, _ = feature_tbc.shape
+    x = feature_tbc
+    for layer in range(2):
+        outs = []
+        for suf in ("", "_reverse"):
+            wih = sd["bi_rnn.weight_ih_l%d%s" % (layer, suf)]
+            whh = sd["bi_rnn.weight_hh_l%d%s" % (layer, suf)]
+            bias = sd["bi_rnn.bias_ih_l%d%s" % (layer, suf)] + sd["bi_rnn.bias_hh_l%d%s" % (layer, suf)]
+            gx = x @ wih.t() + bias
+            h = x.new_zeros(B, 512)
+            c = x.new_zeros(B, 512)
+            ys = [None] * T
+            order = range(T) if suf == "" else range(T - 1, -1, -1)
+            for t in order:
+                g = gx[t] + h @ whh.t()
+                i, f, gg, o = g.chunk(4, dim=1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                ys[t] = h
+            outs.append(torch.stack(ys, 0))
+        x = torch.cat(outs, dim=2)
+    return x
+
+
+def forward(x, sd, taps=None):
+    """Full eval-mode forward -- reference model.py:254-281.  x: [B,>=3,512,1024] f32 in [0,1]."""
+    if x.shape[2] != 512 or x.shape[3] != 1024:
+        raise NotImplementedError()
+    with torch.no_grad():
+        xn = prepare_x(x.float())
+        feats = backbone(xn, sd, taps)
+        B = x.shape[0]
+        feature = torch.cat([global_height_conv(f, sd, s, 256).reshape(B, -1, 256)
+                             for s, f in enumerate(feats)], dim=1)          # model.py:172-179
+        seq = feature.permute(2, 0, 1).contiguous()                          # [256,B,1024]
+        out = lstm_ref(seq, sd)                                              # [256,B,1024]
+        lin = out @ sd["linear.weight"].t() + sd["linear.bias"]             # [256,B,12]
+        lin = lin.view(256, B, 3, 4).permute(1, 2, 0, 3).contiguous().view(B, 3, 1024)
+        if taps is not None:
+            taps.update(c1=feats[0], c2=feats[1], c3=feats[2], c4=feats[3],
+                        feature=feature, lstm=out)
+        return lin[:, 1:], lin[:, :1]                                        # bon, cor
+
+
+def conv_bn_act_nhwc(x_nhwc, w_oihw, bias, bn, stride, relu, residual=None):
+    """Single fused conv step in NHWC, used by the per-kernel GPU parity tests.
+
+    x_nhwc [B,H,W,Cin]; bn = (gamma, beta, mean, var) or None; W circular pad, H zero pad.
+    """
+    x = x_nhwc.permute(0, 3, 1, 2)
+    ks = w_oihw.shape[2]
+    p = ks // 2
+    if p:
+        x = lr_pad(x, p)
+    y = F.conv2d(x, w_oihw, bias, stride=stride, padding=(p, 0))
+    if bn is not None:
+        y = F.batch_norm(y, bn[2], bn[3], bn[0], bn[1], False, 0.0, BN_EPS)
+    y = y.permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return y.contiguous()

@@ -1,0 +1,107 @@
+"""CPU tests: the oracle restatements reproduce the golden vectors captured from the reference.
+
+The vectors under tests/golden/ were produced by oracle/gen_golden.py from the
+unmodified /root/reference (model.py, misc/panostretch.py, inference.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import horizonnet_ref, panostretch_ref, peaks_ref
+from oracle.weights import make_state_dict, state_dict_spec
+
+
+def test_state_dict_spec_matches_reference(golden_dir):
+    spec = json.load(open(os.path.join(golden_dir, "state_dict_spec.json")))
+    ours = state_dict_spec()
+    assert spec["n_tensors"] == 448 == len(ours)
+    assert [k for k, _, _ in spec["keys"]] == list(ours.keys())
+    for k, shape, dt in spec["keys"]:
+        assert tuple(shape) == tuple(ours[k][0]) and dt == str(ours[k][1])
+    n_params = sum(int(np.prod(s)) for k, s, _ in spec["keys"]
+                   if "running_" not in k and "num_batches" not in k)
+    assert n_params == spec["n_params"] == 81570348
+
+
+def test_forward_oracle_demo(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_demo_seed0_bnrandom.npz"))
+    img = np.load(os.path.join(golden_dir, "demo_input_u8.npz"))["img"]
+    x = torch.from_numpy(img.transpose(2, 0, 1)[None].astype(np.float32) / 255.0)
+    sd = make_state_dict(int(g["seed"]), str(g["bn"]))
+    assert abs(sd["feature_extractor.encoder.conv1.1.weight"].double().sum().item() - float(g["w_checksum"])) < 1e-9
+    assert abs(sd["bi_rnn.weight_hh_l1_reverse"].double().sum().item() - float(g["w_checksum_lstm"])) < 1e-9
+    torch.set_num_threads(os.cpu_count())
+    taps = {}
+    bon, cor = horizonnet_ref.forward(x, sd, taps)
+    assert np.abs(bon.numpy() - g["bon"]).max() < 1e-5
+    assert np.abs(cor.numpy() - g["cor"]).max() < 1e-5
+    assert np.abs(taps["feature"].numpy()[:, ::8] - g["feature"]).max() < 1e-5
+    assert np.abs(taps["c4"].numpy()[:, ::128, ::1, ::2] - g["tap_c4"]).max() < 1e-4
+    # corner-index extraction (inference.py:105-110) is identical on oracle and reference outputs
+    for cfg in ((26, 0.05, None), (26, 0.0, 4)):
+        a = peaks_ref.find_N_peaks(peaks_ref.sigmoid_f32(cor.numpy()[0, 0]), *cfg)[0]
+        b = peaks_ref.find_N_peaks(peaks_ref.sigmoid_f32(g["cor"][0, 0]), *cfg)[0]
+        assert np.array_equal(a, b)
+
+
+def test_forward_rejects_other_sizes():
+    with pytest.raises(NotImplementedError):
+        horizonnet_ref.forward(torch.zeros(1, 3, 256, 512), {})
+
+
+def test_panostretch_oracle_small(golden_dir):
+    g = np.load(os.path.join(golden_dir, "panostretch.npz"))
+    for j, (kx, ky) in enumerate(g["small_params"].tolist()):
+        out, _ = panostretch_ref.pano_stretch(g["small_in_%d" % j], g["corners_in"][:2], kx, ky)
+        assert out.dtype == np.float32
+        assert np.array_equal(out, g["small_out_%d" % j])
+
+
+def test_panostretch_oracle_demo(golden_dir):
+    g = np.load(os.path.join(golden_dir, "panostretch.npz"))
+    img = np.load(os.path.join(golden_dir, "demo_input_u8.npz"))["img"].astype(np.float32) / 255.0
+    for i in (1, 4):   # kx != ky and the kx == ky wrap-discontinuity case
+        kx, ky = (float(v) for v in g["params"][i])   # python floats, as dataset.py:70-81 passes
+        out, cor = panostretch_ref.pano_stretch(img, g["corners_in"], kx, ky)
+        rows = np.concatenate([out[0:4], out[254:258], out[508:512]], 0)
+        cols = np.concatenate([out[:, 0:4], out[:, 1020:1024]], 1)
+        assert np.array_equal(rows, g["rows_%d" % i])
+        assert np.array_equal(cols, g["cols_%d" % i])
+        assert np.array_equal(out[::8, ::8], g["grid_%d" % i])
+        assert np.abs(cor - g["corners_%d" % i]).max() < 1e-9
+
+
+def test_scipy_wrap_kat():
+    # SURVEY.md section 4 KAT 1 (scipy 'wrap' has period n-1)
+    a = np.array([0, 1, 2, 3, 10], np.float64)
+    x = np.array([-0.5, -0.25, -0.01, 0, 0.5, 3.5, 4.0, 4.01, 4.25, 4.49, 4.5, 5.0])
+    c = panostretch_ref.scipy_wrap(x, 5)
+    i0 = np.floor(c).astype(int)
+    t = c - i0
+    got = (1 - t) * a[i0] + t * a[np.minimum(i0 + 1, 4)]
+    want = [6.5, 8.25, 9.93, 0, 0.5, 6.5, 10, 0.01, 0.25, 0.49, 0.5, 1.0]
+    assert np.allclose(got, want, atol=1e-12)
+
+
+def test_peaks_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "peaks.npz"))
+    for ci, (r, mv, n) in enumerate(g["cfgs"]):
+        n = None if n < 0 else int(n)
+        for j in range(g["signals"].shape[0]):
+            loc, _ = peaks_ref.find_N_peaks(g["signals"][j], r=int(r), min_v=float(mv), N=n)
+            assert np.array_equal(loc, g["loc_%d_%d" % (ci, j)])
+
+
+def test_maximum_filter_window_kat():
+    # SURVEY.md section 4 KAT 3: even window 26 covers [i-13, i+12], periodic
+    s = np.zeros(1024, np.float32)
+    s[100] = 1.0
+    m = peaks_ref.maximum_filter_wrap(s, 26)
+    assert np.array_equal(np.where(m == 1.0)[0], np.arange(88, 114))
+    s = np.zeros(1024, np.float32)
+    s[1020] = 1.0
+    m = peaks_ref.maximum_filter_wrap(s, 26)
+    assert set(np.where(m == 1.0)[0]) == set((np.arange(1008, 1034) % 1024).tolist())
