@@ -1,0 +1,186 @@
+"""bench.py -- HorizonNet hot-path throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+
+One "step" = one forward of the hot path (ResNet-50 column-feature extractor + height compression +
+bi-LSTM + head) over a batch of synthetic 512x1024 panoramas already resident in HBM.
+Workload = BASELINE.json configs[1]: batch 32 random panoramas, forward only, fp32, per GPU.
+Panoramas are independent units: each rank runs its own replica on its own batch (weak scaling,
+no data-path collective); RCCL is used only for the barrier and the max-over-ranks timing.
+
+Prints ONE JSON line (rank 0) with `roofline` (whole forward vs the fp32 MFMA roof, HIP events on the
+launch stream over the timed region; per-kernel-family breakdown from a separate profiled pass) and
+`cpu_baseline` (the oracle restatement of the reference forward timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FWD_FLOP_PER_PANO = 2.0 * 71_448_920_064          # BASELINE.md section 3 / SURVEY.md section 8(d)
+PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: FP32 matrix peak (spec)
+
+
+def shard_for_rank(global_units, world, rank):
+    """Contiguous [start, end) slice of `global_units` independent panoramas owned by `rank`."""
+    base, rem = divmod(global_units, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (CPU restatement of the reference forward, torch fp32 on the host cores), bounded sample."""
+    from oracle import horizonnet_ref
+    from oracle.weights import make_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = make_state_dict(0, "random")
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(0))
+    horizonnet_ref.forward(x[:1], sd)                  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        horizonnet_ref.forward(x, sd)
+        n += x.shape[0]
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 16:
+            break
+    return {"value": n / el, "unit": "panoramas/s", "cores": cores, "kind": "port",
+            "sample": "%d panoramas (batches of 2) through oracle.horizonnet_ref.forward, torch %s fp32, %d threads, %.1f s"
+                      % (n, torch.__version__, cores, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="panoramas per GPU per step (configs[1]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from horizonnet_amd import HorizonNet
+    from oracle.weights import make_state_dict       # seeded random-init weights (no checkpoint offline)
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(0, "random"))
+    net = net.to(dev).eval()
+
+    B = args.batch
+    lo, hi = shard_for_rank(B * world, world, rank)   # weak scaling: B panoramas per rank
+    assert hi - lo == B
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x = torch.rand(B, 3, 512, 1024, generator=g).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        barrier()
+        stream = torch.cuda.current_stream(dev)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)                              # HIP events on the stream the kernels are launched on
+        for _ in range(args.steps):
+            bon, cor = net(x)
+        ev1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    assert net.hip_status(dev) == 0, "persistent LSTM kernel reported a spin time-out"
+    assert bool(torch.isfinite(bon).all()) and bool(torch.isfinite(cor).all())
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    if rank == 0:
+        total_panos = B * world * args.steps
+        value = total_panos / wall_max
+        # ---- roofline: whole forward as the unit, HIP-event time of the timed region ----
+        ms_per_fwd = dev_ms / args.steps
+        achieved_tflops = FWD_FLOP_PER_PANO * B / (ms_per_fwd * 1e-3) / 1e12
+        with torch.no_grad():
+            _, _, entries = net.profile_forward(x)
+        fam = {}
+        for name, ms, fl in entries:
+            if "ghc_lst" in name:
+                key = "height_compress_convs(conv_igemm_f32)"
+            elif "encoder.layer" in name:
+                key = "resnet_stage_convs(conv_igemm_f32)"
+            elif name.startswith("stem"):
+                key = "stem(prep+conv_igemm_f32+maxpool)"
+            elif "input_gemm" in name:
+                key = "lstm_input_gemm(conv_igemm_f32)"
+            elif "recurrence" in name:
+                key = "lstm_recurrence(persistent)"
+            else:
+                key = "other(upsample,linear)"
+            a = fam.setdefault(key, [0.0, 0.0])
+            a[0] += ms
+            a[1] += fl
+        prof_total = sum(v[0] for v in fam.values())
+        breakdown = {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0.0,
+                         "share": round(v[0] / prof_total, 3)} for k, v in fam.items()}
+        igemm_ms = sum(v[0] for k, v in fam.items() if "conv_igemm" in k)
+        igemm_fl = sum(v[1] for k, v in fam.items() if "conv_igemm" in k)
+        out = {
+            "metric": "panoramas/s (512x1024 fwd)",
+            "value": round(value, 2),
+            "unit": "panoramas/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall_max / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=32 random 512x1024 panos per GPU, ResNet-50 + height-compression + bi-LSTM forward, fp32, seeded random-init weights",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d (independent replicas, no data-path collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": "hn_forward (all launches of one forward; conv_igemm_f32 family = %.0f%% of device time)" % (100.0 * igemm_ms / prof_total),
+                         "achieved": round(achieved_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "algorithmic_flop_per_launch": FWD_FLOP_PER_PANO * B,
+                         "launch_ms_hip_events": round(ms_per_fwd, 3),
+                         "conv_igemm_f32": {"ms": round(igemm_ms, 3), "tflops": round(igemm_fl / (igemm_ms * 1e-3) / 1e12, 2),
+                                            "frac": round(igemm_fl / (igemm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "breakdown": breakdown},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,19 @@
+"""horizonnet_amd -- MI355X (gfx950) engine for the HorizonNet hot path.
+
+Drop-in surface (same names / arguments / error behaviour as the reference):
+
+* ``HorizonNet(backbone, use_rnn)``            -- reference ``model.py:185-281``
+* ``pano_stretch(img, corners, kx, ky)``        -- reference ``misc/panostretch.py:81-117``
+* ``find_N_peaks(signal, r, min_v, N)``         -- reference ``inference.py:21-29``
+
+All compute runs in hand-written HIP kernels behind the C ABI declared in
+``include/horizonnet_hip.h`` (``libhorizonnet_hip.so``, built in-tree by
+``horizonnet_amd/csrc/build.sh``).  There is no CPU or eager-PyTorch fallback:
+importing the compute entry points without the library, or calling them with
+host tensors, raises.
+"""
+from .model import HorizonNet  # noqa: F401
+from .panostretch import pano_stretch, pano_stretch_batch  # noqa: F401
+from .peaks import find_N_peaks, find_peaks_batch  # noqa: F401
+
+__all__ = ["HorizonNet", "pano_stretch", "pano_stretch_batch", "find_N_peaks", "find_peaks_batch"]

@@ -1,0 +1,80 @@
+"""ctypes binding of libhorizonnet_hip.so (the C ABI in include/horizonnet_hip.h).
+
+The library is the product: if it is missing or fails to load this module raises
+immediately -- there is deliberately no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhorizonnet_hip.so")
+
+_c = ctypes
+_vp, _i, _f, _sz, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_int64
+
+# name -> (restype, argtypes); mirrors include/horizonnet_hip.h one to one
+SIGNATURES = {
+    "hn_last_error": (_c.c_char_p, []),
+    "hn_abi_version": (_i, []),
+    "hn_create": (_i, [_c.POINTER(_vp), _i]),
+    "hn_destroy": (_i, [_vp]),
+    "hn_bind_tensor": (_i, [_vp, _c.c_char_p, _vp, _i64]),
+    "hn_packed_bytes": (_sz, []),
+    "hn_pack_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "hn_workspace_bytes": (_sz, [_i]),
+    "hn_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hn_check_status": (_i, [_vp, _vp, _c.POINTER(_i)]),
+    "hn_set_profiling": (_i, [_vp, _i]),
+    "hn_profile_count": (_i, [_vp]),
+    "hn_profile_entry": (_i, [_vp, _i, _c.c_char_p, _i, _c.POINTER(_f), _c.POINTER(_c.c_double)]),
+    "hn_pano_stretch": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _i, _i, _i, _i, _vp]),
+    "hn_find_peaks": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "hn_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "hn_packed_conv_weight_floats": (_sz, [_i, _i, _i, _i]),
+    "hn_fold_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "hn_conv2d_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hn_stem": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hn_upsample_flatten": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hn_lstm_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "hn_linear_head": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libhorizonnet_hip.so not found at %s -- build it with horizonnet_amd/csrc/build.sh "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI drift, also fatal
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hn_last_error()
+        raise HipEngineError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,539 @@
+// C-ABI of libhorizonnet_hip.so: engine object, reference-state_dict binding, weight packing and
+// the eval-mode forward plan of HorizonNet(resnet50, use_rnn=True) -- reference model.py:254-281.
+// See include/horizonnet_hip.h for the contract of every entry point.
+#include "hn_common.h"
+#include "../../include/horizonnet_hip.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---- error reporting ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void hn_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* hn_last_error(void) { return g_err; }
+extern "C" int hn_abi_version(void) { return 1; }
+
+// ---- architecture table ------------------------------------------------------------------------
+namespace {
+
+constexpr int T_COLS = 256;      // sequence length = 1024 / step_cols (reference model.py:194,259)
+constexpr int IMG_H = 512, IMG_W = 1024;
+
+struct ConvLayer {
+    std::string wkey;            // "<...>.weight" (and ".bias" when has_bias)
+    std::string bnkey;           // "<...>" BatchNorm prefix
+    int cin, cout, k, has_bias;
+    size_t w_off, scale_off, shift_off;   // float offsets into the packed buffer
+};
+
+struct Arch {
+    std::vector<ConvLayer> convs;                 // order of the reference state_dict
+    std::unordered_map<std::string, int64_t> numel;   // every bindable key -> element count
+    // bottleneck index helpers
+    int stem = 0;
+    int block_first[4][6];                        // conv index of conv1 of layer li block j
+    int block_down[4];                            // conv index of downsample of layer li (block 0)
+    int ghc_first[4];                             // conv index of ghc_lst[s].layer[0]
+    size_t wih_off[2], lbias_off[2], whh_off[2][2], ones_off, zeros_off, linw_off, linb_off;
+    size_t packed_floats = 0;
+};
+
+size_t packed_w_floats(int cout, int cin, int k)
+{
+    if (k == 7) return (size_t)cout * 7 * 8 * 4;
+    return (size_t)cout * k * k * cin;
+}
+
+const Arch& arch()
+{
+    static Arch A = [] {
+        Arch a;
+        auto add = [&](const std::string& w, const std::string& bn, int cin, int cout, int k, int bias) {
+            ConvLayer c{w, bn, cin, cout, k, bias, 0, 0, 0};
+            a.convs.push_back(c);
+            return (int)a.convs.size() - 1;
+        };
+        const std::string enc = "feature_extractor.encoder.";
+        a.stem = add(enc + "conv1.1", enc + "bn1", 3, 64, 7, 0);
+        const int planes_l[4] = {64, 128, 256, 512};
+        const int nblk[4] = {3, 4, 6, 3};
+        int cin = 64;
+        for (int li = 0; li < 4; ++li) {
+            for (int j = 0; j < nblk[li]; ++j) {
+                const std::string p = enc + "layer" + std::to_string(li + 1) + "." + std::to_string(j) + ".";
+                const int pl = planes_l[li];
+                a.block_first[li][j] = add(p + "conv1", p + "bn1", cin, pl, 1, 0);
+                add(p + "conv2.1", p + "bn2", pl, pl, 3, 0);
+                add(p + "conv3", p + "bn3", pl, pl * 4, 1, 0);
+                if (j == 0) a.block_down[li] = add(p + "downsample.0", p + "downsample.1", cin, pl * 4, 1, 0);
+                cin = pl * 4;
+            }
+        }
+        const int cs[4] = {256, 512, 1024, 2048};
+        for (int s = 0; s < 4; ++s) {
+            const int c = cs[s];
+            const int ch[5] = {c, c / 2, c / 2, c / 4, c / 8};
+            for (int k = 0; k < 4; ++k) {
+                const std::string p = "reduce_height_module.ghc_lst." + std::to_string(s) + ".layer." + std::to_string(k) + ".layers.";
+                const int idx = add(p + "0.1", p + "1", ch[k], ch[k + 1], 3, 1);
+                if (k == 0) a.ghc_first[s] = idx;
+            }
+        }
+        size_t off = 0;
+        auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };   // 256-byte aligned
+        for (auto& c : a.convs) {
+            c.w_off = take(packed_w_floats(c.cout, c.cin, c.k));
+            c.scale_off = take(c.cout);
+            c.shift_off = take(c.cout);
+            a.numel[c.wkey + ".weight"] = (int64_t)c.cout * c.cin * c.k * c.k;
+            if (c.has_bias) a.numel[c.wkey + ".bias"] = c.cout;
+            for (const char* nm : {".weight", ".bias", ".running_mean", ".running_var"}) a.numel[c.bnkey + nm] = c.cout;
+            a.numel[c.bnkey + ".num_batches_tracked"] = 1;
+        }
+        for (int l = 0; l < 2; ++l) {
+            a.wih_off[l] = take((size_t)4096 * 1024);
+            a.lbias_off[l] = take(4096);
+            for (int d = 0; d < 2; ++d) {
+                a.whh_off[l][d] = take((size_t)2048 * 512);
+                const std::string suf = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+                a.numel["bi_rnn.weight_ih" + suf] = 2048 * 1024;
+                a.numel["bi_rnn.weight_hh" + suf] = 2048 * 512;
+                a.numel["bi_rnn.bias_ih" + suf] = 2048;
+                a.numel["bi_rnn.bias_hh" + suf] = 2048;
+            }
+        }
+        a.ones_off = take(4096);
+        a.zeros_off = take(4096);
+        a.linw_off = take(12 * 1024);
+        a.linb_off = take(64);
+        a.numel["linear.weight"] = 12 * 1024;
+        a.numel["linear.bias"] = 12;
+        a.packed_floats = off;
+        return a;
+    }();
+    return A;
+}
+
+// ---- workspace plan ----------------------------------------------------------------------------
+struct Plan {
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y2, total;   // float offsets
+};
+
+Plan make_plan(int B)
+{
+    Plan p;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    const size_t b = (size_t)B;
+    p.sync = take(256);
+    p.xn = take(b * IMG_H * IMG_W * 4);
+    p.stem = take(b * 256 * 512 * 64);
+    p.pool = take(b * 128 * 256 * 64);
+    p.p0 = take(b * 128 * 256 * 256);
+    p.p1 = take(b * 128 * 256 * 256);
+    p.t1 = take(b * 128 * 256 * 128);     // largest conv1 output: layer2.0 (128 planes at 128x256)
+    p.t2 = take(b * 128 * 256 * 64);      // largest conv2 output: layer1 (64 planes at 128x256)
+    p.ds = take(b * 128 * 256 * 256);
+    p.g0 = take(b * 64 * 256 * 128);      // largest height-compression output: ghc0.0
+    p.g1 = take(b * 64 * 256 * 128);
+    p.seq = take((size_t)T_COLS * b * 1024);
+    p.gx = take((size_t)T_COLS * b * 4096);
+    p.y1 = take((size_t)T_COLS * b * 1024);
+    p.y2 = take((size_t)T_COLS * b * 1024);
+    p.total = off;
+    return p;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+struct ProfEntry {
+    std::string name;
+    double flops;                        // algorithmic FLOPs of the launch group (0 for pure data movement)
+    hipEvent_t t0, t1;
+};
+
+struct hn_engine {
+    int device = 0;
+    std::unordered_map<std::string, const void*> bound;
+    const float* packed = nullptr;       // last packed buffer (caller owned)
+    bool profiling = false;
+    std::vector<ProfEntry> prof;         // entries of the last profiled hn_forward
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    hipEvent_t next_event()
+    {
+        if (events_used == event_pool.size()) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+            event_pool.push_back(ev);
+        }
+        return event_pool[events_used++];
+    }
+};
+
+namespace {
+// RAII bracket: records start/stop events around one launch group when profiling is on.
+struct ProfScope {
+    hn_engine* e;
+    hipStream_t s;
+    bool on;
+    ProfScope(hn_engine* e_, hipStream_t s_, const std::string& name, double flops) : e(e_), s(s_), on(e_->profiling)
+    {
+        if (!on) return;
+        ProfEntry pe{name, flops, e->next_event(), e->next_event()};
+        e->prof.push_back(pe);
+        (void)hipEventRecord(pe.t0, s);
+    }
+    ~ProfScope()
+    {
+        if (on) (void)hipEventRecord(e->prof.back().t1, s);
+    }
+};
+}  // namespace
+
+// ---- engine API --------------------------------------------------------------------------------
+extern "C" int hn_create(hn_engine** out, int device)
+{
+    HN_REQUIRE(out != nullptr, "hn_create: out is null");
+    int n = 0;
+    HN_HIP(hipGetDeviceCount(&n));
+    HN_REQUIRE(device >= 0 && device < n, "hn_create: device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    HN_HIP(hipGetDeviceProperties(&prop, device));
+    HN_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "hn_create: device %d is %s; this library is built for gfx950 only",
+               device, prop.gcnArchName);
+    HN_REQUIRE(prop.multiProcessorCount >= 256, "hn_create: %d CUs visible; the persistent LSTM kernel needs 256 co-resident workgroups",
+               prop.multiProcessorCount);
+    hn_engine* e = new hn_engine();
+    e->device = device;
+    *out = e;
+    return 0;
+}
+
+extern "C" int hn_destroy(hn_engine* e)
+{
+    if (e)
+        for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    delete e;
+    return 0;
+}
+
+extern "C" int hn_set_profiling(hn_engine* e, int on)
+{
+    HN_REQUIRE(e != nullptr, "hn_set_profiling: null engine");
+    e->profiling = on != 0;
+    return 0;
+}
+
+extern "C" int hn_profile_count(hn_engine* e) { return e ? (int)e->prof.size() : 0; }
+
+extern "C" int hn_profile_entry(hn_engine* e, int i, char* name, int name_cap, float* ms, double* flops)
+{
+    HN_REQUIRE(e && name && ms && flops && i >= 0 && i < (int)e->prof.size(), "hn_profile_entry: bad index/argument");
+    const ProfEntry& pe = e->prof[i];
+    HN_HIP(hipEventSynchronize(pe.t1));
+    HN_HIP(hipEventElapsedTime(ms, pe.t0, pe.t1));
+    snprintf(name, name_cap, "%s", pe.name.c_str());
+    *flops = pe.flops;
+    return 0;
+}
+
+extern "C" int hn_bind_tensor(hn_engine* e, const char* name, const void* ptr, int64_t numel)
+{
+    HN_REQUIRE(e && name && ptr, "hn_bind_tensor: null argument");
+    const Arch& a = arch();
+    auto it = a.numel.find(name);
+    HN_REQUIRE(it != a.numel.end(), "hn_bind_tensor: unknown state_dict key '%s'", name);
+    HN_REQUIRE(it->second == numel, "hn_bind_tensor: '%s' has %lld elements, expected %lld", name, (long long)numel,
+               (long long)it->second);
+    e->bound[name] = ptr;
+    return 0;
+}
+
+extern "C" size_t hn_packed_bytes(void) { return arch().packed_floats * sizeof(float); }
+
+extern "C" size_t hn_workspace_bytes(int B)
+{
+    if (B < 1) return 0;
+    return make_plan(B).total * sizeof(float);
+}
+
+extern "C" int hn_pack_weights(hn_engine* e, void* packed, size_t packed_bytes, void* stream)
+{
+    HN_REQUIRE(e && packed, "hn_pack_weights: null argument");
+    HN_REQUIRE(packed_bytes >= hn_packed_bytes(), "hn_pack_weights: packed buffer too small (%zu < %zu)", packed_bytes,
+               hn_packed_bytes());
+    const Arch& a = arch();
+    for (const auto& kv : a.numel) {
+        if (kv.first.size() > 19 && kv.first.compare(kv.first.size() - 19, 19, "num_batches_tracked") == 0) continue;
+        HN_REQUIRE(e->bound.count(kv.first) != 0, "hn_pack_weights: state_dict key '%s' was never bound", kv.first.c_str());
+    }
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_pack_weights: cannot select device %d", e->device);
+    hipStream_t s = (hipStream_t)stream;
+    float* P = reinterpret_cast<float*>(packed);
+    auto get = [&](const std::string& k) { return reinterpret_cast<const float*>(e->bound.at(k)); };
+    for (const auto& c : a.convs) {
+        if (int rc = hn_launch_pack_conv(get(c.wkey + ".weight"), P + c.w_off, c.cout, c.cin, c.k, c.k, s)) return rc;
+        if (int rc = hn_launch_fold_bn(get(c.bnkey + ".weight"), get(c.bnkey + ".bias"), get(c.bnkey + ".running_mean"),
+                                       get(c.bnkey + ".running_var"), c.has_bias ? get(c.wkey + ".bias") : nullptr,
+                                       P + c.scale_off, P + c.shift_off, c.cout, s))
+            return rc;
+    }
+    for (int l = 0; l < 2; ++l) {
+        for (int d = 0; d < 2; ++d) {
+            const std::string suf = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+            HN_HIP(hipMemcpyAsync(P + a.wih_off[l] + (size_t)d * 2048 * 1024, get("bi_rnn.weight_ih" + suf),
+                                  (size_t)2048 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HN_HIP(hipMemcpyAsync(P + a.whh_off[l][d], get("bi_rnn.weight_hh" + suf), (size_t)2048 * 512 * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+            if (int rc = hn_launch_add_vec(get("bi_rnn.bias_ih" + suf), get("bi_rnn.bias_hh" + suf),
+                                           P + a.lbias_off[l] + d * 2048, 2048, s))
+                return rc;
+        }
+    }
+    // ones / zeros vectors: scale of the LSTM input-projection "conv" (no BN there)
+    if (int rc = hn_launch_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, P + a.ones_off, P + a.zeros_off, 4096, s)) return rc;
+    HN_HIP(hipMemcpyAsync(P + a.linw_off, get("linear.weight"), 12 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HN_HIP(hipMemcpyAsync(P + a.linb_off, get("linear.bias"), 12 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->packed = P;
+    return 0;
+}
+
+namespace {
+
+int run_conv(hn_engine* e, const float* P, const ConvLayer& c, const float* x, float* y, const float* res, int B, int Hi,
+             int Wi, int sh, int sw, int relu, hipStream_t s)
+{
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.w = P + c.w_off; d.scale = P + c.scale_off; d.shift = P + c.shift_off; d.res = res; d.y = y;
+    d.B = B; d.Hi = Hi; d.Wi = Wi; d.Cin = c.cin; d.Cout = c.cout;
+    d.KH = c.k; d.KW = c.k; d.sh = sh; d.sw = sw; d.ph = c.k / 2; d.pw = c.k / 2;
+    d.Ho = (Hi + 2 * d.ph - c.k) / sh + 1;
+    d.Wo = (Wi + 2 * d.pw - c.k) / sw + 1;
+    d.relu = relu; d.ldy = c.cout; d.stem = 0;
+    ProfScope ps(e, s, c.wkey, 2.0 * B * d.Ho * d.Wo * (double)c.cout * c.cin * c.k * c.k);
+    return hn_launch_conv(d, s);
+}
+
+int run_gemm_rows(const float* x, const float* w, const float* scale, const float* shift, float* y, long rows, int K, int N,
+                  hipStream_t s)
+{
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.w = w; d.scale = scale; d.shift = shift; d.res = nullptr; d.y = y;
+    d.B = 1; d.Hi = 1; d.Wi = (int)rows; d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1; d.ph = 0; d.pw = 0;
+    d.Ho = 1; d.Wo = (int)rows; d.relu = 0; d.ldy = N; d.stem = 0;
+    return hn_launch_conv(d, s);
+}
+
+}  // namespace
+
+extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                          size_t workspace_bytes, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward: null argument");
+    HN_REQUIRE(e->packed != nullptr, "hn_forward: hn_pack_weights has not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward: bad B=%d / C_in=%d", B, C_in);
+    HN_REQUIRE((size_t)B * 128 * 256 <= 0x7fffffffull / 2, "hn_forward: batch %d too large for 32-bit row indices", B);
+    const Plan pl = make_plan(B);
+    HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_forward: workspace too small (%zu < %zu)", workspace_bytes,
+               pl.total * sizeof(float));
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward: cannot select device %d", e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const Arch& a = arch();
+    const float* P = e->packed;
+    float* W = reinterpret_cast<float*>(workspace);
+    int rc;
+
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, 256 * sizeof(float), s));
+    e->prof.clear();
+    e->events_used = 0;
+
+    // stem: normalise + 7x7/2 conv + BN + ReLU, then 3x3/2 max-pool  (model.py:248-252,73-76)
+    {
+        const ConvLayer& c = a.convs[a.stem];
+        ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
+        if ((rc = hn_stem(x, B, C_in, IMG_H, IMG_W, P + c.w_off, P + c.scale_off, P + c.shift_off, W + pl.xn, W + pl.stem,
+                          W + pl.pool, stream)))
+            return rc;
+    }
+
+    // ResNet-50 stages (model.py:78-81) + per-scale height compression (model.py:138-156,172-179)
+    const float* cur = W + pl.pool;
+    int H = 128, Wd = 256;
+    const int nblk[4] = {3, 4, 6, 3};
+    for (int li = 0; li < 4; ++li) {
+        for (int j = 0; j < nblk[li]; ++j) {
+            const int stride = (j == 0 && li > 0) ? 2 : 1;
+            const ConvLayer& c1 = a.convs[a.block_first[li][j]];
+            const ConvLayer& c2 = a.convs[a.block_first[li][j] + 1];
+            const ConvLayer& c3 = a.convs[a.block_first[li][j] + 2];
+            float* out = (cur == W + pl.p0) ? W + pl.p1 : W + pl.p0;
+            if ((rc = run_conv(e, P, c1, cur, W + pl.t1, nullptr, B, H, Wd, 1, 1, 1, s))) return rc;
+            if ((rc = run_conv(e, P, c2, W + pl.t1, W + pl.t2, nullptr, B, H, Wd, stride, stride, 1, s))) return rc;
+            const float* idt = cur;
+            if (j == 0) {
+                const ConvLayer& cd = a.convs[a.block_down[li]];
+                if ((rc = run_conv(e, P, cd, cur, W + pl.ds, nullptr, B, H, Wd, stride, stride, 0, s))) return rc;
+                idt = W + pl.ds;
+            }
+            H /= stride;
+            Wd /= stride;
+            if ((rc = run_conv(e, P, c3, W + pl.t2, out, idt, B, H, Wd, 1, 1, 1, s))) return rc;
+            cur = out;
+        }
+        // GlobalHeightConv for this scale
+        const float* gin = cur;
+        int gh = H;
+        float* gbuf[2] = {W + pl.g0, W + pl.g1};
+        for (int k = 0; k < 4; ++k) {
+            const ConvLayer& gc = a.convs[a.ghc_first[li] + k];
+            float* gout = gbuf[k & 1];
+            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s))) return rc;
+            gin = gout;
+            gh /= 2;
+        }
+        const int cq = a.convs[a.ghc_first[li] + 3].cout;
+        {
+            ProfScope ps(e, s, "upsample_flatten." + std::to_string(li), 0.0);
+            if ((rc = hn_launch_upsample_flatten(gin, W + pl.seq, B, gh, Wd, cq, 256 * li, s))) return rc;
+        }
+    }
+
+    // bi-LSTM x2 + Linear head (model.py:263-269)
+    const long rows = (long)T_COLS * B;
+    const float* lin = W + pl.seq;
+    float* ybuf[2] = {W + pl.y1, W + pl.y2};
+    for (int l = 0; l < 2; ++l) {
+        {
+            ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".input_gemm", 2.0 * rows * 1024.0 * 4096);
+            if ((rc = run_gemm_rows(lin, P + a.wih_off[l], P + a.ones_off, P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
+        }
+        {
+            ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".recurrence", 2.0 * rows * 512.0 * 2048 * 2);
+            if ((rc = hn_launch_lstm_layer(W + pl.gx, P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s)))
+                return rc;
+        }
+        lin = ybuf[l];
+    }
+    ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
+    return hn_launch_linear_head(W + pl.y2, P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
+}
+
+extern "C" int hn_check_status(hn_engine* e, void* workspace, int* status_out)
+{
+    HN_REQUIRE(e && workspace && status_out, "hn_check_status: null argument");
+    DeviceGuard guard(e->device);
+    unsigned st = 0;
+    const unsigned* w = reinterpret_cast<const unsigned*>(reinterpret_cast<float*>(workspace) + make_plan(1).sync) + 64;
+    HN_HIP(hipMemcpy(&st, w, sizeof(st), hipMemcpyDeviceToHost));
+    *status_out = (int)st;
+    return 0;
+}
+
+// ---- per-stage entry points --------------------------------------------------------------------
+extern "C" size_t hn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW)
+{
+    (void)KW;
+    return packed_w_floats(Cout, Cin, KH);
+}
+
+extern "C" int hn_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream)
+{
+    HN_REQUIRE(w_oihw && w_packed, "hn_pack_conv_weight: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3 || (KH == 7 && Cin == 3)), "hn_pack_conv_weight: unsupported %dx%d", KH, KW);
+    return hn_launch_pack_conv(w_oihw, w_packed, Cout, Cin, KH, KW, (hipStream_t)stream);
+}
+
+extern "C" int hn_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
+                          float* scale, float* shift, int C, void* stream)
+{
+    HN_REQUIRE(scale && shift && C > 0, "hn_fold_bn: bad argument");
+    const int n = (gamma != nullptr) + (beta != nullptr) + (mean != nullptr) + (var != nullptr);
+    HN_REQUIRE(n == 0 || n == 4, "hn_fold_bn: gamma/beta/mean/var must be all set or all NULL");
+    return hn_launch_fold_bn(gamma, beta, mean, var, bias, scale, shift, C, (hipStream_t)stream);
+}
+
+extern "C" int hn_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* shift,
+                              const float* res, float* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh,
+                              int sw, int relu, void* stream)
+{
+    HN_REQUIRE(x && w_packed && scale && shift && y, "hn_conv2d_nhwc: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_nhwc: kernel %dx%d unsupported (1x1 / 3x3)", KH, KW);
+    HN_REQUIRE(B >= 1 && Hi >= 1 && Wi >= 1 && sh >= 1 && sw >= 1, "hn_conv2d_nhwc: bad geometry");
+    HN_REQUIRE(KW / 2 <= Wi, "hn_conv2d_nhwc: circular pad wider than the image");
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.w = w_packed; d.scale = scale; d.shift = shift; d.res = res; d.y = y;
+    d.B = B; d.Hi = Hi; d.Wi = Wi; d.Cin = Cin; d.Cout = Cout; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw;
+    d.ph = KH / 2; d.pw = KW / 2;
+    d.Ho = (Hi + 2 * d.ph - KH) / sh + 1;
+    d.Wo = (Wi + 2 * d.pw - KW) / sw + 1;
+    HN_REQUIRE((long)B * d.Ho * d.Wo < 0x7fffffffL, "hn_conv2d_nhwc: too many output pixels");
+    d.relu = relu; d.ldy = Cout; d.stem = 0;
+    return hn_launch_conv(d, (hipStream_t)stream);
+}
+
+extern "C" int hn_stem(const float* x_nchw, int B, int C_in, int H, int W, const float* w_packed, const float* scale,
+                       const float* shift, float* tmp_nhwc4, float* stem_out, float* pool_out, void* stream)
+{
+    HN_REQUIRE(x_nchw && w_packed && scale && shift && tmp_nhwc4 && stem_out && pool_out, "hn_stem: null pointer");
+    HN_REQUIRE(B >= 1 && C_in >= 3 && H % 4 == 0 && W % 4 == 0 && W >= 8, "hn_stem: bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = hn_launch_prep_nhwc4(x_nchw, tmp_nhwc4, B, C_in, H, W, s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = tmp_nhwc4; d.w = w_packed; d.scale = scale; d.shift = shift; d.res = nullptr; d.y = stem_out;
+    d.B = B; d.Hi = H; d.Wi = W; d.Cin = 4; d.Cout = 64; d.KH = 7; d.KW = 7; d.sh = 2; d.sw = 2; d.ph = 3; d.pw = 3;
+    d.Ho = H / 2; d.Wo = W / 2; d.relu = 1; d.ldy = 64; d.stem = 1;
+    if ((rc = hn_launch_conv(d, s))) return rc;
+    return hn_launch_maxpool(stem_out, pool_out, B, H / 2, W / 2, 64, s);
+}
+
+extern "C" int hn_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int cq, int col0, void* stream)
+{
+    HN_REQUIRE(in && seq && B >= 1 && hq >= 1 && cq >= 1, "hn_upsample_flatten: bad argument");
+    return hn_launch_upsample_flatten(in, seq, B, hq, Wq, cq, col0, (hipStream_t)stream);
+}
+
+extern "C" int hn_lstm_layer(const float* gx, const float* whh_fwd, const float* whh_rev, float* y, int T, int B,
+                             void* sync_ws, void* stream)
+{
+    HN_REQUIRE(gx && whh_fwd && whh_rev && y && sync_ws, "hn_lstm_layer: null pointer");
+    HN_HIP(hipMemsetAsync(sync_ws, 0, 256 * sizeof(float), (hipStream_t)stream));
+    return hn_launch_lstm_layer(gx, whh_fwd, whh_rev, y, T, B, sync_ws, (hipStream_t)stream);
+}
+
+extern "C" int hn_linear_head(const float* y, const float* w, const float* bias, float* bon, float* cor, int T, int B,
+                              void* stream)
+{
+    HN_REQUIRE(y && w && bias && bon && cor && T >= 1 && B >= 1, "hn_linear_head: bad argument");
+    return hn_launch_linear_head(y, w, bias, bon, cor, T, B, (hipStream_t)stream);
+}

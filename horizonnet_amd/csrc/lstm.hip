@@ -1,0 +1,177 @@
+// Persistent bidirectional LSTM layer for gfx950 (hidden 512, gates i,f,g,o).
+//
+// Replaces the cuDNN/MKLDNN `nn.LSTM` delegate at reference model.py:222-227,263-264 for the
+// recurrent half of a layer; the input projection gx = x @ W_ih^T + b_ih + b_hh is one implicit-
+// GEMM launch (conv_igemm_f32.hip, 1x1 "conv") done before this kernel.
+//
+// One launch walks all T steps of BOTH directions for up to 32 panoramas:
+//   * 256 workgroups (one per CU), 128 per direction; workgroup j of a direction owns hidden
+//     units [4j, 4j+4) = 16 gate rows of W_hh.  Its W_hh slice (16 x 512 floats) lives in
+//     REGISTERS for the whole sequence (each of the 4 waves holds its 128-wide k-range as the
+//     B operand of v_mfma_f32_16x16x4_f32: 8 x float4 per lane), the cell state c lives in the
+//     registers of the 128 "gate" threads.
+//   * per step: h_{t-1} (all 512 units, [<=32][512]) is read straight from the layer output y
+//     (L2), 4 waves x 64 MFMAs produce k-partial gate pre-activations, reduced through LDS, the
+//     gate threads apply sigmoid/tanh and write h_t into y -- which IS the hand-off buffer.
+//   * hand-off between workgroups: per-direction monotonic arrival counter, agent-scope release
+//     by one lane after the stores, relaxed polling + ONE agent-scope acquire on the consumer
+//     (cdna guide G16).  Placement independent; every spin is bounded and reports through a
+//     status word instead of hanging.
+#include "hn_common.h"
+
+namespace {
+
+constexpr int LSTM_H = 512;
+constexpr int LSTM_U = 4;                    // hidden units per workgroup
+constexpr int LSTM_NB = LSTM_H / LSTM_U;     // 128 workgroups per direction
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr int CNT_STRIDE = 32;               // counters 128 bytes apart
+constexpr int STATUS_WORD = 64;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int BT>   // 16-row batch tiles per launch (1: <=16 panoramas, 2: <=32)
+__global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ gx, const float* __restrict__ whh_f,
+                                                         const float* __restrict__ whh_r, float* y, int T, int B,
+                                                         int b0, int bc, unsigned* sync)
+{
+    __shared__ __attribute__((aligned(16))) float red[4 * BT * 16 * 17];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int dir = blockIdx.x & 1;
+    const int u0 = (blockIdx.x >> 1) * LSTM_U;
+    const float* whh = dir ? whh_r : whh_f;
+    unsigned* cnt = sync + dir * CNT_STRIDE;
+
+    // ---- W_hh fragments: B[k][n], n = gate*4 + unit -> row gate*512 + u0 + unit --------------
+    const int fn = lane & 15;
+    const int kq = lane >> 4;
+    const int koff = wave * 128 + kq * 4;    // + s*16 + q
+    f32x4 wf[8];
+    {
+        const float* wr = whh + (size_t)((fn >> 2) * LSTM_H + u0 + (fn & 3)) * LSTM_H + koff;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wf[s] = *reinterpret_cast<const f32x4*>(wr + s * 16);
+    }
+
+    // ---- gate-thread role ----
+    const bool gate_thread = tid < BT * 16 * LSTM_U;
+    const int gb = tid >> 2;                 // batch row within the chunk
+    const int gu = tid & 3;                  // unit within the workgroup
+    const bool gate_live = gate_thread && gb < bc;
+    float c_state = 0.f;
+
+    // A-operand rows (clamped: padding rows compute garbage that is never stored)
+    int arow[BT];
+#pragma unroll
+    for (int tl = 0; tl < BT; ++tl) {
+        const int r = tl * 16 + fn;
+        arow[tl] = b0 + (r < bc ? r : 0);
+    }
+
+    bool failed = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gate_live) {
+            const float* g = gx + ((size_t)t * B + b0 + gb) * 4096 + dir * 2048 + u0 + gu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gxv[q] = g[q * LSTM_H];
+        }
+
+        f32x4 acc[BT];
+#pragma unroll
+        for (int tl = 0; tl < BT; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            if (tid == 0 && !failed) {
+                const unsigned want = (unsigned)LSTM_NB * (unsigned)step;
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) {
+                        __hip_atomic_store(sync + STATUS_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        failed = true;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+
+            const int tp = dir ? t + 1 : t - 1;
+            f32x4 hf[BT][8];
+#pragma unroll
+            for (int tl = 0; tl < BT; ++tl) {
+                const float* hr = y + ((size_t)tp * B + arow[tl]) * 1024 + dir * LSTM_H + koff;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) hf[tl][s] = *reinterpret_cast<const f32x4*>(hr + s * 16);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tl = 0; tl < BT; ++tl)
+                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf[tl][s][q], wf[s][q], acc[tl], 0, 0, 0);
+        }
+
+        // k-partials -> LDS: red[wave][tile][row b][col n], row stride 17
+#pragma unroll
+        for (int tl = 0; tl < BT; ++tl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((wave * BT + tl) * 16 + kq * 4 + r) * 17 + fn] = acc[tl][r];
+        __syncthreads();
+
+        if (gate_thread) {
+            float pre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = gxv[q];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += red[((w * BT + (gb >> 4)) * 16 + (gb & 15)) * 17 + q * 4 + gu];
+                pre[q] = s;
+            }
+            const float ig = sigmoidf_(pre[0]);
+            const float fg = sigmoidf_(pre[1]);
+            const float gg = tanhf(pre[2]);
+            const float og = sigmoidf_(pre[3]);
+            c_state = fg * c_state + ig * gg;
+            const float h = og * tanhf(c_state);
+            if (gate_live) y[((size_t)t * B + b0 + gb) * 1024 + dir * LSTM_H + u0 + gu] = h;
+        }
+
+        // publish h_t: every storing wave drains, one lane releases at agent scope, then arrives
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r, float* y, int T, int B,
+                         void* sync_ws, hipStream_t s)
+{
+    HN_REQUIRE(T >= 1 && B >= 1, "lstm: bad T/B");
+    unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int bc = (B - b0) < 32 ? (B - b0) : 32;
+        HN_HIP(hipMemsetAsync(sync, 0, 2 * CNT_STRIDE * sizeof(unsigned), s));   // counters only; status is sticky
+        if (bc <= 16)
+            hipLaunchKernelGGL(lstm_layer_kernel<1>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync);
+        else
+            hipLaunchKernelGGL(lstm_layer_kernel<2>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync);
+        HN_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,255 @@
+"""``HorizonNet(nn.Module)`` -- same constructor, attributes, 448-key ``state_dict`` and
+``forward`` contract as reference ``model.py:185-281``; the forward runs in the HIP engine.
+
+The module tree below holds ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.LSTM`` /
+``nn.Linear`` objects purely as PARAMETER CONTAINERS, so that
+``misc/utils.load_trained_model`` (reference ``misc/utils.py:61-65``), ``save_model``
+(``:49-58``), ``feature_extractor.list_blocks()`` freezing (``train.py:200-208``), the
+``bn_momentum`` loop (``train.py:210-213``) and ``flatten_parameters`` (``train.py:39-42``)
+keep working unchanged.  None of the containers' own ``forward`` methods is ever called.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))     # (bottleneck width, blocks) of ResNet-50
+
+
+class LR_PAD(nn.Module):
+    """Marker for circular left/right padding (reference model.py:32-39).  The padding itself is
+    index arithmetic inside the HIP convolution's tile loader; this module only keeps the
+    reference's ``Sequential(LR_PAD, Conv2d)`` naming (``...conv2.1.weight``)."""
+
+    def __init__(self, padding=1):
+        super().__init__()
+        self.padding = padding
+
+    def forward(self, x):
+        raise RuntimeError("LR_PAD is a parameter-tree marker; the HIP engine applies the circular padding")
+
+
+def _lr_conv(cin, cout, k, stride, bias):
+    p = k // 2
+    return nn.Sequential(LR_PAD(p), nn.Conv2d(cin, cout, k, stride=stride, padding=(p, 0), bias=bias))
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, width, stride, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = _lr_conv(width, width, 3, stride, False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(width * 4))
+
+
+class _ResNet50Trunk(nn.Module):
+    """Children in torchvision's order (conv1, bn1, relu, maxpool, layer1..4) because
+    ``list_blocks`` slices ``children()`` positionally (reference model.py:84-91)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _lr_conv(3, 64, 7, 2, False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        cin = 64
+        for i, (width, n) in enumerate(_STAGES):
+            blocks = []
+            for j in range(n):
+                blocks.append(_Bottleneck(cin, width, 2 if (j == 0 and i > 0) else 1, j == 0))
+                cin = width * 4
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class Resnet(nn.Module):
+    def __init__(self, backbone="resnet50"):
+        super().__init__()
+        self.encoder = _ResNet50Trunk()
+
+    def list_blocks(self):
+        ch = list(self.encoder.children())
+        return ch[:4], ch[4:5], ch[5:6], ch[6:7], ch[7:8]
+
+
+class ConvCompressH(nn.Module):
+    def __init__(self, in_c, out_c, ks=3):
+        super().__init__()
+        assert ks % 2 == 1
+        self.layers = nn.Sequential(_lr_conv(in_c, out_c, ks, (2, 1), True), nn.BatchNorm2d(out_c),
+                                    nn.ReLU(inplace=True))
+
+
+class GlobalHeightConv(nn.Module):
+    def __init__(self, in_c, out_c):
+        super().__init__()
+        self.layer = nn.Sequential(ConvCompressH(in_c, in_c // 2), ConvCompressH(in_c // 2, in_c // 2),
+                                   ConvCompressH(in_c // 2, in_c // 4), ConvCompressH(in_c // 4, out_c))
+
+
+class GlobalHeightStage(nn.Module):
+    def __init__(self, c1, c2, c3, c4, out_scale=8):
+        super().__init__()
+        self.cs = c1, c2, c3, c4
+        self.out_scale = out_scale
+        self.ghc_lst = nn.ModuleList([GlobalHeightConv(c, c // out_scale) for c in self.cs])
+
+
+class _DeviceState:
+    """Per-device engine handle + packed weights + workspaces."""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.device = device
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.hn_create(ctypes.byref(h), device.index), "hn_create")
+        self.handle = h
+        self.packed = torch.empty(self.lib.hn_packed_bytes(), dtype=torch.uint8, device=device)
+        self.signature = None
+        self.keepalive = None
+        self.workspaces = {}
+
+    def workspace(self, B):
+        ws = self.workspaces.get(B)
+        if ws is None:
+            self.workspaces.clear()              # one batch size resident at a time
+            ws = torch.empty(self.lib.hn_workspace_bytes(B), dtype=torch.uint8, device=self.device)
+            self.workspaces[B] = ws
+        return ws
+
+    def __del__(self):
+        try:
+            self.lib.hn_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class HorizonNet(nn.Module):
+    x_mean = torch.FloatTensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    x_std = torch.FloatTensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+
+    def __init__(self, backbone, use_rnn):
+        super().__init__()
+        if backbone != "resnet50" or not use_rnn:
+            # north_star scope: resnet50_rnn only; fail like the reference does for
+            # unknown encoders (model.py:204) instead of silently building something else.
+            raise NotImplementedError("the MI355X engine implements backbone='resnet50', use_rnn=True only")
+        self.backbone = backbone
+        self.use_rnn = use_rnn
+        self.out_scale = 8
+        self.step_cols = 4
+        self.rnn_hidden_size = 512
+        self.feature_extractor = Resnet(backbone)
+        c1, c2, c3, c4 = 256, 512, 1024, 2048
+        c_last = (c1 * 8 + c2 * 4 + c3 * 2 + c4 * 1) // self.out_scale
+        self.reduce_height_module = GlobalHeightStage(c1, c2, c3, c4, self.out_scale)
+        self.bi_rnn = nn.LSTM(input_size=c_last, hidden_size=self.rnn_hidden_size, num_layers=2, dropout=0.5,
+                              batch_first=False, bidirectional=True)
+        self.drop_out = nn.Dropout(0.5)
+        self.linear = nn.Linear(2 * self.rnn_hidden_size, 3 * self.step_cols)
+        with torch.no_grad():                                  # head bias init, reference model.py:231-233
+            self.linear.bias[0 * self.step_cols:1 * self.step_cols].fill_(-1)
+            self.linear.bias[1 * self.step_cols:2 * self.step_cols].fill_(-0.478)
+            self.linear.bias[2 * self.step_cols:3 * self.step_cols].fill_(0.425)
+        self._hip_states = {}
+
+    # ---- engine plumbing --------------------------------------------------------------------
+    def _state_tensors(self):
+        for k, v in self.state_dict(keep_vars=True).items():
+            if not k.endswith("num_batches_tracked"):
+                yield k, v
+
+    def _hip_state(self, device):
+        st = self._hip_states.get(device.index)
+        if st is None:
+            st = _DeviceState(device)
+            self._hip_states[device.index] = st
+        tensors = list(self._state_tensors())
+        sig = tuple((t.data_ptr(), t._version) for _, t in tensors)
+        if sig != st.signature:
+            keep = []
+            for k, t in tensors:
+                if t.device != device:
+                    raise RuntimeError("parameter %s lives on %s but the input is on %s" % (k, t.device, device))
+                d = t.detach()
+                if d.dtype != torch.float32 or not d.is_contiguous():
+                    d = d.float().contiguous()
+                keep.append(d)
+                _lib.check(st.lib.hn_bind_tensor(st.handle, k.encode(), _lib.ptr(d), d.numel()), "hn_bind_tensor(%s)" % k)
+            _lib.check(st.lib.hn_pack_weights(st.handle, _lib.ptr(st.packed), st.packed.numel(),
+                                              _lib.stream_ptr(device)), "hn_pack_weights")
+            st.keepalive = keep
+            st.signature = sig
+        return st
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_hip_states"] = {}
+        return d
+
+    def forward(self, x):
+        if x.shape[2] != 512 or x.shape[3] != 1024:
+            raise NotImplementedError()
+        if not x.is_cuda:
+            raise RuntimeError("horizonnet_amd.HorizonNet runs on the MI355X HIP engine only: move the input "
+                               "(and the module) to a cuda/ROCm device; there is no CPU fallback")
+        if self.training:
+            raise NotImplementedError("train-mode forward/backward (dropout, batch-stat BN, autograd) is not built yet; "
+                                      "call .eval()")
+        B, C_in = int(x.shape[0]), int(x.shape[1])
+        if C_in < 3:
+            raise RuntimeError("expected at least 3 input channels")
+        xin = x.detach()
+        if xin.dtype != torch.float32 or not xin.is_contiguous():
+            xin = xin.float().contiguous()
+        with torch.cuda.device(x.device):
+            st = self._hip_state(x.device)
+            bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
+            cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
+            ws = st.workspace(B)
+            _lib.check(st.lib.hn_forward(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr(x.device)), "hn_forward")
+        return bon, cor
+
+    def profile_forward(self, x):
+        """One forward with per-launch-group HIP-event timing (hn_set_profiling).  Returns
+        (bon, cor, [(name, ms, algorithmic_flops), ...]); synchronises.  Not for timed regions."""
+        st = self._hip_state(x.device)
+        _lib.check(st.lib.hn_set_profiling(st.handle, 1), "hn_set_profiling")
+        try:
+            bon, cor = self.forward(x)
+            torch.cuda.synchronize(x.device)
+            entries = []
+            name = ctypes.create_string_buffer(256)
+            ms = ctypes.c_float()
+            fl = ctypes.c_double()
+            for i in range(st.lib.hn_profile_count(st.handle)):
+                _lib.check(st.lib.hn_profile_entry(st.handle, i, name, 256, ctypes.byref(ms), ctypes.byref(fl)),
+                           "hn_profile_entry")
+                entries.append((name.value.decode(), float(ms.value), float(fl.value)))
+        finally:
+            st.lib.hn_set_profiling(st.handle, 0)
+        return bon, cor, entries
+
+    def hip_status(self, device=None):
+        """Blocking read of the engine's device-side status word (0 = ok)."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        st = self._hip_states.get(device.index)
+        if st is None or not st.workspaces:
+            return 0
+        ws = next(iter(st.workspaces.values()))
+        val = ctypes.c_int(0)
+        _lib.check(st.lib.hn_check_status(st.handle, _lib.ptr(ws), ctypes.byref(val)), "hn_check_status")
+        return val.value

@@ -1,0 +1,156 @@
+/*
+ * horizonnet_hip.h -- C ABI of the MI355X (gfx950) HorizonNet hot-path engine.
+ *
+ * The reference (sunset1995/HorizonNet) is pure Python and has no FFI of its
+ * own; its hot path delegates to torch / torchvision / scipy native kernels.
+ * Each entry point below names the reference call site whose native delegate
+ * it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every data pointer is a DEVICE pointer owned by the caller (the PyTorch
+ *     caching allocator in the Python host); nothing here allocates device
+ *     memory for the caller's tensors.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  All work
+ *     is enqueued asynchronously on it; nothing here synchronises the device
+ *     except hn_check_status().
+ *   - return value: 0 = ok, non-zero = error; hn_last_error() returns the
+ *     message of the calling thread's last failure.  No exceptions cross the
+ *     boundary.
+ *   - re-entrant per (engine, stream); one engine per device
+ *     (nn.DataParallel replicas, reference train.py:190-192, call from one
+ *     Python thread per device).
+ *   - arithmetic is float32 (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 =
+ *     exact fmaf chains); pano-stretch coordinates are float64 like the
+ *     reference.
+ */
+#ifndef HORIZONNET_HIP_H
+#define HORIZONNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hn_engine hn_engine;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* hn_last_error(void);
+int hn_abi_version(void);
+
+/* ---- engine: HorizonNet.forward, reference model.py:254-281 ------------------------- */
+
+/* Create / destroy an engine bound to HIP device `device`. */
+int hn_create(hn_engine** out, int device);
+int hn_destroy(hn_engine* e);
+
+/* Bind one tensor of the reference state_dict (reference misc/utils.py:49-65 defines the
+ * checkpoint contract; the 448 keys are e.g. "feature_extractor.encoder.conv1.1.weight",
+ * "reduce_height_module.ghc_lst.0.layer.0.layers.0.1.bias", "bi_rnn.weight_ih_l0_reverse",
+ * "linear.weight").  `ptr` is a device pointer to contiguous float32 data (int64 for
+ * num_batches_tracked, which is ignored), `numel` its element count (checked against the
+ * architecture).  Unknown names and wrong sizes are errors. */
+int hn_bind_tensor(hn_engine* e, const char* name, const void* ptr, int64_t numel);
+
+/* Bytes the caller must provide for the packed (re-laid-out, BN-folded) weights. */
+size_t hn_packed_bytes(void);
+
+/* Pack every bound tensor into `packed` (device, hn_packed_bytes() bytes): conv weights
+ * OIHW -> [Cout][kh][kw][Cin]; eval-mode BatchNorm (eps 1e-5) folded with the conv bias
+ * into per-channel scale/shift (reference model.py:123-135 + torchvision Bottleneck);
+ * bi-LSTM input weights of both directions stacked, bias_ih+bias_hh summed
+ * (reference model.py:222-227).  Re-callable whenever the parameters change.
+ * All 448 tensors (minus the 69 num_batches_tracked) must have been bound. */
+int hn_pack_weights(hn_engine* e, void* packed, size_t packed_bytes, void* stream);
+
+/* Workspace (activations) bytes for batch size B. */
+size_t hn_workspace_bytes(int B);
+
+/* Eval-mode forward.  x: [B, C_in>=3, 512, 1024] float32 NCHW in [0,1] (only the first 3
+ * channels are read, reference model.py:252); bon: [B,2,1024], cor: [B,1,1024] float32.
+ * Replaces the body of HorizonNet.forward (reference model.py:254-281) for
+ * backbone='resnet50', use_rnn=True. */
+int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Blocking: reads back the device-side status word of the last hn_forward / hn_lstm_layer
+ * on this workspace (non-zero = the persistent LSTM kernel's bounded spin gave up). */
+int hn_check_status(hn_engine* e, void* workspace, int* status_out);
+
+/* Optional per-launch-group timing of hn_forward (HIP events on the caller's stream; used by
+ * bench.py for the roofline numbers, never inside the timed region).  After a profiled
+ * hn_forward: hn_profile_count() entries, each a name (the state_dict key of the conv, or a
+ * stage label), its elapsed milliseconds and its algorithmic FLOPs. */
+int hn_set_profiling(hn_engine* e, int on);
+int hn_profile_count(hn_engine* e);
+int hn_profile_entry(hn_engine* e, int i, char* name, int name_cap, float* ms, double* flops);
+
+/* ---- second boundary: misc/panostretch.py:81-102 (image half of pano_stretch) ------- */
+
+/* Batched Pano-Stretch warp.  src/dst: [B][H][W][C] float32 (HWC per image, exactly the
+ * numpy layout reference dataset.py:82 passes); kx, ky: HOST arrays of B doubles.
+ * Coordinates are generated on the fly in float64 (reference misc/panostretch.py:91-96) and
+ * sampled with scipy.ndimage.map_coordinates(order=1, mode='wrap') semantics (legacy wrap:
+ * period len-1).  One launch for the whole batch. */
+int hn_pano_stretch(const float* src, float* dst, const double* kx, const double* ky,
+                    int B, int H, int W, int C, void* stream);
+
+/* ---- corner-index extraction: inference.py:21-29 + :80 ------------------------------ */
+
+/* For each of B signals of length n (float32): optional sigmoid (apply_sigmoid != 0, as
+ * inference.py:80), periodic maximum filter of window r covering [i-r/2, i-r/2+r-1]
+ * (scipy maximum_filter mode='wrap'), peak mask[i] = (max==signal[i]) && signal[i] > min_v.
+ * mask: [B][n] uint8; prob: [B][n] float32 (the post-sigmoid signal) or NULL. */
+int hn_find_peaks(const float* signal, int B, int n, int r, float min_v, int apply_sigmoid,
+                  uint8_t* mask, float* prob, void* stream);
+
+/* ---- per-stage entry points (used by the parity tests; the engine calls the same code) */
+
+/* OIHW -> packed [Cout][kh][kw][Cin] (stem 7x7: [64][7][8][4] zero padded). */
+int hn_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW,
+                        void* stream);
+size_t hn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
+
+/* scale = gamma/sqrt(var+1e-5), shift = (bias-mean)*scale+beta.  Any of gamma/beta/mean/var
+ * may be NULL together (no BN: scale=1, shift=bias); bias may be NULL. */
+int hn_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var,
+               const float* bias, float* scale, float* shift, int C, void* stream);
+
+/* Fused conv + scale/shift (+residual) (+ReLU), NHWC float32, zero padding in H, CIRCULAR
+ * padding in W (reference model.py:27-55).  x: [B][Hi][Wi][Cin]; w: packed; y/res: [B][Ho][Wo][Cout].
+ * KHxKW in {1x1, 3x3}; Cin % 32 == 0; Cout % 32 == 0. */
+int hn_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* shift,
+                   const float* res, float* y, int B, int Hi, int Wi, int Cin, int Cout,
+                   int KH, int KW, int sh, int sw, int relu, void* stream);
+
+/* Stem: x NCHW [B][C_in][512][1024] -> normalise -> 7x7/2 conv (3->64) + scale/shift + ReLU ->
+ * 3x3/2 max-pool (ordinary padding).  tmp_nhwc4: [B][H][W][4]; stem_out: [B][H/2][W/2][64];
+ * pool_out: [B][H/4][W/4][64].  (reference model.py:248-252,73-76) */
+int hn_stem(const float* x_nchw, int B, int C_in, int H, int W, const float* w_packed,
+            const float* scale, const float* shift, float* tmp_nhwc4, float* stem_out,
+            float* pool_out, void* stream);
+
+/* Circular linear up-sampling along W to 256 columns + (c,h) flatten into the sequence
+ * matrix (reference model.py:151-155,175-178).  in: [B][hq][Wq][cq]; seq: [256*B][1024] with
+ * row = t*B + b and column = col0 + c*hq + h. */
+int hn_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int cq, int col0,
+                        void* stream);
+
+/* One bidirectional LSTM layer, hidden 512 (reference model.py:222-227,263-264).
+ * gx: [T*B][4096] = x @ [W_ih_fwd; W_ih_rev]^T + (b_ih + b_hh) (columns dir*2048 + gate*512 + unit,
+ * gates i,f,g,o); whh_fwd / whh_rev: [2048][512]; y: [T*B][1024] (fwd | rev).
+ * sync_ws: >= 256 bytes of device scratch for the grid barrier + status word. */
+int hn_lstm_layer(const float* gx, const float* whh_fwd, const float* whh_rev, float* y,
+                  int T, int B, void* sync_ws, void* stream);
+
+/* Linear(1024,12) + the (seq,step)->column interleave (reference model.py:266-269,278-279).
+ * y: [T*B][1024]; bon: [B][2][4T]; cor: [B][1][4T]. */
+int hn_linear_head(const float* y, const float* w, const float* bias, float* bon, float* cor,
+                   int T, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,354 @@
+"""GPU parity tests (-m gpu): every HIP stage and the whole forward, called through the C ABI,
+against the CPU oracle (oracle/) and the golden vectors captured from the reference.
+
+Tolerances: float32 path, north_star bar = 1e-3 max-abs on bon/cor; the per-stage checks use
+tighter scale-relative bounds.  Index work (peaks) is bit-exact.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from horizonnet_amd import HorizonNet, _lib, find_N_peaks, find_peaks_batch, pano_stretch, pano_stretch_batch  # noqa: E402
+from oracle import horizonnet_ref, panostretch_ref, peaks_ref  # noqa: E402
+from oracle.weights import make_state_dict  # noqa: E402
+
+from hiputil import DEV, P, conv_hip, lib, report, sp  # noqa: E402
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _bn(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2,
+            torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) * 1.5 + 0.5)
+
+
+def test_device_is_gfx950():
+    h = ctypes.c_void_p()
+    _lib.check(lib().hn_create(ctypes.byref(h), 0), "hn_create")
+    lib().hn_destroy(h)
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, bias, bn, relu, residual
+    ("1x1 64->64 tile64x64", 1, 8, 16, 64, 64, 1, 1, False, True, True, False),
+    ("1x1 ragged M, Cout 32 (128x32 tile)", 2, 5, 7, 32, 32, 1, 1, True, False, False, False),
+    ("3x3 s1 circular W", 2, 6, 8, 32, 64, 3, 1, False, True, True, False),
+    ("3x3 s2 (bottleneck conv2 of block 0)", 1, 8, 16, 64, 128, 3, 2, False, True, True, False),
+    ("3x3 s(2,1) bias (height compression)", 2, 8, 16, 64, 32, 3, (2, 1), True, True, True, False),
+    ("3x3 s(2,1) H=2->1 (ghc3.3 shape)", 2, 2, 32, 64, 128, 3, (2, 1), True, True, True, False),
+    ("1x1 s2 downsample no relu", 1, 8, 16, 64, 256, 1, 2, False, True, False, False),
+    ("1x1 + residual + relu (conv3)", 2, 8, 8, 64, 256, 1, 1, False, True, True, True),
+    ("1x1 big grid -> 128x128 tile", 2, 64, 256, 32, 256, 1, 1, False, True, True, True),
+    ("3x3 big grid -> 128x64 tile", 2, 64, 128, 32, 64, 3, 1, False, True, True, False),
+    ("3x3 W=1 (wrap onto itself)", 1, 4, 1, 32, 64, 3, 1, True, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_stage(case):
+    name, B, H, W, cin, cout, k, stride, has_bias, has_bn, relu, has_res = case
+    x = _rand((B, H, W, cin), 1)
+    w = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    bias = _rand((cout,), 3, 0.1) if has_bias else None
+    bn = _bn(cout, 4) if has_bn else None
+    want = horizonnet_ref.conv_bn_act_nhwc(x, w, bias, bn, stride, relu, None)
+    res = _rand(tuple(want.shape), 5) if has_res else None
+    if has_res:
+        want = horizonnet_ref.conv_bn_act_nhwc(x, w, bias, bn, stride, relu, res)
+    got = conv_hip(x, w, bias, bn, stride, relu, res)
+    assert tuple(got.shape) == tuple(want.shape)
+    assert report("conv " + name, got.numpy(), want.numpy(), 2e-5 * max(1.0, float(want.abs().max())))
+
+
+def test_conv_asymmetric_weights_detect_transpose():
+    # A = identity-like input, asymmetric W: catches a swapped row/col in the MFMA C-write (cdna guide G9)
+    cin = cout = 64
+    x = torch.zeros(1, 1, 64, cin)
+    for i in range(64):
+        x[0, 0, i, i] = 1.0
+    w = torch.arange(cout * cin, dtype=torch.float32).view(cout, cin, 1, 1) / 100.0
+    got = conv_hip(x, w, None, None, 1, False)
+    want = horizonnet_ref.conv_bn_act_nhwc(x, w, None, None, 1, False)
+    assert report("conv transpose probe", got.numpy(), want.numpy(), 1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,cin", [(2, 32, 64, 3), (1, 512, 1024, 4)])
+def test_stem_stage(B, H, W, cin):
+    L = lib()
+    sd = make_state_dict(3, "random")
+    enc = "feature_extractor.encoder."
+    x = torch.rand((B, cin, H, W), generator=torch.Generator().manual_seed(9))
+    xn = horizonnet_ref.prepare_x(x)
+    y = torch.relu(horizonnet_ref._bn(horizonnet_ref._conv(xn, sd, enc + "conv1.1", 2, 7), sd, enc + "bn1"))
+    want_stem = y.permute(0, 2, 3, 1).contiguous()
+    want_pool = torch.nn.functional.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    w = sd[enc + "conv1.1.weight"].to(DEV)
+    wp = torch.empty(L.hn_packed_conv_weight_floats(64, 3, 7, 7), device=DEV)
+    _lib.check(L.hn_pack_conv_weight(P(w), P(wp), 64, 3, 7, 7, sp()), "pack")
+    g, b, m, v = (sd[enc + "bn1." + k].to(DEV) for k in ("weight", "bias", "running_mean", "running_var"))
+    scale, shift = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    _lib.check(L.hn_fold_bn(P(g), P(b), P(m), P(v), None, P(scale), P(shift), 64, sp()), "fold")
+    xd = x.to(DEV)
+    tmp = torch.empty((B, H, W, 4), device=DEV)
+    stem = torch.full((B, H // 2, W // 2, 64), float("nan"), device=DEV)
+    pool = torch.full((B, H // 4, W // 4, 64), float("nan"), device=DEV)
+    _lib.check(L.hn_stem(P(xd), B, cin, H, W, P(wp), P(scale), P(shift), P(tmp), P(stem), P(pool), sp()), "stem")
+    torch.cuda.synchronize()
+    ok1 = report("stem conv+bn+relu %dx%d" % (H, W), stem.cpu().numpy(), want_stem.numpy(), 3e-5)
+    ok2 = report("stem maxpool %dx%d" % (H, W), pool.cpu().numpy(), want_pool.numpy(), 3e-5)
+    assert ok1 and ok2
+
+
+@pytest.mark.parametrize("hq,Wq,cq,col0", [(8, 256, 32, 0), (4, 128, 64, 256), (2, 64, 128, 512), (1, 32, 256, 768)])
+def test_upsample_flatten_stage(hq, Wq, cq, col0):
+    B = 3
+    x = _rand((B, cq, hq, Wq), 11)                                  # NCHW like the reference tensor
+    f = 256 // Wq
+    xp = torch.cat([x[..., -1:], x, x[..., :1]], 3)
+    up = torch.nn.functional.interpolate(xp, size=(hq, 256 + 2 * f), mode="bilinear", align_corners=False)[..., f:-f]
+    want = up.reshape(B, -1, 256).permute(2, 0, 1).contiguous()     # [256,B,256]
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)                # NHWC
+    seq = torch.zeros((256 * B, 1024), device=DEV)
+    _lib.check(lib().hn_upsample_flatten(P(xin), P(seq), B, hq, Wq, cq, col0, sp()), "upsample")
+    torch.cuda.synchronize()
+    got = seq.cpu().view(256, B, 1024)[:, :, col0:col0 + 256]
+    assert report("upsample x%d" % f, got.numpy(), want.numpy(), 2e-6)
+    rest = seq.cpu().view(256, B, 1024).clone()
+    rest[:, :, col0:col0 + 256] = 0
+    assert float(rest.abs().max()) == 0.0                            # writes only its own 256 columns
+
+
+@pytest.mark.parametrize("B", [1, 3, 16, 32, 37])
+def test_lstm_layer_stage(B):
+    T = 256
+    sd = make_state_dict(5, "random")
+    gx = _rand((T, B, 4096), 13, 2.0)
+    whh = [sd["bi_rnn.weight_hh_l0"], sd["bi_rnn.weight_hh_l0_reverse"]]
+    # oracle: same recurrence as oracle.horizonnet_ref.lstm_ref with the input projection given
+    outs = []
+    for d in range(2):
+        h = torch.zeros(B, 512)
+        c = torch.zeros(B, 512)
+        ys = [None] * T
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            g = gx[t, :, d * 2048:(d + 1) * 2048] + h @ whh[d].t()
+            i, f, gg, o = g.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            ys[t] = h
+        outs.append(torch.stack(ys, 0))
+    want = torch.cat(outs, 2)
+    gxd = gx.to(DEV).contiguous()
+    wf, wr = whh[0].to(DEV).contiguous(), whh[1].to(DEV).contiguous()
+    y = torch.full((T * B, 1024), float("nan"), device=DEV)
+    sync = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    _lib.check(lib().hn_lstm_layer(P(gxd), P(wf), P(wr), P(y), T, B, P(sync), sp()), "lstm")
+    torch.cuda.synchronize()
+    status = int(sync.cpu().view(torch.int32)[64])
+    assert status == 0, "persistent LSTM kernel reported a spin time-out"
+    assert report("bi-LSTM layer B=%d" % B, y.cpu().view(T, B, 1024).numpy(), want.numpy(), 2e-5)
+
+
+def test_linear_head_stage():
+    T, B = 256, 5
+    y = _rand((T, B, 1024), 17)
+    w = _rand((12, 1024), 18, 0.03)
+    b = _rand((12,), 19)
+    lin = (y @ w.t() + b).view(T, B, 3, 4).permute(1, 2, 0, 3).contiguous().view(B, 3, 4 * T)
+    bon = torch.empty((B, 2, 4 * T), device=DEV)
+    cor = torch.empty((B, 1, 4 * T), device=DEV)
+    _lib.check(lib().hn_linear_head(P(y.to(DEV).contiguous()), P(w.to(DEV)), P(b.to(DEV)), P(bon), P(cor), T, B, sp()), "head")
+    torch.cuda.synchronize()
+    assert report("linear head bon", bon.cpu().numpy(), lin[:, 1:].numpy(), 2e-5)
+    assert report("linear head cor", cor.cpu().numpy(), lin[:, :1].numpy(), 2e-5)
+
+
+def _net(seed, bn):
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(seed, bn), strict=True)
+    return net.to(DEV).eval()
+
+
+def _demo_x(golden_dir):
+    img = np.load(os.path.join(golden_dir, "demo_input_u8.npz"))["img"]
+    return torch.from_numpy(img.transpose(2, 0, 1)[None].astype(np.float32) / 255.0)
+
+
+@pytest.mark.parametrize("name", ["demo_seed0_bnrandom", "demo_seed1_bnidentity", "rand2_seed2_bnrandom"])
+def test_forward_matches_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "forward_%s.npz" % name))
+    if name.startswith("demo"):
+        x = _demo_x(golden_dir)
+    else:
+        x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(1234))
+    net = _net(int(g["seed"]), str(g["bn"]))
+    with torch.no_grad():
+        bon, cor = net(x.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert bon.shape == (x.shape[0], 2, 1024) and cor.shape == (x.shape[0], 1, 1024)
+    ok1 = report("forward %s bon" % name, bon.cpu().numpy(), g["bon"], 1e-3)
+    ok2 = report("forward %s cor" % name, cor.cpu().numpy(), g["cor"], 1e-3)
+    assert ok1 and ok2
+    # corner-index extraction must be identical on engine and reference outputs (inference.py:105-110)
+    for b in range(x.shape[0]):
+        for cfg in ((26, 0.05, None), (26, 0.0, 4)):
+            a = peaks_ref.find_N_peaks(torch.sigmoid(cor[b, 0]).cpu().numpy(), *cfg)[0]
+            r = peaks_ref.find_N_peaks(torch.sigmoid(torch.from_numpy(g["cor"][b, 0])).numpy(), *cfg)[0]
+            assert np.array_equal(a, r), (name, b, cfg)
+
+
+def test_forward_vs_oracle_batch_and_extra_channel():
+    # B=3 with a 4th (ignored) input channel, reference model.py:252 reads x[:, :3]
+    sd = make_state_dict(7, "random")
+    x = torch.rand(3, 4, 512, 1024, generator=torch.Generator().manual_seed(77))
+    torch.set_num_threads(os.cpu_count())
+    want_bon, want_cor = horizonnet_ref.forward(x, sd)
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    bon, cor = net(x.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert report("forward B=3 C_in=4 bon", bon.cpu().numpy(), want_bon.numpy(), 1e-3)
+    assert report("forward B=3 C_in=4 cor", cor.cpu().numpy(), want_cor.numpy(), 1e-3)
+
+
+def test_forward_full_batch32_consistency(golden_dir):
+    # BASELINE.json config 2 size (B=32): size-independent properties -- every panorama of the batch must
+    # equal the same panorama pushed through alone / in a small batch, and the run must be deterministic.
+    net = _net(0, "random")
+    g = torch.Generator().manual_seed(4321)
+    base = torch.rand(4, 3, 512, 1024, generator=g)
+    base[0] = _demo_x(golden_dir)[0]
+    idx = [(7 * i + 3) % 4 for i in range(32)]
+    big = base[idx].to(DEV)
+    with torch.no_grad():
+        bon32, cor32 = net(big)
+        bon32b, cor32b = net(big)
+        bon4, cor4 = net(base.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert torch.equal(bon32, bon32b) and torch.equal(cor32, cor32b), "non-deterministic forward"
+    ok = report("B=32 vs B=4 bon", bon32.cpu().numpy(), bon4.cpu().numpy()[idx], 1e-5)
+    ok &= report("B=32 vs B=4 cor", cor32.cpu().numpy(), cor4.cpu().numpy()[idx], 1e-5)
+    gold = np.load(os.path.join(golden_dir, "forward_demo_seed0_bnrandom.npz"))
+    k = idx.index(0)
+    ok &= report("B=32 slot holding demo.png vs reference golden", bon32[k:k + 1].cpu().numpy(), gold["bon"], 1e-3)
+    assert ok
+
+
+def test_module_contract_errors():
+    net = _net(0, "identity")
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 3, 256, 512, device=DEV))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 512, 1024))
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 3, 512, 1024, device=DEV))
+
+
+def test_weights_repack_after_update(golden_dir):
+    # the engine must notice parameter updates (load_state_dict / optimizer steps bump tensor versions)
+    x = _demo_x(golden_dir).to(DEV)
+    net = _net(0, "random")
+    bon0, _ = net(x)
+    net.load_state_dict(make_state_dict(1, "identity"))
+    bon1, cor1 = net(x)
+    g = np.load(os.path.join(golden_dir, "forward_demo_seed1_bnidentity.npz"))
+    assert report("after load_state_dict", bon1.cpu().numpy(), g["bon"], 1e-3)
+    assert float((bon0 - bon1).abs().max()) > 1e-3
+
+
+# ---- Pano-Stretch ------------------------------------------------------------------------------
+def test_pano_stretch_small_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "panostretch.npz"))
+    ok = True
+    for j, (kx, ky) in enumerate(g["small_params"].tolist()):
+        got, cor = pano_stretch(g["small_in_%d" % j], g["corners_in"][:2], kx, ky)
+        assert got.dtype == np.float32 and got.shape == g["small_out_%d" % j].shape
+        ok &= report("pano_stretch small %d" % j, got, g["small_out_%d" % j], 1e-6)
+    assert ok
+
+
+def test_pano_stretch_demo_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "panostretch.npz"))
+    img = np.load(os.path.join(golden_dir, "demo_input_u8.npz"))["img"].astype(np.float32) / 255.0
+    params = g["params"].tolist()
+    imgs = torch.from_numpy(img).to(DEV)[None].repeat(len(params), 1, 1, 1)
+    out = pano_stretch_batch(imgs, [p[0] for p in params], [p[1] for p in params]).cpu().numpy()
+    ok = True
+    for i, (kx, ky) in enumerate(params):
+        o = out[i]
+        rows = np.concatenate([o[0:4], o[254:258], o[508:512]], 0)
+        cols = np.concatenate([o[:, 0:4], o[:, 1020:1024]], 1)
+        if kx == ky:
+            # reference coordinates sit exactly ON SciPy's wrap discontinuity in column 0 (refx = 0 -+ 1e-13):
+            # compare everything except that column (SURVEY.md section 7 "Pano-Stretch coordinate precision")
+            sel = np.ones(1024, bool)
+            sel[0] = False
+            ok &= report("pano_stretch demo kx=ky=%.2f rows (col 0 excluded)" % kx, rows[:, sel], g["rows_%d" % i][:, sel], 1e-6)
+            ok &= report("pano_stretch demo kx=ky=%.2f grid (col 0 excluded)" % kx, o[::8, 8::8], g["grid_%d" % i][:, 1:], 1e-6)
+        else:
+            ok &= report("pano_stretch demo kx=%.2f ky=%.2f rows" % (kx, ky), rows, g["rows_%d" % i], 1e-6)
+            ok &= report("pano_stretch demo kx=%.2f ky=%.2f cols" % (kx, ky), cols, g["cols_%d" % i], 1e-6)
+            ok &= report("pano_stretch demo kx=%.2f ky=%.2f grid" % (kx, ky), o[::8, ::8], g["grid_%d" % i], 1e-6)
+        _, cor = pano_stretch(img[:8, :16], g["corners_in"], kx, ky)   # corner half: host closed form
+    assert ok
+
+
+def test_pano_stretch_vs_oracle_full_and_identity():
+    rng = np.random.RandomState(3)
+    img = rng.rand(512, 1024, 3).astype(np.float32)
+    want, _ = panostretch_ref.pano_stretch(img, np.zeros((1, 2), np.float32), 1.37, 0.71)
+    got, _ = pano_stretch(img, np.zeros((1, 2), np.float32), 1.37, 0.71)
+    assert report("pano_stretch full random image", got, want, 1e-6)
+    # kx = ky = 1 is the identity warp away from the wrap column / rows
+    ident, _ = pano_stretch(img, np.zeros((1, 2), np.float32), 1.0, 1.0)
+    assert report("pano_stretch identity (interior)", ident[1:-1, 1:-1], img[1:-1, 1:-1], 1e-5)
+
+
+def test_pano_stretch_edge_cases():
+    # empty batch, ragged sizes (W not a multiple of the 256-thread tile, H not of 8), many channels
+    empty = torch.empty((0, 8, 16, 3), device=DEV)
+    assert pano_stretch_batch(empty, [], []).shape == (0, 8, 16, 3)
+    rng = np.random.RandomState(5)
+    for (h, w, c) in [(9, 301, 3), (2, 2, 1), (33, 70, 7)]:
+        img = rng.rand(h, w, c).astype(np.float32)
+        want, _ = panostretch_ref.pano_stretch(img, np.zeros((1, 2), np.float32), 0.8, 1.6)
+        got, _ = pano_stretch(img, np.zeros((1, 2), np.float32), 0.8, 1.6)
+        assert report("pano_stretch ragged %dx%dx%d" % (h, w, c), got, want, 1e-6)
+    with pytest.raises(NotImplementedError):
+        pano_stretch(np.zeros((4, 8, 3), np.float32), np.zeros((1, 2)), 1.0, 1.0, order=0)
+
+
+# ---- corner-index extraction ---------------------------------------------------------------------
+def test_find_peaks_golden_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "peaks.npz"))
+    for ci, (r, mv, n) in enumerate(g["cfgs"]):
+        n = None if n < 0 else int(n)
+        for j in range(g["signals"].shape[0]):
+            loc, val = find_N_peaks(g["signals"][j], r=int(r), min_v=float(mv), N=n)
+            assert np.array_equal(loc, g["loc_%d_%d" % (ci, j)]), (ci, j)
+            assert np.array_equal(val, g["signals"][j][loc])
+
+
+def test_find_peaks_batch_sigmoid():
+    logits = _rand((6, 1024), 23, 4.0)
+    mask, prob = find_peaks_batch(logits.to(DEV), 26, 0.05, apply_sigmoid=True)
+    p = prob.cpu().numpy()
+    assert np.abs(p - torch.sigmoid(logits).numpy()).max() < 2e-7
+    for b in range(6):
+        want = peaks_ref.find_N_peaks(p[b], 26, 0.05, None)[0]      # exact on the device's own f32 probabilities
+        assert np.array_equal(np.where(mask[b].cpu().numpy())[0], want)
