@@ -40,7 +40,8 @@ def cpu_baseline(seconds_budget=20.0):
     """Oracle (CPU restatement of the reference forward, torch fp32 on the host cores), bounded sample."""
     from oracle import horizonnet_ref
     from oracle.weights import make_state_dict
-    cores = os.cpu_count() or 1
+    from oracle.hostinfo import usable_cores
+    cores = usable_cores()                           # cgroup-aware (the GPU box shows 256 CPUs, grants 16)
     torch.set_num_threads(cores)
     sd = make_state_dict(0, "random")
     x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(0))

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void pano_stretch_kernel(const float* __restri
     const double refx = (u0 / (2 * PI) + 0.5) * (double)W - 0.5;
     const double cx = scipy_wrap(refx, (double)(W - 1));
     const double fx = floor(cx);
-    const int x0 = (int)fx;
+    int x0 = (int)fx;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0);     // only NaN coordinates (odd W: u = 0 -> 0/0, as in the reference) get here
     const int x1 = x0 + 1 < W ? x0 + 1 : W - 1;
     const double wx1 = cx - fx, wx0 = 1.0 - wx1;
 
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void pano_stretch_kernel(const float* __restri
         const double refy = (v0 / PI + 0.5) * (double)H - 0.5;
         const double cy = scipy_wrap(refy, (double)(H - 1));
         const double fy = floor(cy);
-        const int yy0 = (int)fy;
+        int yy0 = (int)fy;
+        yy0 = yy0 < 0 ? 0 : (yy0 > H - 1 ? H - 1 : yy0);
         const int yy1 = yy0 + 1 < H ? yy0 + 1 : H - 1;
         const double wy1 = cy - fy, wy0 = 1.0 - wy1;
         const float* p00 = img + ((size_t)yy0 * W + x0) * nc;

@@ -179,7 +179,8 @@ def gen_peaks():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(os.cpu_count())
+    from oracle.hostinfo import usable_cores
+    torch.set_num_threads(usable_cores())
     which = sys.argv[1:] or ["model", "panostretch", "peaks"]
     if "panostretch" in which:
         gen_panostretch()

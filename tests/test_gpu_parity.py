@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
 from horizonnet_amd import HorizonNet, _lib, find_N_peaks, find_peaks_batch, pano_stretch, pano_stretch_batch  # noqa: E402
 from oracle import horizonnet_ref, panostretch_ref, peaks_ref  # noqa: E402
 from oracle.weights import make_state_dict  # noqa: E402
+from oracle.hostinfo import usable_cores  # noqa: E402
+
+torch.set_num_threads(usable_cores())
 
 from hiputil import DEV, P, conv_hip, lib, report, sp  # noqa: E402
 
@@ -167,7 +170,8 @@ def test_linear_head_stage():
     lin = (y @ w.t() + b).view(T, B, 3, 4).permute(1, 2, 0, 3).contiguous().view(B, 3, 4 * T)
     bon = torch.empty((B, 2, 4 * T), device=DEV)
     cor = torch.empty((B, 1, 4 * T), device=DEV)
-    _lib.check(lib().hn_linear_head(P(y.to(DEV).contiguous()), P(w.to(DEV)), P(b.to(DEV)), P(bon), P(cor), T, B, sp()), "head")
+    yd, wd, bd = y.to(DEV).contiguous(), w.to(DEV), b.to(DEV)      # keep alive: the ABI takes raw pointers
+    _lib.check(lib().hn_linear_head(P(yd), P(wd), P(bd), P(bon), P(cor), T, B, sp()), "head")
     torch.cuda.synchronize()
     assert report("linear head bon", bon.cpu().numpy(), lin[:, 1:].numpy(), 2e-5)
     assert report("linear head cor", cor.cpu().numpy(), lin[:, :1].numpy(), 2e-5)
@@ -212,7 +216,6 @@ def test_forward_vs_oracle_batch_and_extra_channel():
     # B=3 with a 4th (ignored) input channel, reference model.py:252 reads x[:, :3]
     sd = make_state_dict(7, "random")
     x = torch.rand(3, 4, 512, 1024, generator=torch.Generator().manual_seed(77))
-    torch.set_num_threads(os.cpu_count())
     want_bon, want_cor = horizonnet_ref.forward(x, sd)
     net = HorizonNet("resnet50", True)
     net.load_state_dict(sd)
@@ -324,7 +327,7 @@ def test_pano_stretch_edge_cases():
     empty = torch.empty((0, 8, 16, 3), device=DEV)
     assert pano_stretch_batch(empty, [], []).shape == (0, 8, 16, 3)
     rng = np.random.RandomState(5)
-    for (h, w, c) in [(9, 301, 3), (2, 2, 1), (33, 70, 7)]:
+    for (h, w, c) in [(9, 300, 3), (2, 2, 1), (33, 70, 7)]:   # even W: odd W puts u=0 (0/0) in the reference itself
         img = rng.rand(h, w, c).astype(np.float32)
         want, _ = panostretch_ref.pano_stretch(img, np.zeros((1, 2), np.float32), 0.8, 1.6)
         got, _ = pano_stretch(img, np.zeros((1, 2), np.float32), 0.8, 1.6)

@@ -12,6 +12,7 @@ import torch
 
 from oracle import horizonnet_ref, panostretch_ref, peaks_ref
 from oracle.weights import make_state_dict, state_dict_spec
+from oracle.hostinfo import usable_cores
 
 
 def test_state_dict_spec_matches_reference(golden_dir):
@@ -33,7 +34,7 @@ def test_forward_oracle_demo(golden_dir):
     sd = make_state_dict(int(g["seed"]), str(g["bn"]))
     assert abs(sd["feature_extractor.encoder.conv1.1.weight"].double().sum().item() - float(g["w_checksum"])) < 1e-9
     assert abs(sd["bi_rnn.weight_hh_l1_reverse"].double().sum().item() - float(g["w_checksum_lstm"])) < 1e-9
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(usable_cores())
     taps = {}
     bon, cor = horizonnet_ref.forward(x, sd, taps)
     assert np.abs(bon.numpy() - g["bon"]).max() < 1e-5
