@@ -8,19 +8,32 @@
 // (reference model.py:123-135).  Padding follows reference model.py:27-55: zeros above/below,
 // CIRCULAR left/right -- here it is index arithmetic in the tile loader, never a padded copy.
 //
-// Design (MI355X): NHWC activations so a filter tap's 32 input channels are one 128-byte
-// line; 256-thread workgroups (one wave per SIMD), BK = 32; tiles staged through registers
-// into padded LDS rows (stride 36 floats -> conflict-free ds_read_b128 fragment reads);
-// v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain, 155 TF roof).  Each lane fetches 4 consecutive
-// k with ONE ds_read_b128 and feeds 4 MFMAs: lanes 0-31 carry k = 8j..8j+3 and lanes 32-63
-// k = 8j+4..8j+7, so MFMA q consumes k = 8j+q and 8j+4+q (any fixed k order is a valid sum).
+// Design (MI355X):
+//  * NHWC activations: a filter tap's 32 input channels are one 128-byte line; GEMM row = pixel.
+//  * 256-thread workgroups (one wave per SIMD), BK = 32, tiles 128x128 / 128x64 / 64x128 / 64x64 /
+//    128x32; 2+ workgroups per CU.
+//  * Tile loads are raw BUFFER loads: a per-row 32-bit byte offset (recomputed only when the filter
+//    tap changes) + a wave-uniform scalar offset for the channel chunk, so the steady-state loop
+//    has no per-lane address arithmetic at all; rows that fall in the zero padding (or past M)
+//    carry an out-of-range offset and the hardware bounds check returns zeros.
+//  * Register-staged double buffering into LDS rows padded to 36 floats (conflict-free
+//    ds_read_b128); v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain, 155 TF roof).  Each lane fetches
+//    4 consecutive k with ONE ds_read_b128 and feeds 4 MFMAs: lanes 0-31 carry k = 8j..8j+3 and
+//    lanes 32-63 k = 8j+4..8j+7, so MFMA q consumes k = 8j+q and 8j+4+q (a fixed k order: results
+//    do not depend on the tile shape).
+//  * MFMA fragments double-buffered in registers; the fragment reads of step kk+1 are issued before
+//    the MFMAs of step kk, also across the per-chunk barrier.
+//  * Epilogue through LDS: whole output rows as float4 (folded BN scale/shift, residual, ReLU).
 #include "hn_common.h"
+
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;   // floats; 144-byte rows keep 16-byte alignment
+constexpr int BK = 32;               // K chunk (floats) = one 128-byte line per tile row
+constexpr int LDS_STRIDE = BK + 4;   // floats; 144-byte rows: conflict-free ds_read_b128, 16-byte aligned
+constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer's num_records -> load returns 0
 
 struct ConvArgs {
     const float* x;
@@ -32,7 +45,17 @@ struct ConvArgs {
     int Hi, Wi, Cin, Ho, Wo, Cout;
     int KW, sh, sw, ph, pw;
     int M, K, nk, relu, ldy;
+    int ablate;          // DEBUG ONLY (HN_CONV_ABLATE): bit0 skip in-loop global loads, bit1 skip LDS staging
+    int xcd_swizzle;     // 1: remap blockIdx so each XCD (own L2) works on a contiguous run of tiles
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
@@ -41,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-    constexpr int AP = BM / 32;      // A rows staged per thread
+    constexpr int AP = BM / 32;      // A rows staged per thread (8 threads x float4 per 128-byte row)
     constexpr int BP = BN / 32;      // W rows staged per thread
     constexpr int A_TILE = BM * LDS_STRIDE;
     constexpr int STAGE = (BM + BN) * LDS_STRIDE;
@@ -52,17 +75,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int lrow = tid >> 3;       // 0..31
+    const int lrow = tid >> 3;       // tile row staged by this thread (+32 per pass)
     const int lcol = tid & 7;        // 16-byte column inside the 128-byte row
 
+    // XCD-aware tile order (cdna guide T1, bijective form): workgroup b runs on XCD b % 8; give XCD x the
+    // contiguous tile range [start_x, start_x + count_x) so tiles sharing A rows / halo rows hit one L2.
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int NT = p.Cout / BN;
-    const int nt = blockIdx.x % NT;
-    const int mt = blockIdx.x / NT;
+    const int nt = bid % NT;
+    const int mt = bid / NT;
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
+    // ---- buffer descriptors (wave-uniform): A rebased at the tile's first image, W at the tile's first row ----
+    const int hw_out = p.Ho * p.Wo;
+    const int b_first = m0 / hw_out;
+    const size_t img_floats = (size_t)p.Hi * p.Wi * (STEM ? 4 : p.Cin);
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)b_first * img_floats), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + (size_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
+
     // ---- per-thread A-row descriptors (output pixel -> input window origin) ----
-    size_t a_base[AP];
+    int a_pix0[AP];                  // (b - b_first) * Hi * Wi, or -1 for rows past M
     int a_hi0[AP], a_wi0[AP];
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
@@ -72,49 +113,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
             const int t = m / p.Wo;
             const int ho = t % p.Ho;
             const int b = t / p.Ho;
-            a_base[q] = (size_t)b * p.Hi * p.Wi;
+            a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
             a_hi0[q] = ho * p.sh - p.ph;
             a_wi0[q] = wo * p.sw - p.pw;
         } else {
-            a_base[q] = 0;
-            a_hi0[q] = -(1 << 28);   // always out of range -> zero rows
+            a_pix0[q] = -1;
+            a_hi0[q] = 0;
             a_wi0[q] = 0;
         }
     }
-    const float* wrow[BP];
+    unsigned w_off[BP];
 #pragma unroll
-    for (int q = 0; q < BP; ++q) wrow[q] = p.w + (size_t)(n0 + lrow + 32 * q) * p.K + lcol * 4;
+    for (int q = 0; q < BP; ++q) w_off[q] = (unsigned)((lrow + 32 * q) * p.K + lcol * 4) * 4u;
 
-    f32x4 ra[AP], rb[BP];
-    int dh = 0, dw = 0, c0 = 0;      // filter-tap cursor of the chunk being fetched
-
-    auto fetch = [&](int kc) {
+    // byte offsets of this thread's A rows for the current filter tap (OOB = zero padding)
+    unsigned a_off[AP];
+    auto tap_offsets = [&](int dh, int dw) {
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
             const int hi = a_hi0[q] + dh;
             int wi = a_wi0[q] + (STEM ? lcol : dw);
             wi = wi < 0 ? wi + p.Wi : wi;
             wi = wi >= p.Wi ? wi - p.Wi : wi;
-            // branch-free: clamp the row, load, then zero the H-padding rows
-            const bool ok = (unsigned)hi < (unsigned)p.Hi;
-            const int hic = ok ? hi : 0;
-            const size_t pix = a_base[q] + (size_t)hic * p.Wi + wi;
-            const float* src = STEM ? p.x + pix * 4 : p.x + pix * p.Cin + c0 + lcol * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            v = ok ? v : z;
-            ra[q] = v;
+            const bool ok = (a_pix0[q] >= 0) && ((unsigned)hi < (unsigned)p.Hi);
+            const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
+            const unsigned off = STEM ? pix * 16u : (pix * (unsigned)p.Cin + (unsigned)lcol * 4u) * 4u;
+            a_off[q] = ok ? off : OOB;
         }
+    };
+
+    f32x4 ra[AP], rb[BP];
+    int dh = 0, dw = 0, c0 = 0;      // filter-tap cursor of the chunk being fetched
+    tap_offsets(0, 0);
+
+    auto fetch = [&](int kc) {
 #pragma unroll
-        for (int q = 0; q < BP; ++q) rb[q] = *reinterpret_cast<const f32x4*>(wrow[q] + (size_t)kc * BK);
-        // advance the tap cursor to the next chunk
+        for (int q = 0; q < AP; ++q) ra[q] = buf_load16(rsrc_a, a_off[q], (unsigned)c0 * 4u);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) rb[q] = buf_load16(rsrc_w, w_off[q], (unsigned)kc * (BK * 4u));
+        // advance the tap cursor to the next chunk (wave-uniform control flow)
         if (STEM) {
             dh += 1;
+            tap_offsets(dh, 0);
         } else {
             c0 += BK;
             if (c0 == p.Cin) {
                 c0 = 0;
                 if (++dw == p.KW) { dw = 0; ++dh; }
+                tap_offsets(dh, dw);
             }
         }
     };
@@ -144,68 +190,110 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     stage(0);
     __syncthreads();
 
-    for (int kc = 0; kc < p.nk; ++kc) {
-        const int buf = kc & 1;
-        const bool more = kc + 1 < p.nk;
-        if (more) fetch(kc + 1);
-
-        const float* a_s = smem + buf * STAGE + (wm * WM + fr) * LDS_STRIDE + fk;
-        const float* b_s = smem + buf * STAGE + A_TILE + (wn * WN + fr) * LDS_STRIDE + fk;
+    // Software-pipelined main loop: MFMA fragments are double-buffered in registers and the fragment
+    // reads of step kk+1 are issued before the MFMAs of step kk -- including ACROSS the per-chunk
+    // barrier (the MFMAs of the chunk's last k-step run after the barrier and cover the LDS latency of
+    // the next chunk's first fragments).
+    {
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto ldfrag = [&](f32x4 (&fa)[TM], f32x4 (&fb)[TN], int buf, int kk) {
+            const float* a_s = smem + buf * STAGE + (wm * WM + fr) * LDS_STRIDE + fk + kk * 8;
+            const float* b_s = smem + buf * STAGE + A_TILE + (wn * WN + fr) * LDS_STRIDE + fk + kk * 8;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 af[TM], bf[TN];
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDS_STRIDE);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(b_s + j * 32 * LDS_STRIDE + kk * 8);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b_s + j * 32 * LDS_STRIDE);
+        };
+        auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
+        };
+        ldfrag(fa0, fb0, 0, 0);
+        for (int kc = 0; kc < p.nk; ++kc) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < p.nk;
+            if (more && !(p.ablate & 1)) fetch(kc + 1);
+            ldfrag(fa1, fb1, buf, 1);
+            mma(fa0, fb0);
+            ldfrag(fa0, fb0, buf, 2);
+            mma(fa1, fb1);
+            ldfrag(fa1, fb1, buf, 3);
+            if (more && !(p.ablate & 2)) stage(buf ^ 1);
+            mma(fa0, fb0);
+            __syncthreads();                 // chunk kc+1 staged; every wave has read all of chunk kc
+            if (more) ldfrag(fa0, fb0, buf ^ 1, 0);
+            mma(fa1, fb1);
         }
-
-        if (more) stage(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: folded BN / bias, residual, ReLU; lanes 0-31 write one 128-byte row segment ----
-    const int half = lane >> 5;
+    // ---- epilogue: accumulators -> LDS (the staging buffers are free after the last barrier) -> whole
+    // rows as 16-byte lanes: scale/shift (folded BN + bias), residual, ReLU, coalesced float4 stores.
+    constexpr int CS = BN + 4;               // C-tile row stride (floats), keeps 16-byte alignment
+    constexpr int EROWS = WM;                // rows per epilogue pass: the waves of one wave-row (wm) at a time
+    static_assert(EROWS * CS <= 2 * STAGE, "C tile must fit in the staging LDS");
+    constexpr int TPR = BN / 4;              // threads per output row
+    constexpr int RPP = 256 / TPR;           // rows per store sweep
+    constexpr int NPS = EROWS / RPP;         // store sweeps per pass
+    static_assert(NPS >= 1, "epilogue geometry");
+    const int ccol = (tid % TPR) * 4;
+    const int crow = tid / TPR;
     auto epilogue = [&](auto has_res) {
         constexpr bool HAS_RES = decltype(has_res)::value;
+        // residual rows first: all loads in flight while the accumulators travel through LDS
+        f32x4 rres[HAS_RES ? WAVES_M * NPS : 1];
+        if (HAS_RES) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + fr;
-            const float sc = p.scale[n];
-            const float sf = p.shift[n];
+            for (int ps = 0; ps < WAVES_M * NPS; ++ps) {
+                const int m = m0 + crow + ps * RPP;
+                const int mc = m < p.M ? m : p.M - 1;
+                rres[ps] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
+            }
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
+        const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mrow0 = m0 + wm * WM + i * 32 + 4 * half;
-                float rv[16];
-                if (HAS_RES) {
+        for (int h = 0; h < WAVES_M; ++h) {
+            if (h > 0) __syncthreads();          // previous pass fully read before it is overwritten
+            if (wm == h) {
+                const int half = lane >> 5;
+                float* c_w = smem + (4 * half) * CS + wn * WN + fr;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                        const int mc = m < p.M ? m : p.M - 1;          // clamped: loads stay unconditional
-                        rv[r] = p.res[(size_t)mc * p.Cout + n];
-                    }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            c_w[(i * 32 + (r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int row = crow + ps * RPP;
+                const int m = m0 + h * EROWS + row;
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + ccol);
+                v = v * sc + sf;
+                if (HAS_RES) v += rres[h * NPS + ps];
+                if (p.relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] * sc + sf;
-                    if (HAS_RES) v += rv[r];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (m < p.M) p.y[(size_t)m * p.ldy + n] = v;
-                }
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n0 + ccol) = v;
             }
         }
     };
     if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
+}
+
+int env_flag(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
@@ -230,15 +318,26 @@ int launch_cfg(const ConvArgs& a, hipStream_t s)
 
 int hn_launch_conv(const ConvDesc& d, hipStream_t s)
 {
+    static const int xcd_swizzle = env_flag("HN_XCD_SWIZZLE", 1);   // tuning knob
+    static const int ablate = env_flag("HN_CONV_ABLATE", 0);        // debug timing ablations, results invalid when != 0
+    static const int force_tile = env_flag("HN_FORCE_TILE", 0);     // experiment knob: 1=128x128 2=128x64 3=64x128 4=64x64
     ConvArgs a;
+    a.xcd_swizzle = xcd_swizzle;
+    a.ablate = ablate;
     a.x = d.x; a.w = d.w; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.y = d.y;
     a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;
     a.ldy = d.ldy ? d.ldy : d.Cout;
+    // 32-bit buffer offsets: a tile spans at most 2 images (+1 for safety) and one weight tile
+    {   // 32-bit buffer offsets are relative to the tile's first image; a 128-row tile spans 128/(Ho*Wo)+2 images at most
+        const double span = 128.0 / ((double)d.Ho * d.Wo) + 2.0;
+        HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 4 : d.Cin) * 4.0 < 2147483648.0, "conv: image too large for 32-bit tile offsets");
+    }
     if (d.stem) {
         HN_REQUIRE(d.KH == 7 && d.KW == 7 && d.Cout == 64 && d.Cin == 4, "stem conv: expects 7x7, Cin(padded)=4, Cout=64");
+        HN_REQUIRE(d.Ho * d.Wo >= 128, "stem conv: output image smaller than one tile");
         a.K = 7 * BK;
         a.nk = 7;
         return launch_cfg<128, 64, 2, 2, true>(a, s);
@@ -247,7 +346,12 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     HN_REQUIRE(d.Cout % 32 == 0, "conv: Cout=%d must be a multiple of 32", d.Cout);
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BK;
+    HN_REQUIRE(128.0 * a.K * 4.0 < 2147483648.0, "conv: K too large for 32-bit weight-tile offsets");
     const long M = a.M;
+    if (force_tile == 1 && d.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, false>(a, s);
+    if (force_tile == 2 && d.Cout % 64 == 0) return launch_cfg<128, 64, 2, 2, false>(a, s);
+    if (force_tile == 3 && d.Cout % 128 == 0) return launch_cfg<64, 128, 2, 2, false>(a, s);
+    if (force_tile == 4 && d.Cout % 64 == 0) return launch_cfg<64, 64, 2, 2, false>(a, s);
     if (d.Cout % 128 == 0) {
         const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 128);
         if (blocks128 >= 512) return launch_cfg<128, 128, 2, 2, false>(a, s);
