@@ -15,3 +15,5 @@ for f in $SRCS; do
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
 echo "built $(readlink -f $OUT)"
+# an unresolved kernel stub only shows up at dlopen time: fail the build, not the first GPU call
+python3 -c "import ctypes,sys; ctypes.CDLL('$(readlink -f $OUT)')" || { echo "libhorizonnet_hip.so does not load"; exit 1; }

@@ -32,7 +32,6 @@
 namespace {
 
 constexpr int BK = 32;               // K chunk (floats) = one 128-byte line per tile row
-constexpr int LDS_STRIDE = BK + 4;   // floats; 144-byte rows: conflict-free ds_read_b128, 16-byte aligned
 constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer's num_records -> load returns 0
 
 struct ConvArgs {
@@ -57,9 +56,24 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
     return __builtin_bit_cast(f32x4, v);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+// 16 bytes per lane from the buffer straight into LDS at lds_base + lane*16 (wave-uniform lds_base).
+__device__ __forceinline__ void buf_load16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_base, unsigned voff, unsigned soff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // device-only builtin; the host pass only needs the kernel stub
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
+
+// DMA = false: tiles staged through registers into LDS rows padded to 36 floats.
+// DMA = true : tiles land in LDS directly (buffer_load ... lds, 1 KiB per wave instruction, no VGPR
+//              round trip, no ds_write); LDS rows are unpadded 128-byte lines and the 16-byte chunk c of
+//              row r is stored in slot c ^ ((r >> 1) & 7) -- the permutation is applied to the per-lane
+//              SOURCE offset (the LDS side of an LDS-DMA is lane-linear) and again on the fragment read,
+//              which keeps ds_read_b128 conflict-free.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
 {
+    constexpr int LDS_STRIDE = DMA ? BK : BK + 4;   // floats per LDS tile row
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -76,7 +90,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int lrow = tid >> 3;       // tile row staged by this thread (+32 per pass)
-    const int lcol = tid & 7;        // 16-byte column inside the 128-byte row
+    const int lslot = tid & 7;       // 16-byte LDS slot inside the 128-byte row
+    const int lcol = DMA ? (lslot ^ ((lrow >> 1) & 7)) : lslot;   // 16-byte source chunk that goes into that slot
 
     // XCD-aware tile order (cdna guide T1, bijective form): workgroup b runs on XCD b % 8; give XCD x the
     // contiguous tile range [start_x, start_x + count_x) so tiles sharing A rows / halo rows hit one L2.
@@ -147,10 +162,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     tap_offsets(0, 0);
 
     auto fetch = [&](int kc) {
+        if (DMA) {
+            // chunk kc -> LDS stage (kc & 1); wave w fills rows 8w..8w+7 of every 32-row group (1 KiB each)
+            float* a_s = smem + (kc & 1) * STAGE;
+            float* b_s = a_s + A_TILE;
 #pragma unroll
-        for (int q = 0; q < AP; ++q) ra[q] = buf_load16(rsrc_a, a_off[q], (unsigned)c0 * 4u);
+            for (int q = 0; q < AP; ++q)
+                buf_load16_to_lds(rsrc_a, a_s + (q * 4 + wave) * 256, a_off[q], (unsigned)c0 * 4u);
 #pragma unroll
-        for (int q = 0; q < BP; ++q) rb[q] = buf_load16(rsrc_w, w_off[q], (unsigned)kc * (BK * 4u));
+            for (int q = 0; q < BP; ++q)
+                buf_load16_to_lds(rsrc_w, b_s + (q * 4 + wave) * 256, w_off[q], (unsigned)kc * (BK * 4u));
+        } else {
+#pragma unroll
+            for (int q = 0; q < AP; ++q) ra[q] = buf_load16(rsrc_a, a_off[q], (unsigned)c0 * 4u);
+#pragma unroll
+            for (int q = 0; q < BP; ++q) rb[q] = buf_load16(rsrc_w, w_off[q], (unsigned)kc * (BK * 4u));
+        }
         // advance the tap cursor to the next chunk (wave-uniform control flow)
         if (STEM) {
             dh += 1;
@@ -165,14 +192,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
         }
     };
     auto stage = [&](int buf) {
+        if (DMA) {                       // the DMA of this chunk must have landed before the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         float* a_s = smem + buf * STAGE;
         float* b_s = a_s + A_TILE;
 #pragma unroll
         for (int q = 0; q < AP; ++q)
-            *reinterpret_cast<f32x4*>(a_s + (lrow + 32 * q) * LDS_STRIDE + lcol * 4) = ra[q];
+            *reinterpret_cast<f32x4*>(a_s + (lrow + 32 * q) * LDS_STRIDE + lslot * 4) = ra[q];
 #pragma unroll
         for (int q = 0; q < BP; ++q)
-            *reinterpret_cast<f32x4*>(b_s + (lrow + 32 * q) * LDS_STRIDE + lcol * 4) = rb[q];
+            *reinterpret_cast<f32x4*>(b_s + (lrow + 32 * q) * LDS_STRIDE + lslot * 4) = rb[q];
     };
 
     f32x16 acc[TM][TN];
@@ -185,6 +216,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
 
     const int fr = lane & 31;
     const int fk = (lane >> 5) * 4;
+    const int fswz = (fr >> 1) & 7;  // DMA layout: slot permutation of this lane's fragment rows (same for every 32-row tile)
 
     fetch(0);
     stage(0);
@@ -197,8 +229,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     {
         f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         auto ldfrag = [&](f32x4 (&fa)[TM], f32x4 (&fb)[TN], int buf, int kk) {
-            const float* a_s = smem + buf * STAGE + (wm * WM + fr) * LDS_STRIDE + fk + kk * 8;
-            const float* b_s = smem + buf * STAGE + A_TILE + (wn * WN + fr) * LDS_STRIDE + fk + kk * 8;
+            const int koff = DMA ? (((2 * kk + (lane >> 5)) ^ fswz) * 4) : (fk + kk * 8);
+            const float* a_s = smem + buf * STAGE + (wm * WM + fr) * LDS_STRIDE + koff;
+            const float* b_s = smem + buf * STAGE + A_TILE + (wn * WN + fr) * LDS_STRIDE + koff;
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDS_STRIDE);
 #pragma unroll
@@ -296,11 +329,21 @@ int env_flag(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA>
+int launch_cfg_d(const ConvArgs& a, hipStream_t s);
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
 int launch_cfg(const ConvArgs& a, hipStream_t s)
 {
-    const size_t lds = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, STEM>;
+    static const int dma = env_flag("HN_CONV_DMA", 1);
+    return dma ? launch_cfg_d<BM, BN, WAVES_M, WAVES_N, STEM, true>(a, s) : launch_cfg_d<BM, BN, WAVES_M, WAVES_N, STEM, false>(a, s);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA>
+int launch_cfg_d(const ConvArgs& a, hipStream_t s)
+{
+    const size_t lds = 2 * (size_t)(BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, STEM, DMA>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
