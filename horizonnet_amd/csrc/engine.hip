@@ -137,7 +137,7 @@ Plan make_plan(int B)
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
     const size_t b = (size_t)B;
-    p.sync = take(256);
+    p.sync = take(HN_SYNC_WORDS);
     p.xn = take(b * IMG_H * IMG_W * 4);
     p.stem = take(b * 256 * 512 * 64);
     p.pool = take(b * 128 * 256 * 64);
@@ -371,7 +371,7 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
     float* W = reinterpret_cast<float*>(workspace);
     int rc;
 
-    HN_HIP(hipMemsetAsync(W + pl.sync, 0, 256 * sizeof(float), s));
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
     e->prof.clear();
     e->events_used = 0;
 
@@ -451,7 +451,7 @@ extern "C" int hn_check_status(hn_engine* e, void* workspace, int* status_out)
     HN_REQUIRE(e && workspace && status_out, "hn_check_status: null argument");
     DeviceGuard guard(e->device);
     unsigned st = 0;
-    const unsigned* w = reinterpret_cast<const unsigned*>(reinterpret_cast<float*>(workspace) + make_plan(1).sync) + 64;
+    const unsigned* w = reinterpret_cast<const unsigned*>(reinterpret_cast<float*>(workspace) + make_plan(1).sync) + HN_STATUS_WORD;
     HN_HIP(hipMemcpy(&st, w, sizeof(st), hipMemcpyDeviceToHost));
     *status_out = (int)st;
     return 0;
@@ -527,7 +527,7 @@ extern "C" int hn_lstm_layer(const float* gx, const float* whh_fwd, const float*
                              void* sync_ws, void* stream)
 {
     HN_REQUIRE(gx && whh_fwd && whh_rev && y && sync_ws, "hn_lstm_layer: null pointer");
-    HN_HIP(hipMemsetAsync(sync_ws, 0, 256 * sizeof(float), (hipStream_t)stream));
+    HN_HIP(hipMemsetAsync(sync_ws, 0, HN_SYNC_WORDS * sizeof(unsigned), (hipStream_t)stream));
     return hn_launch_lstm_layer(gx, whh_fwd, whh_rev, y, T, B, sync_ws, (hipStream_t)stream);
 }
 

@@ -13,10 +13,13 @@
 //   * per step: h_{t-1} (all 512 units, [<=32][512]) is read straight from the layer output y
 //     (L2), 4 waves x 64 MFMAs produce k-partial gate pre-activations, reduced through LDS, the
 //     gate threads apply sigmoid/tanh and write h_t into y -- which IS the hand-off buffer.
-//   * hand-off between workgroups: per-direction monotonic arrival counter, agent-scope release
-//     by one lane after the stores, relaxed polling + ONE agent-scope acquire on the consumer
-//     (cdna guide G16).  Placement independent; every spin is bounded and reports through a
-//     status word instead of hanging.
+//   * hand-off between workgroups (cdna guide G16, form R1): h_t is stored WRITE-THROUGH (sc1,
+//     agent-scope relaxed atomic stores), every storing wave drains vmcnt, one lane arrives on a
+//     monotonic counter (8 counters per direction, 16 arrivals each per step, so the atomics do
+//     not serialise on one word); consumers poll the 8 words relaxed from 8 lanes, then read
+//     h_{t-1} with sc1 loads (L1 bypassed) -- no release/acquire fences on the critical path.
+//     Placement independent; every spin is bounded and reports through a status word instead
+//     of hanging.
 #include "hn_common.h"
 
 namespace {
@@ -25,8 +28,12 @@ constexpr int LSTM_H = 512;
 constexpr int LSTM_U = 4;                    // hidden units per workgroup
 constexpr int LSTM_NB = LSTM_H / LSTM_U;     // 128 workgroups per direction
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr int CNT_STRIDE = 32;               // counters 128 bytes apart
-constexpr int STATUS_WORD = 64;
+constexpr int CNT_SHARDS = 8;                // arrival counters per direction
+constexpr int CNT_STRIDE = 32;               // counters 128 bytes apart: word (dir*8 + shard) * 32
+constexpr int STATUS_WORD = HN_STATUS_WORD;
+static_assert(2 * CNT_SHARDS * CNT_STRIDE <= HN_STATUS_WORD && HN_STATUS_WORD < HN_SYNC_WORDS, "sync scratch layout");
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -43,7 +50,12 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
     const int dir = blockIdx.x & 1;
     const int u0 = (blockIdx.x >> 1) * LSTM_U;
     const float* whh = dir ? whh_r : whh_f;
-    unsigned* cnt = sync + dir * CNT_STRIDE;
+    unsigned* cnt_mine = sync + (dir * CNT_SHARDS + ((blockIdx.x >> 1) & (CNT_SHARDS - 1))) * CNT_STRIDE;
+    unsigned* cnt_poll = sync + (dir * CNT_SHARDS + (tid & (CNT_SHARDS - 1))) * CNT_STRIDE;   // lanes 0..7 of wave 0
+    // h_{t-1} is read with sc1 (L1-bypassing) buffer loads: aux bit 4 = sc1 on gfx940+
+    const __amdgpu_buffer_rsrc_t rsrc_y =
+        __builtin_amdgcn_make_buffer_rsrc(y, 0, (unsigned)((size_t)T * B * 1024 * sizeof(float) > 0xfffffff0u
+                                                               ? 0xfffffff0u : (size_t)T * B * 1024 * sizeof(float)), 0x00020000);
 
     // ---- W_hh fragments: B[k][n], n = gate*4 + unit -> row gate*512 + u0 + unit --------------
     const int fn = lane & 15;
@@ -88,10 +100,10 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
         for (int tl = 0; tl < BT; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (step > 0) {
-            if (tid == 0 && !failed) {
-                const unsigned want = (unsigned)LSTM_NB * (unsigned)step;
+            if (tid < CNT_SHARDS && !failed) {
+                const unsigned want = (unsigned)(LSTM_NB / CNT_SHARDS) * (unsigned)step;
                 unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                while (__hip_atomic_load(cnt_poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > SPIN_LIMIT) {
                         __hip_atomic_store(sync + STATUS_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -99,7 +111,6 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
                         break;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
 
@@ -107,9 +118,10 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
             f32x4 hf[BT][8];
 #pragma unroll
             for (int tl = 0; tl < BT; ++tl) {
-                const float* hr = y + ((size_t)tp * B + arow[tl]) * 1024 + dir * LSTM_H + koff;
+                const unsigned hoff = (unsigned)((((size_t)tp * B + arow[tl]) * 1024 + dir * LSTM_H + koff) * sizeof(float));
 #pragma unroll
-                for (int s = 0; s < 8; ++s) hf[tl][s] = *reinterpret_cast<const f32x4*>(hr + s * 16);
+                for (int s = 0; s < 8; ++s)
+                    hf[tl][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, hoff + s * 64, 0, /*sc1*/ 16));
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s)
@@ -143,17 +155,15 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
             const float og = sigmoidf_(pre[3]);
             c_state = fg * c_state + ig * gg;
             const float h = og * tanhf(c_state);
-            if (gate_live) y[((size_t)t * B + b0 + gb) * 1024 + dir * LSTM_H + u0 + gu] = h;
+            if (gate_live)      // write-through (sc1) store: visible to every XCD once the wave's vmcnt drains
+                __hip_atomic_store(y + ((size_t)t * B + b0 + gb) * 1024 + dir * LSTM_H + u0 + gu, h, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
 
-        // publish h_t: every storing wave drains, one lane releases at agent scope, then arrives
+        // publish h_t: every storing wave drains its write-through stores, then ONE lane arrives
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_fetch_add(cnt_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -163,10 +173,11 @@ int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r
                          void* sync_ws, hipStream_t s)
 {
     HN_REQUIRE(T >= 1 && B >= 1, "lstm: bad T/B");
+    HN_REQUIRE((size_t)T * B * 1024 * sizeof(float) <= 0xfffffff0ull, "lstm: T*B too large for 32-bit buffer offsets");
     unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int bc = (B - b0) < 32 ? (B - b0) : 32;
-        HN_HIP(hipMemsetAsync(sync, 0, 2 * CNT_STRIDE * sizeof(unsigned), s));   // counters only; status is sticky
+        HN_HIP(hipMemsetAsync(sync, 0, STATUS_WORD * sizeof(unsigned), s));   // counters only; status is sticky
         if (bc <= 16)
             hipLaunchKernelGGL(lstm_layer_kernel<1>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync);
         else

@@ -141,7 +141,7 @@ int hn_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int 
 /* One bidirectional LSTM layer, hidden 512 (reference model.py:222-227,263-264).
  * gx: [T*B][4096] = x @ [W_ih_fwd; W_ih_rev]^T + (b_ih + b_hh) (columns dir*2048 + gate*512 + unit,
  * gates i,f,g,o); whh_fwd / whh_rev: [2048][512]; y: [T*B][1024] (fwd | rev).
- * sync_ws: >= 256 bytes of device scratch for the grid barrier + status word. */
+ * sync_ws: 4096 bytes of device scratch (arrival counters; uint32 word 512 = sticky status, 0 = ok). */
 int hn_lstm_layer(const float* gx, const float* whh_fwd, const float* whh_rev, float* y,
                   int T, int B, void* sync_ws, void* stream);
 

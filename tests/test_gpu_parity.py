@@ -154,12 +154,33 @@ def test_lstm_layer_stage(B):
     gxd = gx.to(DEV).contiguous()
     wf, wr = whh[0].to(DEV).contiguous(), whh[1].to(DEV).contiguous()
     y = torch.full((T * B, 1024), float("nan"), device=DEV)
-    sync = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    sync = torch.empty(4096, dtype=torch.uint8, device=DEV)
     _lib.check(lib().hn_lstm_layer(P(gxd), P(wf), P(wr), P(y), T, B, P(sync), sp()), "lstm")
     torch.cuda.synchronize()
-    status = int(sync.cpu().view(torch.int32)[64])
+    status = int(sync.cpu().view(torch.int32)[512])
     assert status == 0, "persistent LSTM kernel reported a spin time-out"
     assert report("bi-LSTM layer B=%d" % B, y.cpu().view(T, B, 1024).numpy(), want.numpy(), 2e-5)
+    # second run on the SAME output / hand-off buffer with different inputs: a consumer that read stale
+    # (cached) h_{t-1} lines from the first run would show up here
+    gx2 = -gxd
+    _lib.check(lib().hn_lstm_layer(P(gx2), P(wf), P(wr), P(y), T, B, P(sync), sp()), "lstm")
+    torch.cuda.synchronize()
+    assert int(sync.cpu().view(torch.int32)[512]) == 0
+    # LSTM with negated gate pre-activations is not a simple transform of the first run: recompute the oracle
+    outs2 = []
+    for d in range(2):
+        h = torch.zeros(B, 512)
+        c = torch.zeros(B, 512)
+        ys = [None] * T
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            g = -gx[t, :, d * 2048:(d + 1) * 2048] + h @ whh[d].t()
+            i, f, gg, o = g.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            ys[t] = h
+        outs2.append(torch.stack(ys, 0))
+    assert report("bi-LSTM layer B=%d, re-run on the same buffers" % B, y.cpu().view(T, B, 1024).numpy(),
+                  torch.cat(outs2, 2).numpy(), 2e-5)
 
 
 def test_linear_head_stage():
