@@ -177,11 +177,48 @@ def gen_peaks():
     np.savez_compressed(os.path.join(GOLD, "peaks.npz"), **outs)
 
 
+def gen_stretch_params():
+    """dataset.py:70-81,189-208 -- reference cor2xybound + the clamped (kx, ky) sampling sequence."""
+    import dataset as ref_ds                        # reference dataset.py (shapely stubbed, never called here)
+    rng = np.random.RandomState(21)
+    out = {}
+    cors = []
+    for j in range(8):                              # synthetic cuboid rooms, label_cor layout (ceil, floor per wall corner)
+        n = 4 if j < 6 else 6
+        xs = np.sort(rng.uniform(20, 1000, n))
+        yc = rng.uniform(100, 200, n)
+        yf = rng.uniform(320, 420, n)
+        cor = np.stack([np.repeat(xs, 2), np.stack([yc, yf], 1).reshape(-1)], 1).astype(np.float32)
+        cors.append(cor)
+        out["cor_%d" % j] = cor
+        out["bound_%d" % j] = np.array(ref_ds.cor2xybound(cor), np.float64)
+        ks = []
+        for seed in range(6):
+            np.random.seed(seed * 7 + j)
+            xmin, ymin, xmax, ymax = ref_ds.cor2xybound(cor)
+            kx = np.random.uniform(1.0, 2.0)
+            ky = np.random.uniform(1.0, 2.0)
+            if np.random.randint(2) == 0:
+                kx = max(1 / kx, min(0.5 / xmin, 1.0))
+            else:
+                kx = min(kx, max(10.0 / xmax, 1.0))
+            if np.random.randint(2) == 0:
+                ky = max(1 / ky, min(0.5 / ymin, 1.0))
+            else:
+                ky = min(ky, max(10.0 / ymax, 1.0))
+            ks.append((kx, ky))
+        out["k_%d" % j] = np.array(ks, np.float64)
+    np.savez_compressed(os.path.join(GOLD, "stretch_params.npz"), **out)
+    print("stretch_params: %d rooms written" % len(cors))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from oracle.hostinfo import usable_cores
     torch.set_num_threads(usable_cores())
-    which = sys.argv[1:] or ["model", "panostretch", "peaks"]
+    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch"]
+    if "stretch" in which:
+        gen_stretch_params()
     if "panostretch" in which:
         gen_panostretch()
     if "peaks" in which:

@@ -106,6 +106,19 @@ def test_corner_half_matches_reference_golden(golden_dir):
         assert np.array_equal(got, g["corners_%d" % i])
 
 
+def test_stretch_param_sampling_matches_reference(golden_dir):
+    # dataset.py:70-81 + cor2xybound (:189-208): same bounds, same clamped (kx, ky) for the same seeds
+    from horizonnet_amd.augment import cor2xybound, sample_stretch
+    g = np.load(os.path.join(golden_dir, "stretch_params.npz"))
+    for j in range(8):
+        cor = g["cor_%d" % j]
+        assert np.allclose(cor2xybound(cor), g["bound_%d" % j], rtol=1e-6, atol=0)
+        for seed in range(6):
+            np.random.seed(seed * 7 + j)
+            kx, ky = sample_stretch(cor, 2.0)
+            assert np.allclose([kx, ky], g["k_%d" % j][seed], rtol=1e-6, atol=0)
+
+
 def test_shard_for_rank_partitions_units():
     sys.path.insert(0, ROOT)
     import bench
