@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void pano_stretch_kernel(const float* __restri
     const int x = blockIdx.x * 256 + threadIdx.x;
     const double PI = 3.141592653589793;
     if (threadIdx.x < PS_ROWS) {
-        const int y = y0 + threadIdx.x;
+        const int y = y0 + threadIdx.x < H ? y0 + threadIdx.x : H - 1;   // tail rows: computed, never stored
         const double v = (((double)y + 0.5) / (double)H - 0.5) * PI;
         tan_v[threadIdx.x] = tan(v);
     }
@@ -62,8 +62,12 @@ __global__ __launch_bounds__(256) void pano_stretch_kernel(const float* __restri
 
     const float* img = src + (size_t)b * H * W * nc;
     float* out = dst + (size_t)b * H * W * nc;
-    const int rows = (H - y0) < PS_ROWS ? (H - y0) : PS_ROWS;
-    for (int r = 0; r < rows; ++r) {
+
+    // Phase 1: coordinates of all rows (independent fp64 chains); phase 2: all gathers in flight; phase 3: stores.
+    int ra0[PS_ROWS], ra1[PS_ROWS];
+    double wy[PS_ROWS];
+#pragma unroll
+    for (int r = 0; r < PS_ROWS; ++r) {
         // misc/panostretch.py:93,96
         const double v0 = atan(tan_v[r] * sin_u0 / sin_u * ky);
         const double refy = (v0 / PI + 0.5) * (double)H - 0.5;
@@ -72,20 +76,54 @@ __global__ __launch_bounds__(256) void pano_stretch_kernel(const float* __restri
         int yy0 = (int)fy;
         yy0 = yy0 < 0 ? 0 : (yy0 > H - 1 ? H - 1 : yy0);
         const int yy1 = yy0 + 1 < H ? yy0 + 1 : H - 1;
-        const double wy1 = cy - fy, wy0 = 1.0 - wy1;
-        const float* p00 = img + ((size_t)yy0 * W + x0) * nc;
-        const float* p01 = img + ((size_t)yy0 * W + x1) * nc;
-        const float* p10 = img + ((size_t)yy1 * W + x0) * nc;
-        const float* p11 = img + ((size_t)yy1 * W + x1) * nc;
-        float* o = out + ((size_t)(y0 + r) * W + x) * nc;
+        ra0[r] = yy0 * W;
+        ra1[r] = yy1 * W;
+        wy[r] = cy - fy;
+    }
+    constexpr int NCL = C > 0 ? C : 1;
+    if (C > 0) {
+        float p00[PS_ROWS][NCL], p01[PS_ROWS][NCL], p10[PS_ROWS][NCL], p11[PS_ROWS][NCL];
 #pragma unroll
-        for (int c = 0; c < nc; ++c) {
-            double t = 0.0;
-            t += (double)p00[c] * wy0 * wx0;
-            t += (double)p01[c] * wy0 * wx1;
-            t += (double)p10[c] * wy1 * wx0;
-            t += (double)p11[c] * wy1 * wx1;
-            o[c] = (float)t;
+        for (int r = 0; r < PS_ROWS; ++r) {
+#pragma unroll
+            for (int c = 0; c < NCL; ++c) {
+                p00[r][c] = img[(size_t)(ra0[r] + x0) * NCL + c];
+                p01[r][c] = img[(size_t)(ra0[r] + x1) * NCL + c];
+                p10[r][c] = img[(size_t)(ra1[r] + x0) * NCL + c];
+                p11[r][c] = img[(size_t)(ra1[r] + x1) * NCL + c];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PS_ROWS; ++r) {
+            if (y0 + r >= H) break;
+            const double wy1 = wy[r], wy0 = 1.0 - wy1;
+            float* o = out + ((size_t)(y0 + r) * W + x) * NCL;
+#pragma unroll
+            for (int c = 0; c < NCL; ++c) {
+                double t = 0.0;                     // SciPy's term order, double accumulate, one rounding to f32
+                t += (double)p00[r][c] * wy0 * wx0;
+                t += (double)p01[r][c] * wy0 * wx1;
+                t += (double)p10[r][c] * wy1 * wx0;
+                t += (double)p11[r][c] * wy1 * wx1;
+                o[c] = (float)t;
+            }
+        }
+    } else {
+        for (int r = 0; r < PS_ROWS && y0 + r < H; ++r) {
+            const double wy1 = wy[r], wy0 = 1.0 - wy1;
+            const float* q00 = img + (size_t)(ra0[r] + x0) * nc;
+            const float* q01 = img + (size_t)(ra0[r] + x1) * nc;
+            const float* q10 = img + (size_t)(ra1[r] + x0) * nc;
+            const float* q11 = img + (size_t)(ra1[r] + x1) * nc;
+            float* o = out + ((size_t)(y0 + r) * W + x) * nc;
+            for (int c = 0; c < nc; ++c) {
+                double t = 0.0;
+                t += (double)q00[c] * wy0 * wx0;
+                t += (double)q01[c] * wy0 * wx1;
+                t += (double)q10[c] * wy1 * wx0;
+                t += (double)q11[c] * wy1 * wx1;
+                o[c] = (float)t;
+            }
         }
     }
 }
