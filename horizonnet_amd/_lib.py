@@ -27,6 +27,15 @@ SIGNATURES = {
     "hn_set_profiling": (_i, [_vp, _i]),
     "hn_profile_count": (_i, [_vp]),
     "hn_profile_entry": (_i, [_vp, _i, _c.c_char_p, _i, _c.POINTER(_f), _c.POINTER(_c.c_double)]),
+    "hn_train_workspace_bytes": (_sz, [_i]),
+    "hn_train_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _f, _f, _f, _c.c_uint64, _vp]),
+    "hn_train_backward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _f, _c.c_uint64, _vp]),
+    "hn_grad_floats": (_sz, []),
+    "hn_train_debug_unit": (_i, [_i, _i, _c.POINTER(_i64)]),
+    "hn_train_debug_set": (_i, [_vp, _i, _vp, _vp]),
+    "hn_grad_offset": (_i64, [_c.c_char_p]),
+    "hn_conv2d_dgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hn_conv2d_wgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_pano_stretch": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _i, _i, _i, _i, _vp]),
     "hn_find_peaks": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "hn_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -44,6 +44,10 @@ struct ConvArgs {
     int Hi, Wi, Cin, Ho, Wo, Cout;
     int KW, sh, sw, ph, pw;
     int M, K, nk, relu, ldy;
+    int xstride;         // floats between consecutive input pixels (>= Cin; lets a GEMM read a column slice)
+    int transposed;      // 1: data-gradient mode -- x is dY on the (Hi,Wi) grid, y is dX on the (Ho,Wo) grid:
+                         //    input pixel = (out + pad - tap) / stride where divisible (reference conv's adjoint)
+    int sh_log2, sw_log2;
     int ablate;          // DEBUG ONLY (HN_CONV_ABLATE): bit0 skip in-loop global loads, bit1 skip LDS staging
     int xcd_swizzle;     // 1: remap blockIdx so each XCD (own L2) works on a contiguous run of tiles
 };
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     // ---- buffer descriptors (wave-uniform): A rebased at the tile's first image, W at the tile's first row ----
     const int hw_out = p.Ho * p.Wo;
     const int b_first = m0 / hw_out;
-    const size_t img_floats = (size_t)p.Hi * p.Wi * (STEM ? 4 : p.Cin);
+    const size_t img_floats = (size_t)p.Hi * p.Wi * (STEM ? 4 : p.xstride);
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)b_first * img_floats), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w =
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
             const int ho = t % p.Ho;
             const int b = t / p.Ho;
             a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
-            a_hi0[q] = ho * p.sh - p.ph;
-            a_wi0[q] = wo * p.sw - p.pw;
+            a_hi0[q] = p.transposed ? ho + p.ph : ho * p.sh - p.ph;
+            a_wi0[q] = p.transposed ? wo + p.pw : wo * p.sw - p.pw;
         } else {
             a_pix0[q] = -1;
             a_hi0[q] = 0;
@@ -146,13 +150,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     auto tap_offsets = [&](int dh, int dw) {
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
-            const int hi = a_hi0[q] + dh;
-            int wi = a_wi0[q] + (STEM ? lcol : dw);
-            wi = wi < 0 ? wi + p.Wi : wi;
-            wi = wi >= p.Wi ? wi - p.Wi : wi;
-            const bool ok = (a_pix0[q] >= 0) && ((unsigned)hi < (unsigned)p.Hi);
+            int hi, wi;
+            bool ok = a_pix0[q] >= 0;
+            if (!STEM && p.transposed) {
+                const int th = a_hi0[q] - dh;                    // = ho_z * sh when this tap contributed
+                int tw = a_wi0[q] - dw;
+                tw = tw < 0 ? tw + p.Wo : tw;                     // circular on the dX grid (width Wo)
+                tw = tw >= p.Wo ? tw - p.Wo : tw;
+                ok = ok && th >= 0 && ((th & (p.sh - 1)) == 0) && ((tw & (p.sw - 1)) == 0);
+                hi = th >> p.sh_log2;
+                wi = tw >> p.sw_log2;
+                ok = ok && hi < p.Hi;
+            } else {
+                hi = a_hi0[q] + dh;
+                wi = a_wi0[q] + (STEM ? lcol : dw);
+                wi = wi < 0 ? wi + p.Wi : wi;
+                wi = wi >= p.Wi ? wi - p.Wi : wi;
+                ok = ok && ((unsigned)hi < (unsigned)p.Hi);
+            }
             const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
-            const unsigned off = STEM ? pix * 16u : (pix * (unsigned)p.Cin + (unsigned)lcol * 4u) * 4u;
+            const unsigned off = STEM ? pix * 16u : (pix * (unsigned)p.xstride + (unsigned)lcol * 4u) * 4u;
             a_off[q] = ok ? off : OOB;
         }
     };
@@ -370,13 +387,19 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     a.x = d.x; a.w = d.w; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.y = d.y;
     a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
+    a.xstride = d.xstride ? d.xstride : d.Cin;
+    a.transposed = d.transposed;
+    a.sh_log2 = d.sh == 2 ? 1 : 0;
+    a.sw_log2 = d.sw == 2 ? 1 : 0;
+    HN_REQUIRE(!d.transposed || ((d.sh == 1 || d.sh == 2) && (d.sw == 1 || d.sw == 2) && !d.stem), "conv dgrad: strides must be 1 or 2");
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;
     a.ldy = d.ldy ? d.ldy : d.Cout;
     // 32-bit buffer offsets: a tile spans at most 2 images (+1 for safety) and one weight tile
     {   // 32-bit buffer offsets are relative to the tile's first image; a 128-row tile spans 128/(Ho*Wo)+2 images at most
         const double span = 128.0 / ((double)d.Ho * d.Wo) + 2.0;
-        HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 4 : d.Cin) * 4.0 < 2147483648.0, "conv: image too large for 32-bit tile offsets");
+        HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 4 : (d.xstride ? d.xstride : d.Cin)) * 4.0 < 2147483648.0,
+                   "conv: image too large for 32-bit tile offsets");
     }
     if (d.stem) {
         HN_REQUIRE(d.KH == 7 && d.KW == 7 && d.Cout == 64 && d.Cin == 4, "stem conv: expects 7x7, Cin(padded)=4, Cout=64");

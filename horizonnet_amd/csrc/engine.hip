@@ -1,8 +1,7 @@
 // C-ABI of libhorizonnet_hip.so: engine object, reference-state_dict binding, weight packing and
 // the eval-mode forward plan of HorizonNet(resnet50, use_rnn=True) -- reference model.py:254-281.
 // See include/horizonnet_hip.h for the contract of every entry point.
-#include "hn_common.h"
-#include "../../include/horizonnet_hip.h"
+#include "engine_internal.h"
 
 #include <stdarg.h>
 #include <string.h>
@@ -26,30 +25,6 @@ extern "C" const char* hn_last_error(void) { return g_err; }
 extern "C" int hn_abi_version(void) { return 1; }
 
 // ---- architecture table ------------------------------------------------------------------------
-namespace {
-
-constexpr int T_COLS = 256;      // sequence length = 1024 / step_cols (reference model.py:194,259)
-constexpr int IMG_H = 512, IMG_W = 1024;
-
-struct ConvLayer {
-    std::string wkey;            // "<...>.weight" (and ".bias" when has_bias)
-    std::string bnkey;           // "<...>" BatchNorm prefix
-    int cin, cout, k, has_bias;
-    size_t w_off, scale_off, shift_off;   // float offsets into the packed buffer
-};
-
-struct Arch {
-    std::vector<ConvLayer> convs;                 // order of the reference state_dict
-    std::unordered_map<std::string, int64_t> numel;   // every bindable key -> element count
-    // bottleneck index helpers
-    int stem = 0;
-    int block_first[4][6];                        // conv index of conv1 of layer li block j
-    int block_down[4];                            // conv index of downsample of layer li (block 0)
-    int ghc_first[4];                             // conv index of ghc_lst[s].layer[0]
-    size_t wih_off[2], lbias_off[2], whh_off[2][2], ones_off, zeros_off, linw_off, linb_off;
-    size_t packed_floats = 0;
-};
-
 size_t packed_w_floats(int cout, int cin, int k)
 {
     if (k == 7) return (size_t)cout * 7 * 8 * 4;
@@ -121,11 +96,32 @@ const Arch& arch()
         a.numel["linear.weight"] = 12 * 1024;
         a.numel["linear.bias"] = 12;
         a.packed_floats = off;
+        // flat gradient buffer: parameters in state_dict order, each 256-byte aligned
+        size_t goff = 0;
+        auto gtake = [&](const std::string& k, size_t n) { a.grad_off[k] = goff; goff += (n + 63) / 64 * 64; };
+        for (const auto& c : a.convs) {
+            gtake(c.wkey + ".weight", (size_t)c.cout * c.cin * c.k * c.k);
+            if (c.has_bias) gtake(c.wkey + ".bias", c.cout);
+            gtake(c.bnkey + ".weight", c.cout);
+            gtake(c.bnkey + ".bias", c.cout);
+        }
+        for (int l = 0; l < 2; ++l)
+            for (int d = 0; d < 2; ++d) {
+                const std::string suf = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+                gtake("bi_rnn.weight_ih" + suf, 2048 * 1024);
+                gtake("bi_rnn.weight_hh" + suf, 2048 * 512);
+                gtake("bi_rnn.bias_ih" + suf, 2048);
+                gtake("bi_rnn.bias_hh" + suf, 2048);
+            }
+        gtake("linear.weight", 12 * 1024);
+        gtake("linear.bias", 12);
+        a.grad_floats = goff;
         return a;
     }();
     return A;
 }
 
+namespace {
 // ---- workspace plan ----------------------------------------------------------------------------
 struct Plan {
     size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y2, total;   // float offsets
@@ -156,62 +152,6 @@ Plan make_plan(int B)
     return p;
 }
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-
-}  // namespace
-
-struct ProfEntry {
-    std::string name;
-    double flops;                        // algorithmic FLOPs of the launch group (0 for pure data movement)
-    hipEvent_t t0, t1;
-};
-
-struct hn_engine {
-    int device = 0;
-    std::unordered_map<std::string, const void*> bound;
-    const float* packed = nullptr;       // last packed buffer (caller owned)
-    bool profiling = false;
-    std::vector<ProfEntry> prof;         // entries of the last profiled hn_forward
-    std::vector<hipEvent_t> event_pool;
-    size_t events_used = 0;
-    hipEvent_t next_event()
-    {
-        if (events_used == event_pool.size()) {
-            hipEvent_t ev;
-            if (hipEventCreate(&ev) != hipSuccess) return nullptr;
-            event_pool.push_back(ev);
-        }
-        return event_pool[events_used++];
-    }
-};
-
-namespace {
-// RAII bracket: records start/stop events around one launch group when profiling is on.
-struct ProfScope {
-    hn_engine* e;
-    hipStream_t s;
-    bool on;
-    ProfScope(hn_engine* e_, hipStream_t s_, const std::string& name, double flops) : e(e_), s(s_), on(e_->profiling)
-    {
-        if (!on) return;
-        ProfEntry pe{name, flops, e->next_event(), e->next_event()};
-        e->prof.push_back(pe);
-        (void)hipEventRecord(pe.t0, s);
-    }
-    ~ProfScope()
-    {
-        if (on) (void)hipEventRecord(e->prof.back().t1, s);
-    }
-};
 }  // namespace
 
 // ---- engine API --------------------------------------------------------------------------------
@@ -536,4 +476,38 @@ extern "C" int hn_linear_head(const float* y, const float* w, const float* bias,
 {
     HN_REQUIRE(y && w && bias && bon && cor && T >= 1 && B >= 1, "hn_linear_head: bad argument");
     return hn_launch_linear_head(y, w, bias, bon, cor, T, B, (hipStream_t)stream);
+}
+
+// ---- training per-stage entry points (parity tests) ----------------------------------------------
+extern "C" int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B, int Hx,
+                                    int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream)
+{
+    HN_REQUIRE(dz && w_oihw && dx && w_scratch, "hn_conv2d_dgrad_nhwc: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_dgrad_nhwc: kernel %dx%d unsupported", KH, KW);
+    HN_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin <= 4096 && Cout <= 4096, "hn_conv2d_dgrad_nhwc: channels must be multiples of 32, <= 4096");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = hn_launch_pack_conv_dgrad(w_oihw, w_scratch, Cout, Cin, KH, KW, s))) return rc;
+    // ones / zeros for the epilogue live behind the packed dgrad weights in the scratch buffer
+    float* ones = w_scratch + (size_t)Cout * Cin * KH * KW;
+    float* zeros = ones + 4096;
+    if ((rc = hn_launch_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, ones, zeros, 4096, s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = dz; d.w = w_scratch; d.scale = ones; d.shift = zeros; d.res = add; d.y = dx;
+    d.B = B; d.Ho = Hx; d.Wo = Wx; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw; d.ph = KH / 2; d.pw = KW / 2;
+    d.Hi = (Hx + 2 * d.ph - KH) / sh + 1;
+    d.Wi = (Wx + 2 * d.pw - KW) / sw + 1;
+    d.Cin = Cout; d.Cout = Cin; d.relu = 0; d.ldy = Cin; d.transposed = 1;
+    return hn_launch_conv(d, s);
+}
+
+extern "C" int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
+                                    int Cout, int KH, int KW, int sh, int sw, int stem, void* stream)
+{
+    HN_REQUIRE(x && dz && dw_oihw && scratch, "hn_conv2d_wgrad_nhwc: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = hn_launch_conv_wgrad(x, dz, scratch, B, Hi, Wi, Cin, Cout, KH, KW, sh, sw, 0, 0, stem, s))) return rc;
+    return hn_launch_unpack_conv(scratch, dw_oihw, Cout, Cin, KH, KW, stem ? 8 : 0, s);
 }

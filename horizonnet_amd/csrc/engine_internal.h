@@ -1,0 +1,95 @@
+// Internal declarations shared by engine.hip (eval forward) and train.hip (training step).
+#pragma once
+#include "hn_common.h"
+#include "../../include/horizonnet_hip.h"
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---- architecture table ------------------------------------------------------------------------
+
+constexpr int T_COLS = 256;      // sequence length = 1024 / step_cols (reference model.py:194,259)
+constexpr int IMG_H = 512, IMG_W = 1024;
+
+struct ConvLayer {
+    std::string wkey;            // "<...>.weight" (and ".bias" when has_bias)
+    std::string bnkey;           // "<...>" BatchNorm prefix
+    int cin, cout, k, has_bias;
+    size_t w_off, scale_off, shift_off;   // float offsets into the packed buffer
+};
+
+struct Arch {
+    std::vector<ConvLayer> convs;                 // order of the reference state_dict
+    std::unordered_map<std::string, int64_t> numel;   // every bindable key -> element count
+    // bottleneck index helpers
+    int stem = 0;
+    int block_first[4][6];                        // conv index of conv1 of layer li block j
+    int block_down[4];                            // conv index of downsample of layer li (block 0)
+    int ghc_first[4];                             // conv index of ghc_lst[s].layer[0]
+    size_t wih_off[2], lbias_off[2], whh_off[2][2], ones_off, zeros_off, linw_off, linb_off;
+    size_t packed_floats = 0;
+    std::unordered_map<std::string, size_t> grad_off;   // parameter key -> float offset in the flat gradient buffer
+    size_t grad_floats = 0;
+};
+
+size_t packed_w_floats(int cout, int cin, int k);
+const Arch& arch();
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct ProfEntry {
+    std::string name;
+    double flops;                        // algorithmic FLOPs of the launch group (0 for pure data movement)
+    hipEvent_t t0, t1;
+};
+
+struct hn_engine {
+    int device = 0;
+    std::unordered_map<std::string, const void*> bound;
+    const float* packed = nullptr;       // last packed buffer (caller owned)
+    bool profiling = false;
+    int debug_unit = -1;                 // training debug tap (hn_train_debug_set): unit whose dy / dz are copied out
+    float* debug_dy = nullptr;
+    float* debug_dz = nullptr;
+    std::vector<ProfEntry> prof;         // entries of the last profiled hn_forward
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    hipEvent_t next_event()
+    {
+        if (events_used == event_pool.size()) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+            event_pool.push_back(ev);
+        }
+        return event_pool[events_used++];
+    }
+};
+
+// RAII bracket: records start/stop events around one launch group when profiling is on.
+struct ProfScope {
+    hn_engine* e;
+    hipStream_t s;
+    bool on;
+    ProfScope(hn_engine* e_, hipStream_t s_, const std::string& name, double flops) : e(e_), s(s_), on(e_->profiling)
+    {
+        if (!on) return;
+        ProfEntry pe{name, flops, e->next_event(), e->next_event()};
+        e->prof.push_back(pe);
+        (void)hipEventRecord(pe.t0, s);
+    }
+    ~ProfScope()
+    {
+        if (on) (void)hipEventRecord(e->prof.back().t1, s);
+    }
+};
+

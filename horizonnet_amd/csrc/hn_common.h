@@ -48,16 +48,45 @@ struct ConvDesc {
     int relu;
     int ldy;             // output row stride (floats)
     int stem;            // 1 = stem addressing (NHWC4 input, K = 7 rows x (8 taps x 4))
+    int xstride;         // floats between input pixels (0 = Cin)
+    int transposed;      // 1 = data-gradient mode: x = dY [B][Hi][Wi][Cin(=Cout of the fwd conv)], y = dX [B][Ho][Wo][Cout(=Cin fwd)],
+                         //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };
 int hn_launch_conv(const ConvDesc& d, hipStream_t s);
 int hn_launch_prep_nhwc4(const float* x, float* out, int B, int C_in, int H, int W, hipStream_t s);
 int hn_launch_maxpool(const float* in, float* out, int B, int Hi, int Wi, int C, hipStream_t s);
 int hn_launch_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
 int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r, float* y, int T, int B,
-                         void* sync_ws, hipStream_t s);
+                         void* sync_ws, hipStream_t s, float* save = nullptr);
+int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh_f, const float* whh_r, float* dh, int B, hipStream_t s);
+int hn_launch_transpose(const float* in, float* out, int R, int C, hipStream_t s);
+int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s);
+int hn_launch_bn_bwd_reduce(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd, double* S1,
+                            double* S2, long M, int C, hipStream_t s);
+int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float* a, float* b, float* save_mean, float* save_invstd, int C,
+                          hipStream_t s);
+int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, long M, int C, int relu,
+                         hipStream_t s);
+int hn_launch_bn_bwd_apply(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd,
+                           const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, long M, int C,
+                           hipStream_t s);
+int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
+int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
+int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int B, int Hi, int Wi, int C, hipStream_t s);
+int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
+int hn_launch_dropout(const float* in, float* out, long n, float p, unsigned long long seed, hipStream_t s);
+int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, const float* y, float* dy, float* dlin, float* dw,
+                       float* db, int T, int B, hipStream_t s);
+int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, const float* dh_rec, float* dc_rec, float* dgx, int T, int B, int step,
+                             hipStream_t s);
 int hn_launch_linear_head(const float* y, const float* w, const float* bias, float* bon, float* cor, int T, int B,
                           hipStream_t s);
 int hn_launch_pack_conv(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int hn_launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                       float* scale, float* shift, int C, hipStream_t s);
+int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
+                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s);
+int hn_launch_unpack_conv(const float* wp, float* w_oihw, int Cout, int Cin, int KH, int KW, int packed_rows, hipStream_t s);
+int hn_launch_pack_conv_dgrad(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int hn_launch_add_vec(const float* a, const float* b, float* out, long n, hipStream_t s);

@@ -40,7 +40,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 template <int BT>   // 16-row batch tiles per launch (1: <=16 panoramas, 2: <=32)
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ gx, const float* __restrict__ whh_f,
                                                          const float* __restrict__ whh_r, float* y, int T, int B,
-                                                         int b0, int bc, unsigned* sync)
+                                                         int b0, int bc, unsigned* sync, float* __restrict__ save)
 {
     __shared__ __attribute__((aligned(16))) float red[4 * BT * 16 * 17];
 
@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
             const float og = sigmoidf_(pre[3]);
             c_state = fg * c_state + ig * gg;
             const float h = og * tanhf(c_state);
+            if (gate_live && save) {   // training: keep (i, f, g, o, c) for the adjoint pass -- [t][b][dir][5][512]
+                float* sv = save + ((((size_t)t * B + b0 + gb) * 2 + dir) * 5) * LSTM_H + u0 + gu;
+                sv[0] = ig; sv[LSTM_H] = fg; sv[2 * LSTM_H] = gg; sv[3 * LSTM_H] = og; sv[4 * LSTM_H] = c_state;
+            }
             if (gate_live)      // write-through (sc1) store: visible to every XCD once the wave's vmcnt drains
                 __hip_atomic_store(y + ((size_t)t * B + b0 + gb) * 1024 + dir * LSTM_H + u0 + gu, h, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -167,10 +171,68 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
     }
 }
 
+// Adjoint recurrence GEMV for one step: dh[b][dir*512 + k] = sum_n dg[b][dir*2048 + n] * Whh_dir[n][k]
+// (reference: autograd of nn.LSTM, train.py:278).  256 workgroups x (32 b x 8 n-slices); 4 k-columns each.
+__global__ __launch_bounds__(256) void lstm_bwd_dh_kernel(const float* __restrict__ dg_f, const float* __restrict__ dg_r,
+                                                          const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                          float* __restrict__ dh, int B)
+{
+    const int dir = blockIdx.x & 1;
+    const int k0 = (blockIdx.x >> 1) * 4;
+    const float* whh = dir ? whh_r : whh_f;
+    const int part = threadIdx.x & 7;
+    const int b = blockIdx.y * 32 + (threadIdx.x >> 3);
+    const int bb = b < B ? b : B - 1;
+    const float* g = (dir ? dg_r : dg_f) + (size_t)bb * 4096 + dir * 2048 + part * 256;   // each direction at its own time index
+    const float* w = whh + (size_t)(part * 256) * 512 + k0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int n = 0; n < 256; n += 4) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += gv[j] * *reinterpret_cast<const f32x4*>(w + (size_t)(n + j) * 512);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = acc[k];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        acc[k] = v;
+    }
+    if (part == 0 && b < B) *reinterpret_cast<f32x4*>(dh + (size_t)b * 1024 + dir * 512 + k0) = acc;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C)
+{
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < R && bx + tx < C) tile[j][tx] = in[(size_t)(by + j) * C + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < C && by + tx < R) out[(size_t)(bx + j) * R + by + tx] = tile[tx][j];
+}
+
 }  // namespace
 
+int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh_f, const float* whh_r, float* dh, int B, hipStream_t s)
+{
+    hipLaunchKernelGGL(lstm_bwd_dh_kernel, dim3(256, (B + 31) / 32), dim3(256), 0, s, dg_f, dg_r, whh_f, whh_r, dh, B);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_transpose(const float* in, float* out, int R, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, out, R, C);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
 int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r, float* y, int T, int B,
-                         void* sync_ws, hipStream_t s)
+                         void* sync_ws, hipStream_t s, float* save)
 {
     HN_REQUIRE(T >= 1 && B >= 1, "lstm: bad T/B");
     HN_REQUIRE((size_t)T * B * 1024 * sizeof(float) <= 0xfffffff0ull, "lstm: T*B too large for 32-bit buffer offsets");
@@ -179,9 +241,9 @@ int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r
         const int bc = (B - b0) < 32 ? (B - b0) : 32;
         HN_HIP(hipMemsetAsync(sync, 0, STATUS_WORD * sizeof(unsigned), s));   // counters only; status is sticky
         if (bc <= 16)
-            hipLaunchKernelGGL(lstm_layer_kernel<1>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync);
+            hipLaunchKernelGGL(lstm_layer_kernel<1>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync, save);
         else
-            hipLaunchKernelGGL(lstm_layer_kernel<2>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync);
+            hipLaunchKernelGGL(lstm_layer_kernel<2>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync, save);
         HN_LAUNCH_CHECK();
     }
     return 0;

@@ -1,0 +1,446 @@
+// Training step of HorizonNet(resnet50, use_rnn=True) on the HIP engine: train-mode forward
+// (batch-statistics BatchNorm with running-stat update, dropout) and the full adjoint (all 379
+// parameter gradients).  Replaces what autograd does for `net(x)` + `loss.backward()` at reference
+// train.py:44-58,272-281; the losses and the optimiser stay in the caller.  float32 throughout.
+//
+// Every conv "unit" keeps its input x, pre-BN output z and post-activation output y resident in
+// HBM (0.98 GB per panorama for z+y -- sized for the 288 GB of the MI355X), so the backward pass
+// re-reads instead of recomputing.
+#include "engine_internal.h"
+
+#include <string.h>
+
+namespace {
+
+struct Unit {
+    int ci;                        // index into arch().convs
+    int Hi, Wi, sh, sw, Ho, Wo;
+    int relu;                      // ReLU directly after this unit's BN (conv3 / downsample: 0)
+    int stem;
+    size_t x, z, y, st;            // float offsets: input, pre-BN, post-activation, [mean|invstd|a|b]
+    long M;
+};
+
+struct TrainPlan {
+    std::vector<Unit> units;
+    int blk[4][6], dsu[4], ghc[4];         // unit indices
+    size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
+    size_t gmax;
+};
+
+const int kBlocks[4] = {3, 4, 6, 3};
+
+TrainPlan make_train_plan(int B)
+{
+    const Arch& a = arch();
+    TrainPlan p;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    const size_t b = (size_t)B;
+    p.sync = take(HN_SYNC_WORDS);
+    p.xn = take(b * IMG_H * IMG_W * 4);
+    auto add_unit = [&](int ci, size_t x, int Hi, int Wi, int sh, int sw, int relu, int stem) {
+        const ConvLayer& c = a.convs[ci];
+        Unit u;
+        u.ci = ci; u.Hi = Hi; u.Wi = Wi; u.sh = sh; u.sw = sw; u.relu = relu; u.stem = stem;
+        u.Ho = (Hi + 2 * (c.k / 2) - c.k) / sh + 1;
+        u.Wo = (Wi + 2 * (c.k / 2) - c.k) / sw + 1;
+        u.M = (long)B * u.Ho * u.Wo;
+        u.x = x;
+        u.z = take((size_t)u.M * c.cout);
+        u.y = take((size_t)u.M * c.cout);
+        u.st = take(4 * (size_t)c.cout);
+        p.units.push_back(u);
+        return (int)p.units.size() - 1;
+    };
+    const int us = add_unit(a.stem, p.xn, IMG_H, IMG_W, 2, 2, 1, 1);
+    (void)us;
+    p.pool = take(b * 128 * 256 * 64);
+    size_t cur = p.pool;
+    int H = 128, W = 256;
+    for (int li = 0; li < 4; ++li) {
+        for (int j = 0; j < kBlocks[li]; ++j) {
+            const int stride = (j == 0 && li > 0) ? 2 : 1;
+            const int c1 = add_unit(a.block_first[li][j], cur, H, W, 1, 1, 1, 0);
+            const int c2 = add_unit(a.block_first[li][j] + 1, p.units[c1].y, H, W, stride, stride, 1, 0);
+            if (j == 0) p.dsu[li] = add_unit(a.block_down[li], cur, H, W, stride, stride, 0, 0);
+            H /= stride;
+            W /= stride;
+            const int c3 = add_unit(a.block_first[li][j] + 2, p.units[c2].y, H, W, 1, 1, 0, 0);
+            p.blk[li][j] = c1;                    // c2 = c1 + 1; (ds = c1 + 2 when j == 0); c3 = last
+            cur = p.units[c3].y;
+        }
+        size_t gin = cur;
+        int gh = H;
+        for (int k = 0; k < 4; ++k) {
+            const int u = add_unit(a.ghc_first[li] + k, gin, gh, W, 2, 1, 1, 0);
+            if (k == 0) p.ghc[li] = u;
+            gin = p.units[u].y;
+            gh /= 2;
+        }
+    }
+    const size_t rows = (size_t)T_COLS * b;
+    p.seq = take(rows * 1024);
+    p.gx = take(rows * 4096);
+    p.y1 = take(rows * 1024);
+    p.y1d = take(rows * 1024);
+    p.y2 = take(rows * 1024);
+    p.y2d = take(rows * 1024);
+    p.save[0] = take(rows * 2 * 5 * 512);
+    p.save[1] = take(rows * 2 * 5 * 512);
+    p.dlin = take(rows * 12);
+    p.gmax = b * 256 * 512 * 64;                 // largest gradient tensor: d(stem output)
+    for (int i = 0; i < 4; ++i) p.G[i] = take(p.gmax);
+    const size_t csz[4] = {b * 128 * 256 * 256, b * 64 * 128 * 512, b * 32 * 64 * 1024, b * 16 * 32 * 2048};
+    for (int i = 0; i < 4; ++i) p.DC[i] = take(csz[i]);
+    p.dhrec = take(b * 1024);
+    p.dcrec = take(b * 1024);
+    p.wsA = take((size_t)1024 * 18432 + 64);      // largest packed weight (ghc3.0) / wgrad scratch
+    p.wsB = take((size_t)1024 * 18432 + 64);
+    p.dstat = take(4 * 4096 * 2);                 // 4 x 4096 doubles
+    p.total = off;
+    return p;
+}
+
+struct Ctx {
+    hn_engine* e;
+    const Arch& a;
+    const TrainPlan& pl;
+    float* W;              // workspace
+    const float* P;        // packed weights (forward layout)
+    float* grads;          // flat gradient buffer (may be null in forward)
+    hipStream_t s;
+    int B;
+    const float* bound(const std::string& k) const { return reinterpret_cast<const float*>(e->bound.at(k)); }
+    float* bound_mut(const std::string& k) const { return const_cast<float*>(reinterpret_cast<const float*>(e->bound.at(k))); }
+    float* grad(const std::string& k) const { return grads + a.grad_off.at(k); }
+};
+
+int conv_z(const Ctx& c, const Unit& u)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = c.W + u.x; d.w = c.P + cl.w_off; d.scale = c.P + c.a.ones_off;
+    d.shift = cl.has_bias ? c.bound(cl.wkey + ".bias") : c.P + c.a.zeros_off;
+    d.res = nullptr; d.y = c.W + u.z;
+    d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = u.stem ? 4 : cl.cin; d.Cout = cl.cout; d.KH = cl.k; d.KW = cl.k;
+    d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo; d.relu = 0; d.ldy = cl.cout; d.stem = u.stem;
+    return hn_launch_conv(d, c.s);
+}
+
+// z -> batch statistics -> y = act(bn(z) (+res)); updates the running statistics in place
+int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float momentum)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    const int C = cl.cout;
+    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
+    float* st = c.W + u.st;
+    int rc;
+    HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
+    if ((rc = hn_launch_col_stats(c.W + u.z, ds, ds + C, u.M, C, C, c.s))) return rc;
+    if ((rc = hn_launch_bn_finalize(ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
+                                    c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
+                                    st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
+        return rc;
+    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, u.M, C, relu, c.s);
+}
+
+// BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
+// tensor or null).  Produces dz (gradient w.r.t. the conv output), optional dpre (masked dy, the identity-branch
+// gradient), and the parameter gradients.
+int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    const int C = cl.cout;
+    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
+    const float* st = c.W + u.st;
+    int rc;
+    HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
+    if ((rc = hn_launch_bn_bwd_reduce(dy, ymask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.s))) return rc;
+    if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
+    if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
+    if ((rc = hn_launch_bn_bwd_apply(dy, ymask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M, dz, dpre,
+                                     u.M, C, c.s)))
+        return rc;
+    if (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) {
+        if (c.e->debug_dy) HN_HIP(hipMemcpyAsync(c.e->debug_dy, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        if (c.e->debug_dz) HN_HIP(hipMemcpyAsync(c.e->debug_dz, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+    }
+    if (cl.has_bias) {
+        double* db = ds + 2 * 4096;
+        HN_HIP(hipMemsetAsync(db, 0, (size_t)C * sizeof(double), c.s));
+        if ((rc = hn_launch_col_stats(dz, db, nullptr, u.M, C, C, c.s))) return rc;
+        if ((rc = hn_launch_d2f(db, c.grad(cl.wkey + ".bias"), C, c.s))) return rc;
+    }
+    // weight gradient (packed layout) -> OIHW
+    float* scratch = c.W + c.pl.wsA;
+    if ((rc = hn_launch_conv_wgrad(c.W + u.x, dz, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, 0, 0, u.stem, c.s)))
+        return rc;
+    return hn_launch_unpack_conv(scratch, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, u.stem ? 8 : 0, c.s);
+}
+
+// data gradient of one unit: dx = conv^T(dz) (+ add)
+int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, float* dx)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    float* wd = c.W + c.pl.wsB;
+    int rc;
+    if ((rc = hn_launch_pack_conv_dgrad(c.bound(cl.wkey + ".weight"), wd, cl.cout, cl.cin, cl.k, cl.k, c.s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = dz; d.w = wd; d.scale = c.P + c.a.ones_off; d.shift = c.P + c.a.zeros_off; d.res = add; d.y = dx;
+    d.B = c.B; d.Hi = u.Ho; d.Wi = u.Wo; d.Cin = cl.cout; d.Cout = cl.cin; d.KH = cl.k; d.KW = cl.k;
+    d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Hi; d.Wo = u.Wi; d.relu = 0; d.ldy = cl.cin;
+    d.transposed = 1;
+    return hn_launch_conv(d, c.s);
+}
+
+int gemm_rows(const float* x, int xstride, const float* w, const float* scale, const float* shift, float* y, long rows, int K, int N,
+              hipStream_t s)
+{
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.w = w; d.scale = scale; d.shift = shift; d.res = nullptr; d.y = y;
+    d.B = 1; d.Hi = 1; d.Wi = (int)rows; d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1;
+    d.Ho = 1; d.Wo = (int)rows; d.relu = 0; d.ldy = N; d.xstride = xstride;
+    return hn_launch_conv(d, s);
+}
+
+}  // namespace
+
+extern "C" size_t hn_train_workspace_bytes(int B)
+{
+    if (B < 1) return 0;
+    return make_train_plan(B).total * sizeof(float);
+}
+
+// Debug taps for the parity tests: geometry / workspace offsets of training unit `unit` (forward order: stem, then per
+// bottleneck conv1, conv2, [downsample], conv3, then the 4 height-compression convs of the scale), and a copy-out of the
+// gradients entering (dy) / leaving (dz) its BatchNorm adjoint during the next hn_train_backward.
+extern "C" int hn_train_debug_unit(int B, int unit, int64_t* out8)
+{
+    const TrainPlan pl = make_train_plan(B);
+    HN_REQUIRE(unit >= 0 && unit < (int)pl.units.size() && out8, "hn_train_debug_unit: bad unit %d (of %d)", unit, (int)pl.units.size());
+    const Unit& u = pl.units[unit];
+    out8[0] = u.ci; out8[1] = u.M; out8[2] = arch().convs[u.ci].cout; out8[3] = (int64_t)u.x; out8[4] = (int64_t)u.z;
+    out8[5] = (int64_t)u.y; out8[6] = (int64_t)u.st; out8[7] = (int64_t)pl.units.size();
+    return 0;
+}
+
+extern "C" int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* dz_dst)
+{
+    HN_REQUIRE(e != nullptr, "hn_train_debug_set: null engine");
+    e->debug_unit = unit; e->debug_dy = dy_dst; e->debug_dz = dz_dst;
+    return 0;
+}
+
+extern "C" size_t hn_grad_floats(void) { return arch().grad_floats; }
+
+extern "C" int64_t hn_grad_offset(const char* name)
+{
+    const Arch& a = arch();
+    auto it = a.grad_off.find(name ? name : "");
+    return it == a.grad_off.end() ? -1 : (int64_t)it->second;
+}
+
+extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                                size_t workspace_bytes, float p_rnn, float p_head, float bn_momentum, uint64_t seed, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_train_forward: null argument");
+    HN_REQUIRE(e->packed != nullptr, "hn_train_forward: hn_pack_weights has not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_train_forward: bad B=%d / C_in=%d", B, C_in);
+    HN_REQUIRE(p_rnn >= 0.f && p_rnn < 1.f && p_head >= 0.f && p_head < 1.f, "hn_train_forward: dropout p out of range");
+    const TrainPlan pl = make_train_plan(B);
+    HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_train_forward: workspace too small (%zu < %zu)", workspace_bytes,
+               pl.total * sizeof(float));
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_train_forward: cannot select device %d", e->device);
+    Ctx c{e, arch(), pl, reinterpret_cast<float*>(workspace), e->packed, nullptr, (hipStream_t)stream, B};
+    const Arch& a = c.a;
+    float* W = c.W;
+    hipStream_t s = c.s;
+    int rc;
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
+
+    // stem
+    if ((rc = hn_launch_prep_nhwc4(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
+    {
+        const Unit& u = pl.units[0];
+        if ((rc = conv_z(c, u))) return rc;
+        if ((rc = bn_forward(c, u, nullptr, 1, bn_momentum))) return rc;
+        if ((rc = hn_launch_maxpool(W + u.y, W + pl.pool, B, 256, 512, 64, s))) return rc;
+    }
+    // backbone + height compression
+    for (int li = 0; li < 4; ++li) {
+        for (int j = 0; j < kBlocks[li]; ++j) {
+            const int i1 = pl.blk[li][j];
+            const Unit& u1 = pl.units[i1];
+            const Unit& u2 = pl.units[i1 + 1];
+            const Unit& u3 = pl.units[i1 + (j == 0 ? 3 : 2)];
+            if ((rc = conv_z(c, u1)) || (rc = bn_forward(c, u1, nullptr, 1, bn_momentum))) return rc;
+            if ((rc = conv_z(c, u2)) || (rc = bn_forward(c, u2, nullptr, 1, bn_momentum))) return rc;
+            const float* idt = W + u1.x;
+            if (j == 0) {
+                const Unit& ud = pl.units[pl.dsu[li]];
+                if ((rc = conv_z(c, ud)) || (rc = bn_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
+                idt = W + ud.y;
+            }
+            if ((rc = conv_z(c, u3)) || (rc = bn_forward(c, u3, idt, 1, bn_momentum))) return rc;
+        }
+        for (int k = 0; k < 4; ++k) {
+            const Unit& ug = pl.units[pl.ghc[li] + k];
+            if ((rc = conv_z(c, ug)) || (rc = bn_forward(c, ug, nullptr, 1, bn_momentum))) return rc;
+        }
+        const Unit& ul = pl.units[pl.ghc[li] + 3];
+        if ((rc = hn_launch_upsample_flatten(W + ul.y, W + pl.seq, B, ul.Ho, ul.Wo, a.convs[ul.ci].cout, 256 * li, s))) return rc;
+    }
+    // bi-LSTM x2 (+ inter-layer dropout) + head dropout + Linear
+    const long rows = (long)T_COLS * B;
+    const float* lin = W + pl.seq;
+    float* ybuf[2] = {W + pl.y1, W + pl.y2};
+    float* ydrop[2] = {W + pl.y1d, W + pl.y2d};
+    const float pdrop[2] = {p_rnn, p_head};
+    for (int l = 0; l < 2; ++l) {
+        if ((rc = gemm_rows(lin, 0, c.P + a.wih_off[l], c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
+        if ((rc = hn_launch_lstm_layer(W + pl.gx, c.P + a.whh_off[l][0], c.P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s,
+                                       W + pl.save[l])))
+            return rc;
+        if (pdrop[l] > 0.f) {
+            if ((rc = hn_launch_dropout(ybuf[l], ydrop[l], rows * 1024, pdrop[l], seed * 2 + 1 + l, s))) return rc;
+        } else {
+            HN_HIP(hipMemcpyAsync(ydrop[l], ybuf[l], rows * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        lin = ydrop[l];
+    }
+    return hn_launch_linear_head(W + pl.y2d, c.P + a.linw_off, c.P + a.linb_off, bon, cor, T_COLS, B, s);
+}
+
+extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
+                                 float* grads, float p_rnn, float p_head, uint64_t seed, void* stream)
+{
+    HN_REQUIRE(e && dbon && dcor && workspace && grads, "hn_train_backward: null argument");
+    const TrainPlan pl = make_train_plan(B);
+    HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_train_backward: workspace too small");
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_train_backward: cannot select device %d", e->device);
+    Ctx c{e, arch(), pl, reinterpret_cast<float*>(workspace), e->packed, grads, (hipStream_t)stream, B};
+    const Arch& a = c.a;
+    float* W = c.W;
+    hipStream_t s = c.s;
+    int rc;
+    const long rows = (long)T_COLS * B;
+    float* G0 = W + pl.G[0];
+    float* G1 = W + pl.G[1];
+    float* G2 = W + pl.G[2];
+    float* G3 = W + pl.G[3];
+    double* ds = reinterpret_cast<double*>(W + pl.dstat);
+
+    // ---- head: Linear + dropout ----
+    if ((rc = hn_launch_head_bwd(dbon, dcor, c.bound("linear.weight"), W + pl.y2d, G0, W + pl.dlin, c.grad("linear.weight"),
+                                 c.grad("linear.bias"), T_COLS, B, s)))
+        return rc;
+    float* dy = G0;                                   // gradient w.r.t. the (dropped) LSTM output
+    const float pdrop[2] = {p_rnn, p_head};
+    const float* layer_in[2] = {W + pl.seq, W + pl.y1d};
+    const float* layer_out[2] = {W + pl.y1, W + pl.y2};
+    float* dx_buf[2] = {G2, G1};                      // layer 1 writes dx into G1, layer 0 into G2
+    for (int l = 1; l >= 0; --l) {
+        if (pdrop[l] > 0.f)
+            if ((rc = hn_launch_dropout(dy, dy, rows * 1024, pdrop[l], seed * 2 + 1 + l, s))) return rc;
+        // recurrence adjoint, one time index per direction per step
+        float* dgx = W + pl.gx;
+        HN_HIP(hipMemsetAsync(W + pl.dhrec, 0, (size_t)B * 1024 * sizeof(float), s));
+        HN_HIP(hipMemsetAsync(W + pl.dcrec, 0, (size_t)B * 1024 * sizeof(float), s));
+        const std::string sf = "_l" + std::to_string(l), sr = sf + "_reverse";
+        for (int step = 0; step < T_COLS; ++step) {
+            if ((rc = hn_launch_lstm_bwd_gates(W + pl.save[l], dy, W + pl.dhrec, W + pl.dcrec, dgx, T_COLS, B, step, s))) return rc;
+            const int tf = T_COLS - 1 - step, tr = step;
+            if ((rc = hn_launch_lstm_bwd_dh(dgx + (size_t)tf * B * 4096, dgx + (size_t)tr * B * 4096, c.bound("bi_rnn.weight_hh" + sf),
+                                            c.bound("bi_rnn.weight_hh" + sr), W + pl.dhrec, B, s)))
+                return rc;
+        }
+        // dW_hh = sum_t dg_t^T h_{t-1}   (fwd: rows m >= B pair with y rows m - B; rev: rows m < (T-1)B pair with y rows m + B)
+        if ((rc = hn_launch_conv_wgrad(layer_out[l], dgx + (size_t)B * 4096, c.grad("bi_rnn.weight_hh" + sf), 1, 1, (int)(rows - B), 512,
+                                       2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
+            return rc;
+        if ((rc = hn_launch_conv_wgrad(layer_out[l] + (size_t)B * 1024 + 512, dgx + 2048, c.grad("bi_rnn.weight_hh" + sr), 1, 1,
+                                       (int)(rows - B), 512, 2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
+            return rc;
+        // dW_ih (both directions stacked) and the bias gradients
+        float* wsc = W + pl.wsA;
+        if ((rc = hn_launch_conv_wgrad(layer_in[l], dgx, wsc, 1, 1, (int)rows, 1024, 4096, 1, 1, 1, 1, 1024, 4096, 0, s))) return rc;
+        HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sf), wsc, (size_t)2048 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sr), wsc + (size_t)2048 * 1024, (size_t)2048 * 1024 * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
+        HN_HIP(hipMemsetAsync(ds, 0, 4096 * sizeof(double), s));
+        if ((rc = hn_launch_col_stats(dgx, ds, nullptr, rows, 4096, 4096, s))) return rc;
+        if ((rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_ih" + sf), 2048, s))) return rc;
+        if ((rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_hh" + sf), 2048, s))) return rc;
+        if ((rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_ih" + sr), 2048, s))) return rc;
+        if ((rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_hh" + sr), 2048, s))) return rc;
+        // dx = dg @ [W_ih_fwd; W_ih_rev]   (GEMM weights [N=1024][K=4096] = transpose of the stacked W_ih)
+        float* wt = W + pl.wsB;
+        if ((rc = hn_launch_transpose(c.P + a.wih_off[l], wt, 4096, 1024, s))) return rc;
+        if ((rc = gemm_rows(dgx, 0, wt, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s))) return rc;
+        dy = dx_buf[l];
+    }
+    float* dseq = dy;                                  // = G2: gradient w.r.t. the [256*B][1024] sequence matrix
+
+    // ---- height compression, all four scales: leaves d(C_s) in DC[s] ----
+    for (int li = 0; li < 4; ++li) {
+        const Unit& ul = pl.units[pl.ghc[li] + 3];
+        if ((rc = hn_launch_upsample_flatten_bwd(dseq, G0, B, ul.Ho, ul.Wo, a.convs[ul.ci].cout, 256 * li, s))) return rc;
+        float* gy = G0;
+        float* gz = G1;
+        float* gx = G3;
+        for (int k = 3; k >= 0; --k) {
+            const Unit& u = pl.units[pl.ghc[li] + k];
+            if ((rc = unit_backward(c, u, gy, W + u.y, gz, nullptr))) return rc;
+            float* out = (k == 0) ? W + pl.DC[li] : gx;
+            if ((rc = unit_dgrad(c, u, gz, nullptr, out))) return rc;
+            float* t = gy; gy = gx; gx = t;            // next unit's dy is what was just written
+        }
+    }
+
+    // ---- backbone, layer4 -> layer1 ----
+    float* Ga = G0;
+    float* Gb = G1;
+    float* Gc = G2;
+    float* Gd = G3;
+    const size_t csz[4] = {(size_t)B * 128 * 256 * 256, (size_t)B * 64 * 128 * 512, (size_t)B * 32 * 64 * 1024, (size_t)B * 16 * 32 * 2048};
+    HN_HIP(hipMemcpyAsync(Ga, W + pl.DC[3], csz[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int li = 3; li >= 0; --li) {
+        for (int j = kBlocks[li] - 1; j >= 0; --j) {
+            const int i1 = pl.blk[li][j];
+            const Unit& u1 = pl.units[i1];
+            const Unit& u2 = pl.units[i1 + 1];
+            const Unit& u3 = pl.units[i1 + (j == 0 ? 3 : 2)];
+            // conv3 + bn3 + (add) + relu: mask = block output
+            if ((rc = unit_backward(c, u3, Ga, W + u3.y, Gb, Gc))) return rc;       // dz3 -> Gb, identity grad -> Gc
+            if ((rc = unit_dgrad(c, u3, Gb, nullptr, Gd))) return rc;               // d(t2) -> Gd
+            if ((rc = unit_backward(c, u2, Gd, W + u2.y, Ga, nullptr))) return rc;  // dz2 -> Ga
+            if ((rc = unit_dgrad(c, u2, Ga, nullptr, Gb))) return rc;               // d(t1) -> Gb
+            if ((rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> Gd
+            if (j == 0) {
+                const Unit& ud = pl.units[pl.dsu[li]];
+                if ((rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr))) return rc;   // dz_ds -> Ga
+                if ((rc = unit_dgrad(c, ud, Ga, nullptr, Gb))) return rc;               // ds path -> Gb
+                if ((rc = unit_dgrad(c, u1, Gd, Gb, Gc))) return rc;                    // + conv1 path -> Gc
+                float* t = Ga; Ga = Gc; Gc = t;
+            } else {
+                if ((rc = unit_dgrad(c, u1, Gd, Gc, Ga))) return rc;                    // conv1 path + identity -> Ga
+            }
+        }
+        if (li > 0) {   // the block input of layer li is C_{li-1}: add the height-compression branch's gradient
+            if ((rc = hn_launch_axpy(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s))) return rc;
+        }
+    }
+    // ---- max-pool + stem ----
+    {
+        const Unit& u = pl.units[0];
+        if ((rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
+        if ((rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr))) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,441 @@
+// Training-mode helper kernels of the HorizonNet step (reference train.py:44-58,272-281 drives
+// autograd through model.py:254-281): batch-statistics BatchNorm forward/backward, ReLU masks,
+// column reductions, max-pool / up-sample adjoints, dropout, the Linear head's adjoint and the
+// per-step LSTM gate adjoint.  All HBM-bound, NHWC / row-major float32, float4 vectorised; column
+// reductions accumulate per-thread partials in f32 and combine across workgroups with f64 atomics.
+#include "hn_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions over a row-major [M][C] matrix.  MODE 0: sum(a), sum(a*a)           (BN statistics, bias grads)
+//                                                    MODE 1: sum(g), sum(g * (z - mean) * invstd)   with g = dy * (y > 0 | 1)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ ymask,
+                                                         const float* __restrict__ z, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, double* __restrict__ out0,
+                                                         double* __restrict__ out1, long M, int C, int lda, int slab)
+{
+    __shared__ float red[2][256 * 4];
+    const int CQ = (C < 256 ? C : 256) / 4;      // column quads per workgroup
+    const int RL = 256 / CQ;                     // row lanes
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const int col = blockIdx.y * 256 + cq * 4;
+    const long r0 = (long)blockIdx.x * slab;
+    long r1 = r0 + slab;
+    if (r1 > M) r1 = M;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+    if (MODE == 1) {
+        mu = *reinterpret_cast<const f32x4*>(mean + col);
+        is = *reinterpret_cast<const f32x4*>(invstd + col);
+    }
+    if (rl < RL) {
+        for (long r = r0 + rl; r < r1; r += RL) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(a + r * lda + col);
+            if (MODE == 0) {
+                s0 += v;
+                s1 += v * v;
+            } else {
+                if (ymask) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(ymask + r * (long)C + col);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
+                }
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * (long)C + col);
+                s0 += v;
+                s1 += v * ((zz - mu) * is);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[0][threadIdx.x * 4 + k] = s0[k];
+        red[1][threadIdx.x * 4 + k] = s1[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < CQ * 4) {
+        const int q = threadIdx.x / 4, k = threadIdx.x % 4;
+        float t0 = 0.f, t1 = 0.f;
+        for (int j = 0; j < RL; ++j) {
+            t0 += red[0][(j * CQ + q) * 4 + k];
+            t1 += red[1][(j * CQ + q) * 4 + k];
+        }
+        const int c = blockIdx.y * 256 + q * 4 + k;
+        atomicAdd(out0 + c, (double)t0);
+        if (out1) atomicAdd(out1 + c, (double)t1);
+    }
+}
+
+// BN(train) statistics -> per-channel affine + saved mean / invstd + running-stat update (momentum, unbiased var)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sum, const double* sumsq, double n, const float* gamma,
+                                                          const float* beta, float* running_mean, float* running_var,
+                                                          float momentum, float* a, float* b, float* save_mean,
+                                                          float* save_invstd, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sum[c] / n;
+    double var = sumsq[c] / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float aa = gamma[c] * invstd;
+    a[c] = aa;
+    b[c] = beta[c] - (float)m * aa;
+    save_mean[c] = (float)m;
+    save_invstd[c] = invstd;
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = act(z * a[c] + b[c] (+ res))
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                         const float* __restrict__ b, const float* __restrict__ res,
+                                                         float* __restrict__ y, long total4, int C4, int relu)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+        v = v * *reinterpret_cast<const f32x4*>(a + c) + *reinterpret_cast<const f32x4*>(b + c);
+        if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+// BN backward apply: g = dy * mask;  dz = gamma*invstd * (g - S1/N - zhat * S2/N);  optional dpre = g (identity branch)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                           const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ S1, const double* __restrict__ S2, double n,
+                                                           float* __restrict__ dz, float* __restrict__ dpre, long total4, int C4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        if (ymask) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(ymask + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
+        }
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float is = invstd[c + k];
+            const float zh = (zz[k] - mean[c + k]) * is;
+            const float m1 = (float)(S1[c + k] / n), m2 = (float)(S2[c + k] / n);
+            o[k] = gamma[c + k] * is * (g[k] - m1 - zh * m2);
+        }
+        *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+        if (dpre) *reinterpret_cast<f32x4*>(dpre + i * 4) = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void d2f_kernel(const double* in, float* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        *reinterpret_cast<f32x4*>(y + i * 4) += *reinterpret_cast<const f32x4*>(x + i * 4);
+}
+
+// max-pool 3x3/2 pad 1 adjoint (gather form, deterministic): each input pixel collects from the <= 4 windows
+// that contain it and whose arg-max (first maximum in row-major window order, as torch) it is.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                          float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C, long total)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int wi = (int)(t % Wi);
+        t /= Wi;
+        const int hi = (int)(t % Hi);
+        const long b = t / Hi;
+        const float v = in[i];
+        float g = 0.f;
+        for (int ho = (hi) / 2; ho <= (hi + 1) / 2; ++ho) {           // windows rows covering hi: 2*ho-1 <= hi <= 2*ho+1
+            if (ho < 0 || ho >= Ho) continue;
+            for (int wo = (wi) / 2; wo <= (wi + 1) / 2; ++wo) {
+                if (wo < 0 || wo >= Wo) continue;
+                // is (hi, wi) the first maximum of window (ho, wo)?
+                bool first = true;
+                for (int dh = 0; dh < 3 && first; ++dh) {
+                    const int h2 = ho * 2 - 1 + dh;
+                    if ((unsigned)h2 >= (unsigned)Hi) continue;
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int w2 = wo * 2 - 1 + dw;
+                        if ((unsigned)w2 >= (unsigned)Wi) continue;
+                        const float u = in[((b * Hi + h2) * Wi + w2) * (long)C + c];
+                        const bool before = (h2 < hi) || (h2 == hi && w2 < wi);
+                        if (u > v || (before && u == v)) { first = false; break; }
+                    }
+                }
+                if (first) g += dout[((b * Ho + ho) * Wo + wo) * (long)C + c];
+            }
+        }
+        din[i] = g;
+    }
+}
+
+// adjoint of upsample_flatten: din[b][h][i][c] = sum_t w0(t)[i0(t)==i] * dseq + w1(t)[i1(t)==i] * dseq
+__global__ __launch_bounds__(256) void upsample_flatten_bwd_kernel(const float* __restrict__ dseq, float* __restrict__ din, int B, int hq,
+                                                                   int Wq, int cq, int col0, int f)
+{
+    const int i = blockIdx.x;            // input column
+    const int b = blockIdx.y;
+    const int n = cq * hq;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int c = e % cq, h = e / cq;
+        float g = 0.f;
+        // outputs t whose footprint can touch column i: padded source index src(t) in [i, i+2)
+        for (int t = 0; t < 256; ++t) {
+            const float src = (1.0f / (float)f) * ((float)(t + f) + 0.5f) - 0.5f;
+            const int i0p = (int)src;
+            const float w1 = src - (float)i0p, w0 = 1.0f - w1;
+            int i0 = i0p - 1;
+            i0 = i0 < 0 ? i0 + Wq : i0;
+            int i1 = i0p;
+            i1 = i1 >= Wq ? i1 - Wq : i1;
+            if (i0 != i && i1 != i) continue;
+            const float d = dseq[((long)t * B + b) * 1024 + col0 + c * hq + h];
+            if (i0 == i) g += w0 * d;
+            if (i1 == i) g += w1 * d;
+        }
+        din[(((long)b * hq + h) * Wq + i) * cq + c] = g;
+    }
+}
+
+// counter-based dropout mask: keep iff hash(seed, index) >= p * 2^32; out = in * keep / (1 - p)
+__device__ __forceinline__ unsigned hash32(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (unsigned)x;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float p,
+                                                      unsigned long long seed)
+{
+    const unsigned thr = (unsigned)((double)p * 4294967296.0);
+    const float sc = 1.0f / (1.0f - p);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = hash32(seed * 0x9e3779b97f4a7c15ULL + (unsigned long long)i) >= thr ? in[i] * sc : 0.f;
+}
+
+// Linear head adjoint: dlin[t*B+b][12] gathered from dbon / dcor; dy[row][k] = sum_o dlin[row][o] * w[o][k]
+__global__ __launch_bounds__(256) void head_bwd_dy_kernel(const float* __restrict__ dbon, const float* __restrict__ dcor,
+                                                          const float* __restrict__ w, float* __restrict__ dy,
+                                                          float* __restrict__ dlin, int T, int B)
+{
+    const long row = blockIdx.x;
+    const int t = (int)(row / B), b = (int)(row % B);
+    __shared__ float dl[12];
+    if (threadIdx.x < 12) {
+        const int ch = threadIdx.x >> 2, s = threadIdx.x & 3;
+        const int W = 4 * T;
+        const float v = ch == 0 ? dcor[(long)b * W + 4 * t + s] : dbon[((long)b * 2 + (ch - 1)) * W + 4 * t + s];
+        dl[threadIdx.x] = v;
+        dlin[row * 12 + threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 12; ++o) s += dl[o] * w[o * 1024 + k];
+        dy[row * 1024 + k] = s;
+    }
+}
+// dW[o][k] = sum_rows dlin[row][o] * y[row][k];  db[o] = sum_rows dlin[row][o]   (one workgroup per 64 k-columns, f64 atomics-free)
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ dlin, const float* __restrict__ y,
+                                                          float* __restrict__ dw, float* __restrict__ db, long rows)
+{
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;                 // 4 row partitions
+    float acc[12];
+#pragma unroll
+    for (int o = 0; o < 12; ++o) acc[o] = 0.f;
+    float bsum[12];
+#pragma unroll
+    for (int o = 0; o < 12; ++o) bsum[o] = 0.f;
+    for (long r = part; r < rows; r += 4) {
+        const float yv = y[r * 1024 + k];
+#pragma unroll
+        for (int o = 0; o < 12; ++o) {
+            const float d = dlin[r * 12 + o];
+            acc[o] += d * yv;
+            bsum[o] += d;
+        }
+    }
+    __shared__ float red[4][12][64];
+    __shared__ float redb[4][12];
+#pragma unroll
+    for (int o = 0; o < 12; ++o) red[part][o][threadIdx.x & 63] = acc[o];
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int o = 0; o < 12; ++o) redb[part][o] = bsum[o];
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int o = 0; o < 12; ++o)
+            dw[o * 1024 + k] = red[0][o][threadIdx.x] + red[1][o][threadIdx.x] + red[2][o][threadIdx.x] + red[3][o][threadIdx.x];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 12) db[threadIdx.x] = redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x];
+}
+
+// LSTM gate adjoint for ONE time index per direction (fwd at t_f, rev at t_r):
+//   saved[t][b][dir][5][512] = (i, f, g, o, c) post-activation;  c_prev = c of the previous step of that direction (0 at its first step)
+//   dh = dy[t][b][dir*512+u] + dh_rec[b][dir*512+u];  standard LSTM adjoint -> dgx[t][b][dir*2048 + gate*512 + u], dc_rec updated in place
+__global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __restrict__ saved, const float* __restrict__ dy,
+                                                             const float* __restrict__ dh_rec, float* __restrict__ dc_rec,
+                                                             float* __restrict__ dgx, int T, int B, int step)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over B * 2 * 512
+    if (idx >= B * 1024) return;
+    const int u = idx & 511;
+    const int dir = (idx >> 9) & 1;
+    const int b = idx >> 10;
+    // backward walks each direction's own time order in reverse: fwd dir at t = T-1-step, rev dir at t = step
+    const int t = dir ? step : T - 1 - step;
+    const int tprev = dir ? t + 1 : t - 1;                     // the step that ran BEFORE t in that direction's forward pass
+    const float* sv = saved + (((size_t)t * B + b) * 2 + dir) * 5 * 512;
+    const float ig = sv[u], fg = sv[512 + u], gg = sv[1024 + u], og = sv[1536 + u], c = sv[2048 + u];
+    float cprev = 0.f;
+    if (tprev >= 0 && tprev < T) cprev = saved[((((size_t)tprev * B + b) * 2 + dir) * 5 + 4) * 512 + u];
+    const float dh = dy[((size_t)t * B + b) * 1024 + dir * 512 + u] + dh_rec[(size_t)b * 1024 + dir * 512 + u];
+    const float tc = tanhf(c);
+    const float dc = dc_rec[(size_t)b * 1024 + dir * 512 + u] + dh * og * (1.f - tc * tc);
+    float* g = dgx + ((size_t)t * B + b) * 4096 + dir * 2048 + u;
+    g[0] = dc * gg * ig * (1.f - ig);            // d pre-activation of i
+    g[512] = dc * cprev * fg * (1.f - fg);       // f
+    g[1024] = dc * ig * (1.f - gg * gg);         // g (tanh)
+    g[1536] = dh * tc * og * (1.f - og);         // o
+    dc_rec[(size_t)b * 1024 + dir * 512 + u] = dc * fg;
+}
+
+inline unsigned grid_for(long total, long cap = 256L * 16)
+{
+    long g = (total + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s)
+{
+    HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "col_stats: unsupported C=%d", C);
+    const int slab = 1024;
+    dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
+    hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_bn_bwd_reduce(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd, double* S1,
+                            double* S2, long M, int C, hipStream_t s)
+{
+    HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "bn_bwd_reduce: unsupported C=%d", C);
+    const int slab = 1024;
+    dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
+    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, ymask, z, mean, invstd, S1, S2, M, C, C, slab);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float* a, float* b, float* save_mean, float* save_invstd, int C,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sum, sumsq, n, gamma, beta, running_mean,
+                       running_var, momentum, a, b, save_mean, save_invstd, C);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, long M, int C, int relu,
+                         hipStream_t s)
+{
+    const long total4 = M * C / 4;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, total4, C / 4, relu);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_bn_bwd_apply(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd,
+                           const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, long M, int C,
+                           hipStream_t s)
+{
+    const long total4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, ymask, z, mean, invstd, gamma, S1, S2, n, dz,
+                       dpre, total4, C / 4);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(d2f_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s)
+{
+    HN_REQUIRE(n % 4 == 0, "axpy: n %% 4");
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, y, n / 4);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int B, int Hi, int Wi, int C, hipStream_t s)
+{
+    const long total = (long)B * Hi * Wi * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, in, dout, din, Hi, Wi, Hi / 2, Wi / 2, C, total);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, hipStream_t s)
+{
+    hipLaunchKernelGGL(upsample_flatten_bwd_kernel, dim3(Wq, B), dim3(256), 0, s, dseq, din, B, hq, Wq, cq, col0, 256 / Wq);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_dropout(const float* in, float* out, long n, float p, unsigned long long seed, hipStream_t s)
+{
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n, p, seed);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, const float* y, float* dy, float* dlin, float* dw,
+                       float* db, int T, int B, hipStream_t s)
+{
+    const long rows = (long)T * B;
+    hipLaunchKernelGGL(head_bwd_dy_kernel, dim3((unsigned)rows), dim3(256), 0, s, dbon, dcor, w, dy, dlin, T, B);
+    HN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(16), dim3(256), 0, s, dlin, y, dw, db, rows);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, const float* dh_rec, float* dc_rec, float* dgx, int T, int B, int step,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(lstm_bwd_gates_kernel, dim3((B * 1024 + 255) / 256), dim3(256), 0, s, saved, dy, dh_rec, dc_rec, dgx, T, B, step);
+    HN_LAUNCH_CHECK();
+    return 0;
+}

@@ -129,11 +129,68 @@ class _DeviceState:
             self.workspaces[B] = ws
         return ws
 
+    def train_workspace(self, B):
+        ws = self.workspaces.get(("train", B))
+        if ws is None:
+            self.workspaces.clear()
+            ws = torch.empty(self.lib.hn_train_workspace_bytes(B), dtype=torch.uint8, device=self.device)
+            self.workspaces[("train", B)] = ws
+        return ws
+
     def __del__(self):
         try:
             self.lib.hn_destroy(self.handle)
         except Exception:
             pass
+
+
+class _HipTrainStep(torch.autograd.Function):
+    """autograd node of one train-mode forward on the HIP engine (hn_train_forward / hn_train_backward)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        st = net._hip_state(x.device)
+        B, C_in = int(x.shape[0]), int(x.shape[1])
+        ws = st.train_workspace(B)
+        bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
+        cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
+        bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
+        momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+        seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())        # host RNG: follows torch.manual_seed
+        p_rnn, p_head = float(net.bi_rnn.dropout), float(net.drop_out.p)
+        _lib.check(st.lib.hn_train_forward(st.handle, _lib.ptr(x), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws), ws.numel(),
+                                           p_rnn, p_head, float(momentum), seed, _lib.stream_ptr(x.device)), "hn_train_forward")
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        net._train_steps += 1                                    # running stats changed under torch's feet
+        ctx.net, ctx.B, ctx.seed, ctx.p = net, B, seed, (p_rnn, p_head)
+        ctx.names = net._param_names
+        ctx.needs = [p.requires_grad for p in params]
+        return bon, cor
+
+    @staticmethod
+    def backward(ctx, dbon, dcor):
+        net = ctx.net
+        dev = dbon.device if dbon is not None else dcor.device
+        st = net._hip_states[dev.index]
+        B = ctx.B
+        dbon = torch.zeros((B, 2, 1024), device=dev) if dbon is None else dbon.contiguous().float()
+        dcor = torch.zeros((B, 1, 1024), device=dev) if dcor is None else dcor.contiguous().float()
+        ws = st.train_workspace(B)
+        flat = torch.empty(st.lib.hn_grad_floats(), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(st.lib.hn_train_backward(st.handle, _lib.ptr(dbon), _lib.ptr(dcor), B, _lib.ptr(ws), ws.numel(), _lib.ptr(flat),
+                                                ctx.p[0], ctx.p[1], ctx.seed, _lib.stream_ptr(dev)), "hn_train_backward")
+        grads = []
+        for (name, shape), need in zip(ctx.names, ctx.needs):
+            if not need:
+                grads.append(None)
+                continue
+            off = st.lib.hn_grad_offset(name.encode())
+            n = 1
+            for d in shape:
+                n *= d
+            grads.append(flat[off:off + n].view(shape))
+        return (None, None) + tuple(grads)
 
 
 class HorizonNet(nn.Module):
@@ -164,6 +221,8 @@ class HorizonNet(nn.Module):
             self.linear.bias[1 * self.step_cols:2 * self.step_cols].fill_(-0.478)
             self.linear.bias[2 * self.step_cols:3 * self.step_cols].fill_(0.425)
         self._hip_states = {}
+        self._train_steps = 0
+        self._param_names = [(k, tuple(p.shape)) for k, p in self.named_parameters()]
 
     # ---- engine plumbing --------------------------------------------------------------------
     def _state_tensors(self):
@@ -177,7 +236,7 @@ class HorizonNet(nn.Module):
             st = _DeviceState(device)
             self._hip_states[device.index] = st
         tensors = list(self._state_tensors())
-        sig = tuple((t.data_ptr(), t._version) for _, t in tensors)
+        sig = tuple((t.data_ptr(), t._version) for _, t in tensors) + (self._train_steps,)
         if sig != st.signature:
             keep = []
             for k, t in tensors:
@@ -205,10 +264,15 @@ class HorizonNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("horizonnet_amd.HorizonNet runs on the MI355X HIP engine only: move the input "
                                "(and the module) to a cuda/ROCm device; there is no CPU fallback")
-        if self.training:
-            raise NotImplementedError("train-mode forward/backward (dropout, batch-stat BN, autograd) is not built yet; "
-                                      "call .eval()")
         B, C_in = int(x.shape[0]), int(x.shape[1])
+        if self.training:
+            if C_in < 3:
+                raise RuntimeError("expected at least 3 input channels")
+            xin = x.detach()
+            if xin.dtype != torch.float32 or not xin.is_contiguous():
+                xin = xin.float().contiguous()
+            with torch.cuda.device(x.device):
+                return _HipTrainStep.apply(self, xin, *self.parameters())
         if C_in < 3:
             raise RuntimeError("expected at least 3 input channels")
         xin = x.detach()

@@ -87,6 +87,30 @@ int hn_set_profiling(hn_engine* e, int on);
 int hn_profile_count(hn_engine* e);
 int hn_profile_entry(hn_engine* e, int i, char* name, int name_cap, float* ms, double* flops);
 
+/* ---- training step: autograd of net(x) at reference train.py:44-58,272-281 (float32) ---------- */
+
+/* Workspace bytes for a training step at batch B (keeps every conv input / pre-BN / post-activation
+ * tensor for the backward pass: about 1.5 GB per panorama). */
+size_t hn_train_workspace_bytes(int B);
+
+/* Train-mode forward: batch-statistics BatchNorm (running_mean / running_var of the bound tensors are
+ * updated IN PLACE with `bn_momentum`, unbiased variance), dropout p_rnn between the LSTM layers and
+ * p_head before the Linear (counter-based masks from `seed`; 0 disables).  Needs hn_pack_weights of the
+ * current parameters.  num_batches_tracked is the caller's to increment. */
+int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                     size_t workspace_bytes, float p_rnn, float p_head, float bn_momentum, uint64_t seed, void* stream);
+
+/* Backward of the last hn_train_forward on `workspace`: dbon [B,2,1024], dcor [B,1,1024] -> gradients of all
+ * 379 parameters written (not accumulated) into the flat buffer `grads` (hn_grad_floats() floats; the
+ * tensor named `key` starts at float offset hn_grad_offset(key), in its reference layout, e.g. OIHW). */
+int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
+                      float* grads, float p_rnn, float p_head, uint64_t seed, void* stream);
+size_t hn_grad_floats(void);
+/* debug taps used by the parity tests (see train.hip) */
+int hn_train_debug_unit(int B, int unit, int64_t* out8);
+int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* dz_dst);
+int64_t hn_grad_offset(const char* name);
+
 /* ---- second boundary: misc/panostretch.py:81-102 (image half of pano_stretch) ------- */
 
 /* Batched Pano-Stretch warp.  src/dst: [B][H][W][C] float32 (HWC per image, exactly the
@@ -149,6 +173,16 @@ int hn_lstm_layer(const float* gx, const float* whh_fwd, const float* whh_rev, f
  * y: [T*B][1024]; bon: [B][2][4T]; cor: [B][1][4T]. */
 int hn_linear_head(const float* y, const float* w, const float* bias, float* bon, float* cor,
                    int T, int B, void* stream);
+
+/* Data gradient of hn_conv2d_nhwc (adjoint w.r.t. x): dz [B][Ho][Wo][Cout] -> dx [B][Hx][Wx][Cin] (+ add).
+ * w_oihw: the ORIGINAL OIHW weights; w_scratch: Cout*Cin*KH*KW + 8192 floats of device scratch. */
+int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
+                         int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
+
+/* Weight gradient of hn_conv2d_nhwc / the stem conv: dw_oihw [Cout][Cin][KH][KW] = sum_m dz[m][n] * patch(x)[m][k].
+ * stem != 0: x is the NHWC4 normalised image and the conv is the 7x7/2 stem.  scratch: Cout*max(KH*KW*Cin, 256) floats. */
+int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
+                         int Cout, int KH, int KW, int sh, int sw, int stem, void* stream);
 
 #ifdef __cplusplus
 }

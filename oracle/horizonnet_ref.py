@@ -20,9 +20,12 @@ def lr_pad(x, p):
     return torch.cat([x[..., -p:], x, x[..., :p]], dim=3)
 
 
+_TRAIN = {"on": False, "momentum": 0.1}     # set by forward_train(): batch statistics + running-stat update
+
+
 def _bn(x, sd, k):
     return F.batch_norm(x, sd[k + ".running_mean"], sd[k + ".running_var"],
-                        sd[k + ".weight"], sd[k + ".bias"], False, 0.0, BN_EPS)
+                        sd[k + ".weight"], sd[k + ".bias"], _TRAIN["on"], _TRAIN["momentum"], BN_EPS)
 
 
 def _conv(x, sd, k, stride, ks):
@@ -47,8 +50,8 @@ def _bottleneck(x, sd, p, stride, down):
 
 def prepare_x(x):
     """reference model.py:248-252."""
-    mean = torch.tensor(X_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
-    std = torch.tensor(X_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    mean = torch.tensor(X_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(X_STD, dtype=x.dtype).view(1, 3, 1, 1)
     return (x[:, :3] - mean) / std
 
 
@@ -128,6 +131,28 @@ def forward(x, sd, taps=None):
             taps.update(c1=feats[0], c2=feats[1], c3=feats[2], c4=feats[3],
                         feature=feature, lstm=out)
         return lin[:, 1:], lin[:, :1]                                        # bon, cor
+
+
+def forward_train(x, sd, momentum=0.1):
+    """Train-mode forward WITH autograd (reference train.py:44-58 calls net(x) with net.train()): batch-statistics
+    BatchNorm (running stats in `sd` are updated in place), dropout disabled (p = 0: the parity tests compare
+    deterministic arithmetic; dropout is checked statistically).  Tensors in `sd` that require grad get .grad from
+    a backward() on the returned (bon, cor)."""
+    if x.shape[2] != 512 or x.shape[3] != 1024:
+        raise NotImplementedError()
+    _TRAIN["on"], _TRAIN["momentum"] = True, momentum
+    try:
+        xn = prepare_x(x)                      # dtype follows x: float32 = the reference, float64 = ground truth for tests
+        feats = backbone(xn, sd)
+        B = x.shape[0]
+        feature = torch.cat([global_height_conv(f, sd, s, 256).reshape(B, -1, 256) for s, f in enumerate(feats)], dim=1)
+        seq = feature.permute(2, 0, 1).contiguous()
+        out = lstm_ref(seq, sd)
+        lin = out @ sd["linear.weight"].t() + sd["linear.bias"]
+        lin = lin.view(256, B, 3, 4).permute(1, 2, 0, 3).contiguous().view(B, 3, 1024)
+        return lin[:, 1:], lin[:, :1]
+    finally:
+        _TRAIN["on"] = False
 
 
 def conv_bn_act_nhwc(x_nhwc, w_oihw, bias, bn, stride, relu, residual=None):

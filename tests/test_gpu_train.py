@@ -1,0 +1,177 @@
+"""GPU parity tests of the training step (-m gpu): data/weight gradient kernels against torch autograd on
+the host, and the whole train-mode forward + backward of HorizonNet against the oracle's autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from horizonnet_amd import HorizonNet, _lib  # noqa: E402
+from oracle import horizonnet_ref  # noqa: E402
+from oracle.weights import make_state_dict  # noqa: E402
+from oracle.hostinfo import usable_cores  # noqa: E402
+
+from hiputil import DEV, P, lib, report, sp  # noqa: E402
+
+torch.set_num_threads(usable_cores())
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _conv_ref(x_nhwc, w, stride):
+    k = w.shape[2]
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if k // 2:
+        x = horizonnet_ref.lr_pad(x, k // 2)
+    return F.conv2d(x, w, None, stride=stride, padding=(k // 2, 0)).permute(0, 2, 3, 1)
+
+
+GRAD_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride
+    ("1x1 s1", 2, 8, 16, 64, 128, 1, 1),
+    ("3x3 s1", 2, 8, 16, 64, 64, 3, 1),
+    ("3x3 s2", 1, 16, 32, 64, 128, 3, 2),
+    ("3x3 s(2,1)", 2, 8, 16, 128, 64, 3, (2, 1)),
+    ("1x1 s2", 1, 16, 32, 128, 256, 1, 2),
+    ("3x3 s(2,1) H=2", 2, 2, 32, 64, 128, 3, (2, 1)),
+    ("3x3 s(2,1) Cout=32 (ghc0.3)", 2, 16, 32, 64, 32, 3, (2, 1)),
+    ("ghc3.3 shape 512->256", 2, 2, 32, 512, 256, 3, (2, 1)),
+    ("ghc2.2 shape 512->256", 2, 8, 64, 512, 256, 3, (2, 1)),
+    ("ghc1.2 shape 256->128", 2, 16, 128, 256, 128, 3, (2, 1)),
+    ("layer4 conv2 512->512 s1", 2, 16, 32, 512, 512, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[c[0] for c in GRAD_CASES])
+def test_conv_dgrad_wgrad_stage(case):
+    name, B, H, W, cin, cout, k, stride = case
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    x = _rand((B, H, W, cin), 1).requires_grad_(True)
+    w = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k)).requires_grad_(True)
+    y = _conv_ref(x, w, (sh, sw))
+    dz = _rand(tuple(y.shape), 3)
+    add = _rand((B, H, W, cin), 4)
+    y.backward(dz)
+    L = lib()
+    dzd, wd, addd = dz.contiguous().to(DEV), w.detach().to(DEV), add.to(DEV)
+    dx = torch.full((B, H, W, cin), float("nan"), device=DEV)
+    scr = torch.empty(cout * cin * k * k + 8192, device=DEV)
+    _lib.check(L.hn_conv2d_dgrad_nhwc(P(dzd), P(wd), P(addd), P(dx), P(scr), B, H, W, cin, cout, k, k, sh, sw, sp()), "dgrad")
+    dw = torch.full((cout, cin, k, k), float("nan"), device=DEV)
+    scr2 = torch.empty(cout * max(k * k * cin, 256), device=DEV)
+    xd = x.detach().to(DEV)
+    _lib.check(L.hn_conv2d_wgrad_nhwc(P(xd), P(dzd), P(dw), P(scr2), B, H, W, cin, cout, k, k, sh, sw, 0, sp()), "wgrad")
+    torch.cuda.synchronize()
+    ok = report("dgrad " + name, dx.cpu().numpy(), (x.grad + add).numpy(), 2e-5 * max(1.0, float(x.grad.abs().max())))
+    ok &= report("wgrad " + name, dw.cpu().numpy(), w.grad.numpy(), 2e-5 * max(1.0, float(w.grad.abs().max())))
+    assert ok
+
+
+def test_stem_wgrad_stage():
+    B, H, W = 2, 32, 64
+    x = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5))
+    xn = horizonnet_ref.prepare_x(x)
+    w = _rand((64, 3, 7, 7), 6, 0.1).requires_grad_(True)
+    y = F.conv2d(horizonnet_ref.lr_pad(xn, 3), w, None, stride=2, padding=(3, 0)).permute(0, 2, 3, 1)
+    dz = _rand(tuple(y.shape), 7)
+    y.backward(dz)
+    x4 = torch.zeros((B, H, W, 4))
+    x4[..., :3] = xn.permute(0, 2, 3, 1)
+    dw = torch.full((64, 3, 7, 7), float("nan"), device=DEV)
+    scr = torch.empty(64 * 256, device=DEV)
+    x4d, dzd = x4.to(DEV), dz.contiguous().to(DEV)          # keep alive: the ABI takes raw pointers
+    _lib.check(lib().hn_conv2d_wgrad_nhwc(P(x4d), P(dzd), P(dw), P(scr), B, H, W, 3, 64, 7, 7, 2, 2, 1, sp()), "wgrad")
+    torch.cuda.synchronize()
+    assert report("wgrad stem 7x7", dw.cpu().numpy(), w.grad.numpy(), 2e-5 * float(w.grad.abs().max()))
+
+
+def _oracle_grads(sd, x, wb, wc, dtype):
+    ref = {k: (v.clone().to(dtype) if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}   # never alias sd
+    for k, v in ref.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    rb, rc_ = horizonnet_ref.forward_train(x.to(dtype), ref, 0.1)
+    ((rb * wb.to(dtype)).sum() + (rc_ * wc.to(dtype)).sum()).backward()
+    return ref, rb.detach(), rc_.detach()
+
+
+def test_train_step_matches_oracle_autograd():
+    """Whole train-mode forward + backward (B=1, dropout off): outputs, all 241 parameter gradients and the
+    updated BatchNorm running statistics.
+
+    Gradients of a ReLU network are discontinuous in the pre-activations, so two float32 implementations
+    legitimately differ wherever a pre-activation sits within rounding noise of zero (a handful of mask flips
+    per layer; they weigh 1/M in a parameter gradient and M is as small as 32 here).  The yardstick is
+    therefore the float64 oracle: the engine must be as close to it as the float32 oracle (= the reference's
+    own arithmetic) is, up to a small factor, and point in the same direction."""
+    B = 1
+    sd = make_state_dict(11, "random")
+    x = torch.rand(B, 3, 512, 1024, generator=torch.Generator().manual_seed(12))
+    wb = _rand((B, 2, 1024), 13)
+    wc = _rand((B, 1, 1024), 14)
+    ref64, rb64, rc64 = _oracle_grads(sd, x, wb, wc, torch.float64)
+    ref32, rb32, rc32 = _oracle_grads(sd, x, wb, wc, torch.float32)
+
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    bon, cor = net(x.to(DEV))
+    ((bon * wb.to(DEV)).sum() + (cor * wc.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    ok = report("train fwd bon vs f32 oracle", bon.detach().cpu().numpy(), rb32.numpy(), 1e-3)
+    ok &= report("train fwd cor vs f32 oracle", cor.detach().cpu().numpy(), rc32.numpy(), 1e-3)
+    rows = []
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        t = ref64[k].grad
+        nt = float(t.norm()) + 1e-30
+        e_eng = float((p.grad.cpu().double() - t).norm()) / nt
+        e_o32 = float((ref32[k].grad.double() - t).norm()) / nt
+        cos = float((p.grad.cpu().double() * t).sum()) / (float(p.grad.cpu().double().norm()) * nt + 1e-30)
+        zero_grad = float(t.abs().max()) < 1e-6            # conv biases in front of a batch-stat BN: true gradient is 0
+        rows.append((e_eng, e_o32, cos, k, zero_grad, float(p.grad.abs().max())))
+    rows.sort(reverse=True)
+    for e_eng, e_o32, cos, k, zg, gm in [r for r in rows if not r[4]][:10]:
+        print("[parity] grad %-60s L2-rel vs f64: engine %.2e, f32 oracle %.2e, cos %.6f" % (k[-60:], e_eng, e_o32, cos))
+    bad = [r for r in rows if not r[4] and not (r[0] <= 10.0 * max(r[1], 1e-5) and r[2] > 0.999)]
+    badz = [r for r in rows if r[4] and not (r[5] < 1e-4)]
+    med_ratio = float(np.median([r[0] / max(r[1], 1e-12) for r in rows if not r[4]]))
+    print("[parity] %d / %d gradients worse than 10x the f32 oracle's own error; median engine/oracle error ratio %.2f; "
+          "%d zero-gradient biases not ~0" % (len(bad), len(rows), med_ratio, len(badz)))
+    ok &= not bad and not badz and med_ratio < 3.0
+    # running statistics (momentum 0.1, unbiased variance) and num_batches_tracked
+    sd_after = net.state_dict()
+    for k in ("feature_extractor.encoder.bn1", "feature_extractor.encoder.layer3.2.bn2",
+              "reduce_height_module.ghc_lst.3.layer.3.layers.1"):
+        ok &= report("running_mean " + k, sd_after[k + ".running_mean"].cpu().numpy(), ref32[k + ".running_mean"].numpy(), 1e-4)
+        ok &= report("running_var " + k, sd_after[k + ".running_var"].cpu().numpy(), ref32[k + ".running_var"].numpy(), 1e-3)
+        assert int(sd_after[k + ".num_batches_tracked"]) == 1
+    assert ok
+
+
+def test_dropout_statistics_and_eval_after_train():
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(0, "random"))
+    net = net.to(DEV).train()
+    x = torch.rand(1, 3, 512, 1024, generator=torch.Generator().manual_seed(3)).to(DEV)
+    torch.manual_seed(1)
+    b1, c1 = net(x)
+    torch.manual_seed(2)
+    b2, c2 = net(x)
+    torch.cuda.synchronize()
+    assert float((b1 - b2).abs().max()) > 1e-4          # different dropout masks
+    assert bool(torch.isfinite(b1).all()) and bool(torch.isfinite(c2).all())
+    net.eval()
+    with torch.no_grad():
+        e1, _ = net(x)
+        e2, _ = net(x)
+    assert torch.equal(e1, e2)                            # eval path re-packs with the updated running stats
