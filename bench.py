@@ -90,6 +90,59 @@ def pano_stretch_leg(dev, n_img=64, iters=10):
             "max_abs_vs_oracle": err}
 
 
+def train_leg(dev, world, B, steps, warmup, dist):
+    """Training step of reference train.py:272-281 on the engine: train-mode forward, L1(bon) + BCE-with-logits(cor)
+    (train.py:53-54), backward (all 241 gradients), data-parallel all-reduce when world > 1, Adam (lr 1e-4).
+    float32; synthetic inputs and labels resident in HBM."""
+    import torch.nn.functional as F
+    from horizonnet_amd import HorizonNet, broadcast_module_
+    from oracle.weights import make_state_dict
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(0, "random"))
+    net = net.to(dev).train()
+    broadcast_module_(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), fused=True)
+    g = torch.Generator().manual_seed(2000 + (dist.get_rank() if dist else 0))
+    x = torch.rand(B, 3, 512, 1024, generator=g).to(dev)
+    y_bon = ((torch.rand(B, 2, 1024, generator=g) - 0.5) * 1.2).to(dev)
+    y_cor = (torch.rand(B, 1, 1024, generator=g) < 0.05).float().to(dev)
+
+    def step():
+        bon, cor = net(x)
+        loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    assert net.hip_status(dev) == 0 and bool(torch.isfinite(loss))
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    flop = 3.0 * FWD_FLOP_PER_PANO * B * world * steps          # fwd + dgrad + wgrad (BASELINE.md section 3)
+    return {"metric": "training panoramas/s (512x1024, fwd+bwd+Adam)", "value": round(B * world * steps / wall, 2),
+            "unit": "panoramas/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train.py step on synthetic data (L1 + BCE losses, Adam), fp32 -- BASELINE configs[2] is bf16 batch 64; this is the fp32 engine",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (RCCL all-reduce of the flat 326 MB gradient buffer)" % world},
+            "roofline": {"bound": "mfma", "achieved": round(flop / wall / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flop / wall / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None},
+            "final_loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +150,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="panoramas per GPU per step (configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward = the headline metric (default); train = one optimisation step per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,6 +166,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+
+    if args.mode == "train":
+        out = train_leg(dev, world, args.batch, args.steps, args.warmup, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from horizonnet_amd import HorizonNet
     from oracle.weights import make_state_dict       # seeded random-init weights (no checkpoint offline)

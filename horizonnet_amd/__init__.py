@@ -15,5 +15,7 @@ host tensors, raises.
 from .model import HorizonNet  # noqa: F401
 from .panostretch import pano_stretch, pano_stretch_batch  # noqa: F401
 from .peaks import find_N_peaks, find_peaks_batch  # noqa: F401
+from .parallel import allreduce_mean_, broadcast_module_  # noqa: F401
 
-__all__ = ["HorizonNet", "pano_stretch", "pano_stretch_batch", "find_N_peaks", "find_peaks_batch"]
+__all__ = ["HorizonNet", "pano_stretch", "pano_stretch_batch", "find_N_peaks", "find_peaks_batch",
+           "allreduce_mean_", "broadcast_module_"]

@@ -180,6 +180,9 @@ class _HipTrainStep(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(st.lib.hn_train_backward(st.handle, _lib.ptr(dbon), _lib.ptr(dcor), B, _lib.ptr(ws), ws.numel(), _lib.ptr(flat),
                                                 ctx.p[0], ctx.p[1], ctx.seed, _lib.stream_ptr(dev)), "hn_train_backward")
+        if net.sync_gradients:                    # data-parallel replicas: one RCCL all-reduce (mean) of the flat buffer
+            from .parallel import allreduce_mean_
+            allreduce_mean_(flat, net.process_group)
         grads = []
         for (name, shape), need in zip(ctx.names, ctx.needs):
             if not need:
@@ -222,6 +225,8 @@ class HorizonNet(nn.Module):
             self.linear.bias[2 * self.step_cols:3 * self.step_cols].fill_(0.425)
         self._hip_states = {}
         self._train_steps = 0
+        self.sync_gradients = True          # all-reduce gradients over torch.distributed when it is initialised (world > 1)
+        self.process_group = None
         self._param_names = [(k, tuple(p.shape)) for k, p in self.named_parameters()]
 
     # ---- engine plumbing --------------------------------------------------------------------

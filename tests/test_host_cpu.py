@@ -130,6 +130,39 @@ def test_shard_for_rank_partitions_units():
         assert max(sizes) - min(sizes) <= 1
 
 
+_GRAD_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from horizonnet_amd.parallel import allreduce_mean_, broadcast_module_
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 1_000_003                                            # not a multiple of the bucket size
+flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+allreduce_mean_(flat, bucket_bytes=1 << 20)              # 4 buckets
+want = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+lin = torch.nn.Linear(4, 3)
+with torch.no_grad():
+    lin.weight.fill_(float(rank)); lin.bias.fill_(float(rank))
+broadcast_module_(lin, src=0)
+ok = torch.allclose(flat, want, rtol=1e-6) and float(lin.weight.abs().max()) == 0.0
+if rank == 0:
+    print("GRADOK" if ok else "GRADBAD")
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_gradient_allreduce(tmp_path):
+    # the data-parallel exchange step of training (a14/e): bucketed all-reduce-mean of the flat gradient buffer
+    script = tmp_path / "gworker.py"
+    script.write_text(_GRAD_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "GRADOK" in out.stdout
+
+
 _GLOO_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
