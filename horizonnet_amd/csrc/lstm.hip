@@ -172,35 +172,40 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
 }
 
 // Adjoint recurrence GEMV for one step: dh[b][dir*512 + k] = sum_n dg[b][dir*2048 + n] * Whh_dir[n][k]
-// (reference: autograd of nn.LSTM, train.py:278).  256 workgroups x (32 b x 8 n-slices); 4 k-columns each.
+// (reference: autograd of nn.LSTM, train.py:278).  Takes Whh TRANSPOSED ([512][2048], k-major) so that the 4
+// k-columns a workgroup owns are 4 contiguous 8 KB rows.  256 workgroups x (32 b x 8 n-slices).
 __global__ __launch_bounds__(256) void lstm_bwd_dh_kernel(const float* __restrict__ dg_f, const float* __restrict__ dg_r,
-                                                          const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                          const float* __restrict__ whhT_f, const float* __restrict__ whhT_r,
                                                           float* __restrict__ dh, int B)
 {
     const int dir = blockIdx.x & 1;
     const int k0 = (blockIdx.x >> 1) * 4;
-    const float* whh = dir ? whh_r : whh_f;
+    const float* wt = (dir ? whhT_r : whhT_f) + (size_t)k0 * 2048;
     const int part = threadIdx.x & 7;
     const int b = blockIdx.y * 32 + (threadIdx.x >> 3);
     const int bb = b < B ? b : B - 1;
     const float* g = (dir ? dg_r : dg_f) + (size_t)bb * 4096 + dir * 2048 + part * 256;   // each direction at its own time index
-    const float* w = whh + (size_t)(part * 256) * 512 + k0;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* w = wt + part * 256;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int n = 0; n < 256; n += 4) {
         const f32x4 gv = *reinterpret_cast<const f32x4*>(g + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc += gv[j] * *reinterpret_cast<const f32x4*>(w + (size_t)(n + j) * 512);
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)k * 2048 + n);
+            acc[k] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+        }
     }
+    f32x4 out;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float v = acc[k];
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
-        acc[k] = v;
+        out[k] = v;
     }
-    if (part == 0 && b < B) *reinterpret_cast<f32x4*>(dh + (size_t)b * 1024 + dir * 512 + k0) = acc;
+    if (part == 0 && b < B) *reinterpret_cast<f32x4*>(dh + (size_t)b * 1024 + dir * 512 + k0) = out;
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C)
@@ -217,9 +222,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 }  // namespace
 
-int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh_f, const float* whh_r, float* dh, int B, hipStream_t s)
+// whhT_f / whhT_r: the recurrent weights transposed to [512][2048]
+int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whhT_f, const float* whhT_r, float* dh, int B, hipStream_t s)
 {
-    hipLaunchKernelGGL(lstm_bwd_dh_kernel, dim3(256, (B + 31) / 32), dim3(256), 0, s, dg_f, dg_r, whh_f, whh_r, dh, B);
+    hipLaunchKernelGGL(lstm_bwd_dh_kernel, dim3(256, (B + 31) / 32), dim3(256), 0, s, dg_f, dg_r, whhT_f, whhT_r, dh, B);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -353,11 +353,14 @@ extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* d
         HN_HIP(hipMemsetAsync(W + pl.dhrec, 0, (size_t)B * 1024 * sizeof(float), s));
         HN_HIP(hipMemsetAsync(W + pl.dcrec, 0, (size_t)B * 1024 * sizeof(float), s));
         const std::string sf = "_l" + std::to_string(l), sr = sf + "_reverse";
+        float* whhT = W + pl.wsB;                     // [2][512][2048]: recurrent weights, k-major, for the adjoint GEMV
+        if ((rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sf), whhT, 2048, 512, s))) return rc;
+        if ((rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sr), whhT + (size_t)512 * 2048, 2048, 512, s))) return rc;
         for (int step = 0; step < T_COLS; ++step) {
             if ((rc = hn_launch_lstm_bwd_gates(W + pl.save[l], dy, W + pl.dhrec, W + pl.dcrec, dgx, T_COLS, B, step, s))) return rc;
             const int tf = T_COLS - 1 - step, tr = step;
-            if ((rc = hn_launch_lstm_bwd_dh(dgx + (size_t)tf * B * 4096, dgx + (size_t)tr * B * 4096, c.bound("bi_rnn.weight_hh" + sf),
-                                            c.bound("bi_rnn.weight_hh" + sr), W + pl.dhrec, B, s)))
+            if ((rc = hn_launch_lstm_bwd_dh(dgx + (size_t)tf * B * 4096, dgx + (size_t)tr * B * 4096, whhT, whhT + (size_t)512 * 2048,
+                                            W + pl.dhrec, B, s)))
                 return rc;
         }
         // dW_hh = sum_t dg_t^T h_{t-1}   (fwd: rows m >= B pair with y rows m - B; rev: rows m < (T-1)B pair with y rows m + B)
