@@ -1,5 +1,5 @@
 // Training step of HorizonNet(resnet50, use_rnn=True) on the HIP engine: train-mode forward
-// (batch-statistics BatchNorm with running-stat update, dropout) and the full adjoint (all 379
+// (batch-statistics BatchNorm with running-stat update, dropout) and the full adjoint (all 241
 // parameter gradients).  Replaces what autograd does for `net(x)` + `loss.backward()` at reference
 // train.py:44-58,272-281; the losses and the optimiser stay in the caller.  float32 throughout.
 //

@@ -101,7 +101,7 @@ int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, 
                      size_t workspace_bytes, float p_rnn, float p_head, float bn_momentum, uint64_t seed, void* stream);
 
 /* Backward of the last hn_train_forward on `workspace`: dbon [B,2,1024], dcor [B,1,1024] -> gradients of all
- * 379 parameters written (not accumulated) into the flat buffer `grads` (hn_grad_floats() floats; the
+ * 241 parameters written (not accumulated) into the flat buffer `grads` (hn_grad_floats() floats; the
  * tensor named `key` starts at float offset hn_grad_offset(key), in its reference layout, e.g. OIHW). */
 int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
                       float* grads, float p_rnn, float p_head, uint64_t seed, void* stream);

@@ -278,9 +278,9 @@ def test_module_contract_errors():
         net(torch.zeros(1, 3, 256, 512, device=DEV))
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 512, 1024))
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 3, 512, 1024, device=DEV))
+    net.train()                                   # train mode is served by the engine's training step (test_gpu_train.py)
+    bon, cor = net(torch.zeros(1, 3, 512, 1024, device=DEV))
+    assert bon.requires_grad and cor.requires_grad and bon.shape == (1, 2, 1024)
 
 
 def test_weights_repack_after_update(golden_dir):
