@@ -246,6 +246,10 @@ def main():
                          "share": round(v[0] / prof_total, 3)} for k, v in fam.items()}
         igemm_ms = sum(v[0] for k, v in fam.items() if "conv_igemm" in k)
         igemm_fl = sum(v[1] for k, v in fam.items() if "conv_igemm" in k)
+        traffic = None                                   # HBM-side bytes per forward from the committed PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r1_v1_pmc_traffic.json")
+        if B == 32 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("total_bytes")
         out = {
             "metric": "panoramas/s (512x1024 fwd)",
             "value": round(value, 2),
@@ -264,7 +268,8 @@ def main():
                        "parallelism": "dp%d (independent replicas, no data-path collective)" % world},
             "roofline": {"bound": "mfma", "kernel": "hn_forward (all launches of one forward; conv_igemm_f32 family = %.0f%% of device time)" % (100.0 * igemm_ms / prof_total),
                          "achieved": round(achieved_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate --pmc passes, profiles/r1_v1_pmc_traffic.json; Infinity-Cache hits included; algorithmic minimum 31.7 GB",
                          "algorithmic_flop_per_launch": FWD_FLOP_PER_PANO * B,
                          "launch_ms_hip_events": round(ms_per_fwd, 3),
                          "conv_igemm_f32": {"ms": round(igemm_ms, 3), "tflops": round(igemm_fl / (igemm_ms * 1e-3) / 1e12, 2),
