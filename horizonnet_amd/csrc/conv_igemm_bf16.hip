@@ -1,0 +1,521 @@
+// Implicit-GEMM convolution for gfx950, bf16 operands on the matrix cores, f32 accumulation.
+//
+// Same algorithm, data flow and boundary semantics as conv_igemm_f32.hip (see the header there):
+//   y[m][n] = act( scale[n] * sum_k A[m][k] * W[n][k] + shift[n] (+ res[m][n]) )
+// with NHWC bf16 activations, packed bf16 weights [Cout][kh][kw][Cin], f32 scale/shift (folded BN), bf16
+// (or f32) output.  It serves the bf16 inference mode that BASELINE configs 3-5 name (the reference trains
+// and infers under autocast, train.py:51,273).  What changes against the f32 kernel:
+//   * BK = 64 elements, so a tile row is again ONE 128-byte line = 8 chunks of 16 bytes; the LDS-DMA
+//     staging, the source-side slot swizzle c ^ ((r >> 1) & 7) and the buffer-load addressing are
+//     byte-for-byte the f32 kernel's;
+//   * v_mfma_f32_32x32x16_bf16: one 16-byte fragment (8 consecutive k) per lane per operand feeds ONE
+//     MFMA (lanes 0-31 carry k = 16s..16s+7, lanes 32-63 k = 16s+8..16s+15);
+//   * the epilogue converts with v_cvt_pk_bf16_f32 (round to nearest even) and stores 16 bytes per lane.
+// The 7x7 stem reads an NHWC8 bf16 image (3 real channels), 8 taps x 8 channels per 128-byte chunk.
+#include "hn_common.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int BKE = 64;                  // K chunk in elements (128 bytes)
+constexpr int ROWB = 128;                // bytes per LDS tile row
+constexpr unsigned OOB = 0x80000000u;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+struct ConvArgsH {
+    const u16* x;
+    const u16* w;
+    const float* scale;
+    const float* shift;
+    const u16* res;
+    void* y;
+    int Hi, Wi, Cin, Ho, Wo, Cout;
+    int KW, sh, sw, ph, pw;
+    int M, K, nk, relu, ldy;
+    int xstride;
+    int xcd_swizzle;
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, unsigned voff, unsigned soff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
+{
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int A_BYTES = BM * ROWB;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid >> 3;
+    const int lslot = tid & 7;
+    const int lcol = lslot ^ ((lrow >> 1) & 7);
+
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int NT = p.Cout / BN;
+    const int nt = bid % NT;
+    const int mt = bid / NT;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int hw_out = p.Ho * p.Wo;
+    const int b_first = m0 / hw_out;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * (STEM ? 8 : p.xstride);
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w + (size_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
+
+    int a_pix0[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int m = m0 + lrow + 32 * q;
+        if (m < p.M) {
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int b = t / p.Ho;
+            a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
+            a_hi0[q] = ho * p.sh - p.ph;
+            a_wi0[q] = wo * p.sw - p.pw;
+        } else {
+            a_pix0[q] = -1;
+            a_hi0[q] = 0;
+            a_wi0[q] = 0;
+        }
+    }
+    unsigned w_off[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) w_off[q] = (unsigned)((lrow + 32 * q) * p.K + lcol * 8) * 2u;
+
+    unsigned a_off[AP];
+    auto tap_offsets = [&](int dh, int dw) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const int hi = a_hi0[q] + dh;
+            int wi = a_wi0[q] + (STEM ? lcol : dw);
+            wi = wi < 0 ? wi + p.Wi : wi;
+            wi = wi >= p.Wi ? wi - p.Wi : wi;
+            const bool ok = (a_pix0[q] >= 0) && ((unsigned)hi < (unsigned)p.Hi);
+            const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
+            const unsigned off = STEM ? pix * 16u : (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u;
+            a_off[q] = ok ? off : OOB;
+        }
+    };
+
+    int dh = 0, dw = 0, c0 = 0;
+    tap_offsets(0, 0);
+
+    auto fetch = [&](int kc) {       // chunk kc -> LDS stage (kc & 1)
+        char* a_s = smem + (kc & 1) * STAGE_BYTES;
+        char* b_s = a_s + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < AP; ++q) dma16(rsrc_a, a_s + (q * 4 + wave) * 1024, a_off[q], (unsigned)c0 * 2u);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) dma16(rsrc_w, b_s + (q * 4 + wave) * 1024, w_off[q], (unsigned)kc * (unsigned)ROWB);
+        if (STEM) {
+            dh += 1;
+            tap_offsets(dh, 0);
+        } else {
+            c0 += BKE;
+            if (c0 == p.Cin) {
+                c0 = 0;
+                if (++dw == p.KW) { dw = 0; ++dh; }
+                tap_offsets(dh, dw);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31;
+    const int half = lane >> 5;
+    const int fswz = (fr >> 1) & 7;
+
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    {
+        u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto ldfrag = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN], int buf, int ks) {
+            const int koff = ((2 * ks + half) ^ fswz) * 16;
+            const char* a_s = smem + buf * STAGE_BYTES + (wm * WM + fr) * ROWB + koff;
+            const char* b_s = smem + buf * STAGE_BYTES + A_BYTES + (wn * WN + fr) * ROWB + koff;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a_s + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b_s + j * 32 * ROWB);
+        };
+        auto mma = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        };
+        ldfrag(fa0, fb0, 0, 0);
+        for (int kc = 0; kc < p.nk; ++kc) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < p.nk;
+            if (more) fetch(kc + 1);
+            ldfrag(fa1, fb1, buf, 1);
+            mma(fa0, fb0);
+            ldfrag(fa0, fb0, buf, 2);
+            mma(fa1, fb1);
+            ldfrag(fa1, fb1, buf, 3);
+            mma(fa0, fb0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc+1 has landed
+            __syncthreads();
+            if (more) ldfrag(fa0, fb0, buf ^ 1, 0);
+            mma(fa1, fb1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: f32 accumulators -> LDS -> 8 channels per lane: scale/shift, residual, ReLU, bf16 (or f32) rows ----
+    constexpr int CS = BN + 4;
+    constexpr int EROWS = WM;
+    static_assert(EROWS * CS * 4 <= 2 * STAGE_BYTES, "C tile must fit in the staging LDS");
+    constexpr int TPR = BN / 8;
+    constexpr int RPP = 256 / TPR;
+    constexpr int NPS = EROWS >= RPP ? EROWS / RPP : 1;     // BN = 32: one sweep, only the first EROWS row-lanes work
+    float* cs = reinterpret_cast<float*>(smem);
+    const int ccol = (tid % TPR) * 8;
+    const int crow = tid / TPR;
+    auto epilogue = [&](auto has_res) {
+        constexpr bool HAS_RES = decltype(has_res)::value;
+        u32x4 rres[HAS_RES ? WAVES_M * NPS : 1];
+        if (HAS_RES) {
+#pragma unroll
+            for (int ps = 0; ps < WAVES_M * NPS; ++ps) {
+                const int m = m0 + (ps / NPS) * EROWS + crow + (ps % NPS) * RPP;
+                const int mc = m < p.M ? m : p.M - 1;
+                rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
+            }
+        }
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
+        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol + 4);
+        const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
+        const f32x4 sf1 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol + 4);
+#pragma unroll
+        for (int h = 0; h < WAVES_M; ++h) {
+            if (h > 0) __syncthreads();
+            if (wm == h) {
+                float* c_w = cs + (4 * half) * CS + wn * WN + fr;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            c_w[(i * 32 + (r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int row = crow + ps * RPP;
+                if (row >= EROWS) continue;
+                const int m = m0 + h * EROWS + row;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + row * CS + ccol);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + row * CS + ccol + 4);
+                v0 = v0 * sc0 + sf0;
+                v1 = v1 * sc1 + sf1;
+                if (HAS_RES) {
+                    const u32x4 rr = rres[h * NPS + ps];
+                    v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
+                    v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+                }
+                if (m < p.M) {
+                    if (OUT_F32) {
+                        float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n0 + ccol;
+                        *reinterpret_cast<f32x4*>(yo) = v0;
+                        *reinterpret_cast<f32x4*>(yo + 4) = v1;
+                    } else {
+                        u32x4 o;
+                        o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+                        o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + n0 + ccol) = o;
+                    }
+                }
+            }
+        }
+    };
+    if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32>
+int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
+{
+    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STEM, OUT_F32>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int MT = hn_cdiv(a.M, BM);
+    const int NT = a.Cout / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(256), lds, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool OUT_F32>
+int dispatch(const ConvArgsH& a, const ConvDesc& d, hipStream_t s)
+{
+    const long M = a.M;
+    if (d.Cout % 128 == 0) {
+        const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 128);
+        if (blocks128 >= 512) return launch_cfg_h<128, 128, 2, 2, false, OUT_F32>(a, s);
+        return launch_cfg_h<64, 128, 2, 2, false, OUT_F32>(a, s);
+    }
+    if (d.Cout % 64 == 0) {
+        const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 64);
+        if (blocks128 >= 512) return launch_cfg_h<128, 64, 2, 2, false, OUT_F32>(a, s);
+        return launch_cfg_h<64, 64, 2, 2, false, OUT_F32>(a, s);
+    }
+    return launch_cfg_h<128, 32, 4, 1, false, OUT_F32>(a, s);
+}
+
+// ---- bf16 helper kernels -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, u16* __restrict__ out, long n8)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(in + i * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 8 + 4);
+        u32x4 o;
+        o[0] = pack_bf16(a[0], a[1]); o[1] = pack_bf16(a[2], a[3]); o[2] = pack_bf16(b[0], b[1]); o[3] = pack_bf16(b[2], b[3]);
+        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+    }
+}
+
+// (x[:, :3] - mean) / std, NCHW f32 -> NHWC8 bf16 (channels 3..7 = 0)   (reference model.py:248-252)
+__global__ __launch_bounds__(256) void prep_nhwc8_bf16_kernel(const float* __restrict__ x, u16* __restrict__ out, long npix, long total,
+                                                              int C_in)
+{
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / npix;
+        const long pix = i - b * npix;
+        const float* src = x + b * C_in * npix + pix;
+        const float v0 = (src[0] - mean[0]) / stdv[0];
+        const float v1 = (src[npix] - mean[1]) / stdv[1];
+        const float v2 = (src[2 * npix] - mean[2]) / stdv[2];
+        u32x4 o = {pack_bf16(v0, v1), pack_bf16(v2, 0.f), 0u, 0u};
+        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+    }
+}
+
+// 3x3 / 2 / pad 1 max-pool, NHWC bf16, 8 channels per thread (ordinary -inf padding)
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const u16* __restrict__ in, u16* __restrict__ out, int Hi, int Wi, int Ho, int Wo,
+                                                           int C8, long total)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long b = t / Ho;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = ho * 2 - 1 + dh;
+            if ((unsigned)hi >= (unsigned)Hi) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wi = wo * 2 - 1 + dw;
+                if ((unsigned)wi >= (unsigned)Wi) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(in + (((b * Hi + hi) * Wi + wi) * (long)C8 + c8) * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    m[2 * k] = fmaxf(m[2 * k], bf16_lo(v[k]));
+                    m[2 * k + 1] = fmaxf(m[2 * k + 1], bf16_hi(v[k]));
+                }
+            }
+        }
+        u32x4 o = {pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3]), pack_bf16(m[4], m[5]), pack_bf16(m[6], m[7])};
+        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+    }
+}
+
+// circular linear up-sample along W + (c, h) flatten, bf16 in -> bf16 sequence matrix (see elementwise.hip)
+__global__ __launch_bounds__(256) void upsample_flatten_bf16_kernel(const u16* __restrict__ in, u16* __restrict__ seq, int B, int hq, int Wq,
+                                                                    int cq, int col0, int f)
+{
+    const int t = blockIdx.x;
+    const int b = blockIdx.y;
+    const float src = (1.0f / (float)f) * ((float)(t + f) + 0.5f) - 0.5f;
+    const int i0p = (int)src;
+    const float w1 = src - (float)i0p;
+    const float w0 = 1.0f - w1;
+    int i0 = i0p - 1;
+    i0 = i0 < 0 ? i0 + Wq : i0;
+    int i1 = i0p;
+    i1 = i1 >= Wq ? i1 - Wq : i1;
+    u16* dst = seq + ((long)t * B + b) * 1024 + col0;
+    const int n = cq * hq;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int c = e % cq;
+        const int h = e / cq;
+        const long base = ((long)b * hq + h) * Wq;
+        const float a = __builtin_bit_cast(float, (unsigned)in[(base + i0) * cq + c] << 16);
+        const float bb = __builtin_bit_cast(float, (unsigned)in[(base + i1) * cq + c] << 16);
+        dst[c * hq + h] = (u16)(pack_bf16(w0 * a + w1 * bb, 0.f) & 0xffffu);
+    }
+}
+
+// OIHW f32 -> packed bf16 [Cout][kh][KWp][Cp] (zero padded taps / channels for the stem)
+__global__ __launch_bounds__(256) void pack_conv_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout, int Cin, int KH,
+                                                             int KW, int KWp, int Cp)
+{
+    const long total = (long)Cout * KH * KWp * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        long t = i / Cp;
+        const int dw = (int)(t % KWp);
+        t /= KWp;
+        const int dh = (int)(t % KH);
+        const int o = (int)(t / KH);
+        float v = 0.f;
+        if (c < Cin && dw < KW) v = w[(((long)o * Cin + c) * KH + dh) * KW + dw];
+        out[i] = (u16)(pack_bf16(v, 0.f) & 0xffffu);
+    }
+}
+
+inline unsigned grid_for(long total, long cap = 256L * 16)
+{
+    long g = (total + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// d.x / d.w / d.res / d.y are reinterpreted as bf16 buffers (d.y as f32 when out_f32)
+int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
+{
+    static const char* env = getenv("HN_XCD_SWIZZLE");
+    ConvArgsH a;
+    a.xcd_swizzle = env ? atoi(env) : 1;
+    a.x = reinterpret_cast<const u16*>(d.x); a.w = reinterpret_cast<const u16*>(d.w); a.scale = d.scale; a.shift = d.shift;
+    a.res = reinterpret_cast<const u16*>(d.res); a.y = d.y;
+    a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
+    a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
+    a.xstride = d.xstride ? d.xstride : d.Cin;
+    a.M = d.B * d.Ho * d.Wo;
+    a.relu = d.relu;
+    a.ldy = d.ldy ? d.ldy : d.Cout;
+    {
+        const double span = 128.0 / ((double)d.Ho * d.Wo) + 2.0;
+        HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 8 : a.xstride) * 2.0 < 2147483648.0, "conv bf16: image too large for 32-bit tile offsets");
+    }
+    if (d.stem) {
+        HN_REQUIRE(d.KH == 7 && d.KW == 7 && d.Cout == 64, "stem conv bf16: expects 7x7, Cout=64");
+        HN_REQUIRE(!out_f32 && d.Ho * d.Wo >= 128, "stem conv bf16: bf16 output, image >= one tile");
+        a.K = 7 * BKE;
+        a.nk = 7;
+        return launch_cfg_h<128, 64, 2, 2, true, false>(a, s);
+    }
+    HN_REQUIRE(d.Cin % BKE == 0, "conv bf16: Cin=%d must be a multiple of %d", d.Cin, BKE);
+    HN_REQUIRE(d.Cout % 32 == 0, "conv bf16: Cout=%d must be a multiple of 32", d.Cout);
+    a.K = d.KH * d.KW * d.Cin;
+    a.nk = a.K / BKE;
+    HN_REQUIRE(128.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
+    return out_f32 ? dispatch<true>(a, d, s) : dispatch<false>(a, d, s);
+}
+
+int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s)
+{
+    const bool stem = KH == 7;
+    const int KWp = stem ? 8 : KW, Cp = stem ? 8 : Cin;
+    const long total = (long)Cout * KH * KWp * Cp;
+    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, reinterpret_cast<u16*>(out), Cout, Cin, KH, KW, KWp, Cp);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s)
+{
+    HN_REQUIRE(n % 8 == 0, "f32_to_bf16: n %% 8");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, in, reinterpret_cast<u16*>(out), n / 8);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_prep_nhwc8_bf16(const float* x, void* out, int B, int C_in, int H, int W, hipStream_t s)
+{
+    const long npix = (long)H * W, total = npix * B;
+    hipLaunchKernelGGL(prep_nhwc8_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, reinterpret_cast<u16*>(out), npix, total, C_in);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_maxpool_bf16(const void* in, void* out, int B, int Hi, int Wi, int C, hipStream_t s)
+{
+    HN_REQUIRE(C % 8 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "maxpool bf16: C%%8, even H/W required");
+    const int Ho = Hi / 2, Wo = Wi / 2, C8 = C / 8;
+    const long total = (long)B * Ho * Wo * C8;
+    hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const u16*>(in),
+                       reinterpret_cast<u16*>(out), Hi, Wi, Ho, Wo, C8, total);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_upsample_flatten_bf16(const void* in, void* seq, int B, int hq, int Wq, int cq, int col0, hipStream_t s)
+{
+    HN_REQUIRE(Wq > 0 && 256 % Wq == 0 && col0 + cq * hq <= 1024, "upsample bf16: bad geometry");
+    hipLaunchKernelGGL(upsample_flatten_bf16_kernel, dim3(256, B), dim3(256), 0, s, reinterpret_cast<const u16*>(in),
+                       reinterpret_cast<u16*>(seq), B, hq, Wq, cq, col0, 256 / Wq);
+    HN_LAUNCH_CHECK();
+    return 0;
+}

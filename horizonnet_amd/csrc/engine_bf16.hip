@@ -1,0 +1,236 @@
+// bf16 inference mode of the engine: same forward plan as hn_forward (engine.hip) with NHWC bf16 activations and
+// bf16 MFMA convolutions (conv_igemm_bf16.hip); BatchNorm stays folded in f32 scale/shift, the bi-LSTM recurrence,
+// its gate pre-activations and the Linear head stay f32.  Serves the bf16 configurations of BASELINE.json (the
+// reference runs net(x) under autocast, train.py:51,273); parity bar there is 3D-IoU / peak agreement, not 1e-3.
+#include "engine_internal.h"
+
+#include <string.h>
+
+namespace {
+
+typedef unsigned short u16;
+
+struct HOff {
+    std::vector<size_t> conv;      // element offsets of the packed bf16 conv weights, arch().convs order
+    size_t wih[2];
+    size_t total;                  // elements
+};
+
+const HOff& hoff()
+{
+    static HOff H = [] {
+        HOff h;
+        size_t off = 0;
+        auto take = [&](size_t n) { size_t o = off; off += (n + 127) / 128 * 128; return o; };
+        for (const auto& c : arch().convs) h.conv.push_back(take(c.k == 7 ? (size_t)c.cout * 7 * 8 * 8 : (size_t)c.cout * c.k * c.k * c.cin));
+        for (int l = 0; l < 2; ++l) h.wih[l] = take((size_t)4096 * 1024);
+        h.total = off;
+        return h;
+    }();
+    return H;
+}
+
+struct PlanH {                     // byte offsets
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y1h, y2, total;
+};
+
+PlanH make_plan_h(int B)
+{
+    PlanH p;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t b = (size_t)B;
+    p.sync = take(HN_SYNC_WORDS * 4);
+    p.xn = take(b * IMG_H * IMG_W * 8 * 2);
+    p.stem = take(b * 256 * 512 * 64 * 2);
+    p.pool = take(b * 128 * 256 * 64 * 2);
+    p.p0 = take(b * 128 * 256 * 256 * 2);
+    p.p1 = take(b * 128 * 256 * 256 * 2);
+    p.t1 = take(b * 128 * 256 * 128 * 2);
+    p.t2 = take(b * 128 * 256 * 64 * 2);
+    p.ds = take(b * 128 * 256 * 256 * 2);
+    p.g0 = take(b * 64 * 256 * 128 * 2);
+    p.g1 = take(b * 64 * 256 * 128 * 2);
+    p.seq = take((size_t)T_COLS * b * 1024 * 2);
+    p.gx = take((size_t)T_COLS * b * 4096 * 4);
+    p.y1 = take((size_t)T_COLS * b * 1024 * 4);
+    p.y1h = take((size_t)T_COLS * b * 1024 * 2);
+    p.y2 = take((size_t)T_COLS * b * 1024 * 4);
+    p.total = off;
+    return p;
+}
+
+int run_conv_h(hn_engine* e, const ConvLayer& c, size_t woff, const void* x, void* y, const void* res, int B, int Hi, int Wi, int sh,
+               int sw, int relu, hipStream_t s)
+{
+    const float* P = e->packed;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = reinterpret_cast<const float*>(x);
+    d.w = reinterpret_cast<const float*>(reinterpret_cast<const u16*>(e->packed_h) + woff);
+    d.scale = P + c.scale_off; d.shift = P + c.shift_off; d.res = reinterpret_cast<const float*>(res); d.y = reinterpret_cast<float*>(y);
+    d.B = B; d.Hi = Hi; d.Wi = Wi; d.Cin = c.cin; d.Cout = c.cout; d.KH = c.k; d.KW = c.k; d.sh = sh; d.sw = sw;
+    d.ph = c.k / 2; d.pw = c.k / 2;
+    d.Ho = (Hi + 2 * d.ph - c.k) / sh + 1;
+    d.Wo = (Wi + 2 * d.pw - c.k) / sw + 1;
+    d.relu = relu; d.ldy = c.cout;
+    ProfScope ps(e, s, c.wkey, 2.0 * B * d.Ho * d.Wo * (double)c.cout * c.cin * c.k * c.k);
+    return hn_launch_conv_bf16(d, 0, s);
+}
+
+}  // namespace
+
+extern "C" size_t hn_packed_bf16_bytes(void) { return hoff().total * sizeof(u16); }
+
+extern "C" size_t hn_workspace_bf16_bytes(int B)
+{
+    if (B < 1) return 0;
+    return make_plan_h(B).total;
+}
+
+extern "C" int hn_pack_weights_bf16(hn_engine* e, void* packed_h, size_t bytes, void* stream)
+{
+    HN_REQUIRE(e && packed_h, "hn_pack_weights_bf16: null argument");
+    HN_REQUIRE(e->packed != nullptr, "hn_pack_weights_bf16: call hn_pack_weights first (f32 scale/shift, LSTM and head weights come from it)");
+    HN_REQUIRE(bytes >= hn_packed_bf16_bytes(), "hn_pack_weights_bf16: buffer too small (%zu < %zu)", bytes, hn_packed_bf16_bytes());
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_pack_weights_bf16: cannot select device %d", e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const Arch& a = arch();
+    const HOff& h = hoff();
+    u16* H = reinterpret_cast<u16*>(packed_h);
+    int rc;
+    for (size_t i = 0; i < a.convs.size(); ++i) {
+        const ConvLayer& c = a.convs[i];
+        auto it = e->bound.find(c.wkey + ".weight");
+        HN_REQUIRE(it != e->bound.end(), "hn_pack_weights_bf16: '%s.weight' was never bound", c.wkey.c_str());
+        if ((rc = hn_launch_pack_conv_bf16(reinterpret_cast<const float*>(it->second), H + h.conv[i], c.cout, c.cin, c.k, c.k, s))) return rc;
+    }
+    for (int l = 0; l < 2; ++l)
+        if ((rc = hn_launch_f32_to_bf16(e->packed + a.wih_off[l], H + h.wih[l], (long)4096 * 1024, s))) return rc;
+    e->packed_h = packed_h;
+    return 0;
+}
+
+extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                               size_t workspace_bytes, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward_bf16: null argument");
+    HN_REQUIRE(e->packed != nullptr && e->packed_h != nullptr, "hn_forward_bf16: hn_pack_weights / hn_pack_weights_bf16 have not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward_bf16: bad B=%d / C_in=%d", B, C_in);
+    const PlanH pl = make_plan_h(B);
+    HN_REQUIRE(workspace_bytes >= pl.total, "hn_forward_bf16: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward_bf16: cannot select device %d", e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const Arch& a = arch();
+    const HOff& h = hoff();
+    const float* P = e->packed;
+    const u16* H = reinterpret_cast<const u16*>(e->packed_h);
+    char* W = reinterpret_cast<char*>(workspace);
+    int rc;
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
+    e->prof.clear();
+    e->events_used = 0;
+
+    {   // stem: normalise -> NHWC8 bf16, 7x7/2 conv + BN + ReLU, max-pool
+        const ConvLayer& c = a.convs[a.stem];
+        ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
+        if ((rc = hn_launch_prep_nhwc8_bf16(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
+        ConvDesc d;
+        memset(&d, 0, sizeof(d));
+        d.x = reinterpret_cast<const float*>(W + pl.xn); d.w = reinterpret_cast<const float*>(H + h.conv[a.stem]);
+        d.scale = P + c.scale_off; d.shift = P + c.shift_off; d.y = reinterpret_cast<float*>(W + pl.stem);
+        d.B = B; d.Hi = IMG_H; d.Wi = IMG_W; d.Cin = 8; d.Cout = 64; d.KH = 7; d.KW = 7; d.sh = 2; d.sw = 2; d.ph = 3; d.pw = 3;
+        d.Ho = 256; d.Wo = 512; d.relu = 1; d.ldy = 64; d.stem = 1;
+        if ((rc = hn_launch_conv_bf16(d, 0, s))) return rc;
+        if ((rc = hn_launch_maxpool_bf16(W + pl.stem, W + pl.pool, B, 256, 512, 64, s))) return rc;
+    }
+
+    const char* cur = W + pl.pool;
+    int Hh = 128, Wd = 256;
+    const int nblk[4] = {3, 4, 6, 3};
+    for (int li = 0; li < 4; ++li) {
+        for (int j = 0; j < nblk[li]; ++j) {
+            const int stride = (j == 0 && li > 0) ? 2 : 1;
+            const int i1 = a.block_first[li][j];
+            char* out = (cur == W + pl.p0) ? W + pl.p1 : W + pl.p0;
+            if ((rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
+            if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
+            const char* idt = cur;
+            if (j == 0) {
+                const int id = a.block_down[li];
+                if ((rc = run_conv_h(e, a.convs[id], h.conv[id], cur, W + pl.ds, nullptr, B, Hh, Wd, stride, stride, 0, s))) return rc;
+                idt = W + pl.ds;
+            }
+            Hh /= stride;
+            Wd /= stride;
+            if ((rc = run_conv_h(e, a.convs[i1 + 2], h.conv[i1 + 2], W + pl.t2, out, idt, B, Hh, Wd, 1, 1, 1, s))) return rc;
+            cur = out;
+        }
+        const char* gin = cur;
+        int gh = Hh;
+        char* gbuf[2] = {W + pl.g0, W + pl.g1};
+        for (int k = 0; k < 4; ++k) {
+            const int ig = a.ghc_first[li] + k;
+            char* gout = gbuf[k & 1];
+            if ((rc = run_conv_h(e, a.convs[ig], h.conv[ig], gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s))) return rc;
+            gin = gout;
+            gh /= 2;
+        }
+        {
+            ProfScope ps(e, s, "upsample_flatten." + std::to_string(li), 0.0);
+            if ((rc = hn_launch_upsample_flatten_bf16(gin, W + pl.seq, B, gh, Wd, a.convs[a.ghc_first[li] + 3].cout, 256 * li, s))) return rc;
+        }
+    }
+
+    // bi-LSTM x2: bf16 input GEMMs with f32 gate pre-activations, f32 recurrence; f32 Linear head
+    const long rows = (long)T_COLS * B;
+    const void* lin = W + pl.seq;
+    float* ybuf[2] = {reinterpret_cast<float*>(W + pl.y1), reinterpret_cast<float*>(W + pl.y2)};
+    for (int l = 0; l < 2; ++l) {
+        {
+            ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".input_gemm", 2.0 * rows * 1024.0 * 4096);
+            ConvDesc d;
+            memset(&d, 0, sizeof(d));
+            d.x = reinterpret_cast<const float*>(lin); d.w = reinterpret_cast<const float*>(H + h.wih[l]);
+            d.scale = P + a.ones_off; d.shift = P + a.lbias_off[l]; d.y = reinterpret_cast<float*>(W + pl.gx);
+            d.B = 1; d.Hi = 1; d.Wi = (int)rows; d.Cin = 1024; d.Cout = 4096; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1;
+            d.Ho = 1; d.Wo = (int)rows; d.relu = 0; d.ldy = 4096;
+            if ((rc = hn_launch_conv_bf16(d, 1, s))) return rc;
+        }
+        {
+            ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".recurrence", 2.0 * rows * 512.0 * 2048 * 2);
+            if ((rc = hn_launch_lstm_layer(reinterpret_cast<float*>(W + pl.gx), P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l], T_COLS, B,
+                                           W + pl.sync, s)))
+                return rc;
+        }
+        if (l == 0) {
+            if ((rc = hn_launch_f32_to_bf16(ybuf[0], W + pl.y1h, rows * 1024, s))) return rc;
+            lin = W + pl.y1h;
+        }
+    }
+    ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
+    return hn_launch_linear_head(ybuf[1], P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
+}
+
+// per-stage entry point for the parity tests: x / w / res / y are bf16 device buffers (y f32 when out_f32)
+extern "C" int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
+                                   const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
+                                   int relu, int out_f32, void* stream)
+{
+    HN_REQUIRE(x && w_oihw && w_scratch && scale && shift && y, "hn_conv2d_nhwc_bf16: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = hn_launch_pack_conv_bf16(w_oihw, w_scratch, Cout, Cin, KH, KW, s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = reinterpret_cast<const float*>(x); d.w = reinterpret_cast<const float*>(w_scratch); d.scale = scale; d.shift = shift;
+    d.res = reinterpret_cast<const float*>(res); d.y = reinterpret_cast<float*>(y);
+    d.B = B; d.Hi = Hi; d.Wi = Wi; d.Cin = Cin; d.Cout = Cout; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw; d.ph = KH / 2; d.pw = KW / 2;
+    d.Ho = (Hi + 2 * d.ph - KH) / sh + 1;
+    d.Wo = (Wi + 2 * d.pw - KW) / sw + 1;
+    d.relu = relu; d.ldy = Cout;
+    return hn_launch_conv_bf16(d, out_f32, s);
+}

@@ -57,6 +57,7 @@ struct hn_engine {
     int device = 0;
     std::unordered_map<std::string, const void*> bound;
     const float* packed = nullptr;       // last packed buffer (caller owned)
+    const void* packed_h = nullptr;      // last bf16 weight buffer (hn_pack_weights_bf16, caller owned)
     bool profiling = false;
     int debug_unit = -1;                 // training debug tap (hn_train_debug_set): unit whose dy / dz are copied out
     float* debug_dy = nullptr;

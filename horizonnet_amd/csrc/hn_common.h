@@ -89,4 +89,11 @@ int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int 
                          int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s);
 int hn_launch_unpack_conv(const float* wp, float* w_oihw, int Cout, int Cin, int KH, int KW, int packed_rows, hipStream_t s);
 int hn_launch_pack_conv_dgrad(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
+// bf16 family (conv_igemm_bf16.hip): buffers are bf16 unless noted
+int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s);
+int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
+int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);
+int hn_launch_prep_nhwc8_bf16(const float* x, void* out, int B, int C_in, int H, int W, hipStream_t s);
+int hn_launch_maxpool_bf16(const void* in, void* out, int B, int Hi, int Wi, int C, hipStream_t s);
+int hn_launch_upsample_flatten_bf16(const void* in, void* seq, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
 int hn_launch_add_vec(const float* a, const float* b, float* out, long n, hipStream_t s);

@@ -117,6 +117,8 @@ class _DeviceState:
         _lib.check(self.lib.hn_create(ctypes.byref(h), device.index), "hn_create")
         self.handle = h
         self.packed = torch.empty(self.lib.hn_packed_bytes(), dtype=torch.uint8, device=device)
+        self.packed_h = None               # bf16 conv / input-GEMM weights, allocated on first bf16 forward
+        self.signature_h = None
         self.signature = None
         self.keepalive = None
         self.workspaces = {}
@@ -127,6 +129,14 @@ class _DeviceState:
             self.workspaces.clear()              # one batch size resident at a time
             ws = torch.empty(self.lib.hn_workspace_bytes(B), dtype=torch.uint8, device=self.device)
             self.workspaces[B] = ws
+        return ws
+
+    def workspace_bf16(self, B):
+        ws = self.workspaces.get(("bf16", B))
+        if ws is None:
+            self.workspaces.clear()
+            ws = torch.empty(self.lib.hn_workspace_bf16_bytes(B), dtype=torch.uint8, device=self.device)
+            self.workspaces[("bf16", B)] = ws
         return ws
 
     def train_workspace(self, B):
@@ -225,6 +235,7 @@ class HorizonNet(nn.Module):
             self.linear.bias[2 * self.step_cols:3 * self.step_cols].fill_(0.425)
         self._hip_states = {}
         self._train_steps = 0
+        self.precision = "f32"              # "f32" (exact, the parity path) or "bf16" (eval-mode inference only)
         self.sync_gradients = True          # all-reduce gradients over torch.distributed when it is initialised (world > 1)
         self.process_group = None
         self._param_names = [(k, tuple(p.shape)) for k, p in self.named_parameters()]
@@ -287,6 +298,19 @@ class HorizonNet(nn.Module):
             st = self._hip_state(x.device)
             bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
             cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
+            if self.precision == "bf16":
+                if st.packed_h is None:
+                    st.packed_h = torch.empty(st.lib.hn_packed_bf16_bytes(), dtype=torch.uint8, device=x.device)
+                if st.signature_h != st.signature:
+                    _lib.check(st.lib.hn_pack_weights_bf16(st.handle, _lib.ptr(st.packed_h), st.packed_h.numel(),
+                                                           _lib.stream_ptr(x.device)), "hn_pack_weights_bf16")
+                    st.signature_h = st.signature
+                ws = st.workspace_bf16(B)
+                _lib.check(st.lib.hn_forward_bf16(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
+                                                  ws.numel(), _lib.stream_ptr(x.device)), "hn_forward_bf16")
+                return bon, cor
+            if self.precision != "f32":
+                raise ValueError("precision must be 'f32' or 'bf16'")
             ws = st.workspace(B)
             _lib.check(st.lib.hn_forward(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
                                          ws.numel(), _lib.stream_ptr(x.device)), "hn_forward")

@@ -87,6 +87,19 @@ int hn_set_profiling(hn_engine* e, int on);
 int hn_profile_count(hn_engine* e);
 int hn_profile_entry(hn_engine* e, int i, char* name, int name_cap, float* ms, double* flops);
 
+/* ---- bf16 inference mode (BASELINE configs 3-5; the reference runs net(x) under autocast, train.py:51,273) ----
+ * NHWC bf16 activations, bf16 MFMA convolutions with f32 accumulation and f32 folded-BN epilogues; the LSTM
+ * recurrence, its gate pre-activations and the Linear head stay f32.  Needs hn_pack_weights first. */
+size_t hn_packed_bf16_bytes(void);
+int hn_pack_weights_bf16(hn_engine* e, void* packed_bf16, size_t bytes, void* stream);
+size_t hn_workspace_bf16_bytes(int B);
+int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* per-stage (tests): x / res / y bf16 NHWC (y f32 when out_f32), w_oihw f32, w_scratch Cout*KH*KW*Cin bf16 */
+int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
+                        const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
+                        int relu, int out_f32, void* stream);
+
 /* ---- training step: autograd of net(x) at reference train.py:44-58,272-281 (float32) ---------- */
 
 /* Workspace bytes for a training step at batch B (keeps every conv input / pre-BN / post-activation

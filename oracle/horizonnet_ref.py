@@ -155,6 +155,88 @@ def forward_train(x, sd, momentum=0.1):
         _TRAIN["on"] = False
 
 
+def _r16(t):
+    """Round to bfloat16 (nearest even) and back: the storage precision of the engine's bf16 mode."""
+    return t.bfloat16().float()
+
+
+def forward_bf16_emulated(x, sd):
+    """What the engine's bf16 mode computes, restated on the CPU: every tensor the engine stores as bf16 (normalised
+    input, conv weights, conv outputs after the folded-BN / residual / ReLU epilogue, the sequence matrix, the LSTM
+    layer-0 output fed to layer 1) is rounded to bf16; products are exact and accumulation is f32; BatchNorm is the
+    f32 per-channel scale/shift fold; the LSTM recurrence, its gate pre-activations and the head are f32.
+    This is NOT the reference's arithmetic (that is forward()); it exists to check the bf16 kernels tightly."""
+    def fold(k_conv, k_bn):
+        s_ = sd[k_bn + ".weight"] / torch.sqrt(sd[k_bn + ".running_var"] + BN_EPS)
+        b_ = sd.get(k_conv + ".bias")
+        b_ = torch.zeros_like(s_) if b_ is None else b_
+        return s_, (b_ - sd[k_bn + ".running_mean"]) * s_ + sd[k_bn + ".bias"]
+
+    def unit(t, k_conv, k_bn, stride, ks, relu, res=None):
+        p_ = ks // 2
+        if p_:
+            t = lr_pad(t, p_)
+        y = F.conv2d(t, _r16(sd[k_conv + ".weight"]), None, stride=stride, padding=(p_, 0))
+        s_, t_ = fold(k_conv, k_bn)
+        y = y * s_.view(1, -1, 1, 1) + t_.view(1, -1, 1, 1)
+        if res is not None:
+            y = y + res
+        if relu:
+            y = F.relu(y)
+        return _r16(y)
+
+    with torch.no_grad():
+        enc = "feature_extractor.encoder."
+        y = _r16(prepare_x(x.float()))
+        y = unit(y, enc + "conv1.1", enc + "bn1", 2, 7, True)
+        y = F.max_pool2d(y, 3, 2, 1)
+        feats = []
+        for li, n in enumerate((3, 4, 6, 3)):
+            for j in range(n):
+                p = "%slayer%d.%d." % (enc, li + 1, j)
+                st = 2 if (j == 0 and li > 0) else 1
+                t1 = unit(y, p + "conv1", p + "bn1", 1, 1, True)
+                t2 = unit(t1, p + "conv2.1", p + "bn2", st, 3, True)
+                idt = unit(y, p + "downsample.0", p + "downsample.1", st, 1, False) if j == 0 else y
+                y = unit(t2, p + "conv3", p + "bn3", 1, 1, True, idt)
+            feats.append(y)
+        B = x.shape[0]
+        cols = []
+        for s_i, f in enumerate(feats):
+            g = f
+            for k in range(4):
+                p = "reduce_height_module.ghc_lst.%d.layer.%d.layers." % (s_i, k)
+                g = unit(g, p + "0.1", p + "1", (2, 1), 3, True)
+            fac = 256 // g.shape[3]
+            gp = torch.cat([g[..., -1:], g, g[..., :1]], 3)
+            up = F.interpolate(gp, size=(g.shape[2], 256 + 2 * fac), mode="bilinear", align_corners=False)[..., fac:-fac]
+            cols.append(_r16(up).reshape(B, -1, 256))
+        seq = torch.cat(cols, dim=1).permute(2, 0, 1).contiguous()
+        xin = seq
+        for layer in range(2):
+            outs = []
+            for suf in ("", "_reverse"):
+                wih = _r16(sd["bi_rnn.weight_ih_l%d%s" % (layer, suf)])
+                whh = sd["bi_rnn.weight_hh_l%d%s" % (layer, suf)]
+                bias = sd["bi_rnn.bias_ih_l%d%s" % (layer, suf)] + sd["bi_rnn.bias_hh_l%d%s" % (layer, suf)]
+                gx = xin @ wih.t() + bias
+                h = xin.new_zeros(B, 512)
+                c = xin.new_zeros(B, 512)
+                ys = [None] * 256
+                for t in (range(256) if suf == "" else range(255, -1, -1)):
+                    g4 = gx[t] + h @ whh.t()
+                    i_, f_, gg, o_ = g4.chunk(4, dim=1)
+                    c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
+                    h = torch.sigmoid(o_) * torch.tanh(c)
+                    ys[t] = h
+                outs.append(torch.stack(ys, 0))
+            out = torch.cat(outs, dim=2)
+            xin = _r16(out)
+        lin = out @ sd["linear.weight"].t() + sd["linear.bias"]
+        lin = lin.view(256, B, 3, 4).permute(1, 2, 0, 3).contiguous().view(B, 3, 1024)
+        return lin[:, 1:], lin[:, :1]
+
+
 def conv_bn_act_nhwc(x_nhwc, w_oihw, bias, bn, stride, relu, residual=None):
     """Single fused conv step in NHWC, used by the per-kernel GPU parity tests.
 

@@ -1,0 +1,110 @@
+"""GPU tests of the bf16 inference mode (-m gpu): the bf16 MFMA convolution against torch on bf16-rounded operands,
+and the whole forward against (a) a CPU emulation of the engine's bf16 rounding points (tight) and (b) the
+reference's f32 golden outputs (the bf16 precision cost; BASELINE judges bf16 configs on peak / 3D-IoU agreement)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from horizonnet_amd import HorizonNet, _lib  # noqa: E402
+from oracle import horizonnet_ref, peaks_ref  # noqa: E402
+from oracle.weights import make_state_dict  # noqa: E402
+from oracle.hostinfo import usable_cores  # noqa: E402
+
+from hiputil import DEV, P, lib, report, sp  # noqa: E402
+
+torch.set_num_threads(usable_cores())
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CASES = [
+    ("1x1 64->64", 2, 8, 16, 64, 64, 1, 1, False, False),
+    ("3x3 s1 residual", 2, 8, 16, 64, 128, 3, 1, True, False),
+    ("3x3 s2", 1, 16, 32, 128, 128, 3, 2, False, False),
+    ("3x3 s(2,1) Cout=32", 2, 8, 16, 64, 32, 3, (2, 1), False, False),
+    ("1x1 big grid 128x128 tile", 2, 64, 256, 64, 256, 1, 1, True, False),
+    ("gemm f32 out", 1, 1, 512, 1024, 256, 1, 1, False, True),
+    ("3x3 ragged M", 1, 5, 7, 64, 64, 3, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16_stage(case):
+    name, B, H, W, cin, cout, k, stride, has_res, out_f32 = case
+    x = horizonnet_ref._r16(_rand((B, H, W, cin), 1))
+    w = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = _rand((cout,), 4, 0.2)
+    want = horizonnet_ref.conv_bn_act_nhwc(x, horizonnet_ref._r16(w), None, None, stride, False, None) * scale + shift
+    res = horizonnet_ref._r16(_rand(tuple(want.shape), 5)) if has_res else None
+    if has_res:
+        want = want + res
+    want = torch.relu(want)
+    if not out_f32:
+        want = horizonnet_ref._r16(want)
+    L = lib()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    xd = x.to(DEV).bfloat16().contiguous()
+    wd = w.to(DEV).contiguous()
+    scr = torch.empty(cout * cin * k * k, dtype=torch.bfloat16, device=DEV)
+    sd_, fd_ = scale.to(DEV), shift.to(DEV)
+    rd = None if res is None else res.to(DEV).bfloat16().contiguous()
+    y = torch.full(tuple(want.shape), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV)
+    _lib.check(L.hn_conv2d_nhwc_bf16(P(xd), P(wd), P(scr), P(sd_), P(fd_), P(rd), P(y), B, H, W, cin, cout, k, k, sh, sw, 1,
+                                     int(out_f32), sp()), "conv bf16")
+    torch.cuda.synchronize()
+    # one bf16 ulp of slack where the f32 sums straddle a rounding boundary
+    tol = (2e-5 if out_f32 else 8e-3) * max(1.0, float(want.abs().max()))
+    assert report("conv bf16 " + name, y.float().cpu().numpy(), want.numpy(), tol)
+
+
+def _net(seed, bn):
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(seed, bn))
+    net = net.to(DEV).eval()
+    net.precision = "bf16"
+    return net
+
+
+def test_forward_bf16_vs_emulation_and_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_demo_seed0_bnrandom.npz"))
+    img = np.load(os.path.join(golden_dir, "demo_input_u8.npz"))["img"]
+    x = torch.from_numpy(img.transpose(2, 0, 1)[None].astype(np.float32) / 255.0)
+    sd = make_state_dict(int(g["seed"]), str(g["bn"]))
+    ebon, ecor = horizonnet_ref.forward_bf16_emulated(x, sd)
+    net = _net(int(g["seed"]), str(g["bn"]))
+    with torch.no_grad():
+        bon, cor = net(x.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    ok = report("bf16 forward vs CPU emulation: bon", bon.cpu().numpy(), ebon.numpy(), 5e-3)
+    ok &= report("bf16 forward vs CPU emulation: cor", cor.cpu().numpy(), ecor.numpy(), 5e-3)
+    # precision cost against the reference's f32 forward (CPU bf16 autocast of the reference itself: 1.4e-2)
+    ok &= report("bf16 forward vs reference f32 golden: bon", bon.cpu().numpy(), g["bon"], 5e-2)
+    ok &= report("bf16 forward vs reference f32 golden: cor", cor.cpu().numpy(), g["cor"], 5e-2)
+    assert ok
+    # f32 mode of the same module is untouched by the bf16 buffers
+    net.precision = "f32"
+    with torch.no_grad():
+        b32, c32 = net(x.to(DEV))
+    assert report("f32 mode after bf16 mode", b32.cpu().numpy(), g["bon"], 1e-3)
+
+
+def test_forward_bf16_batch32_consistency():
+    net = _net(0, "random")
+    base = torch.rand(4, 3, 512, 1024, generator=torch.Generator().manual_seed(4321))
+    idx = [(7 * i + 3) % 4 for i in range(32)]
+    with torch.no_grad():
+        b32, c32 = net(base[idx].to(DEV))
+        b4, c4 = net(base.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert report("bf16 B=32 vs B=4 bon", b32.cpu().numpy(), b4.cpu().numpy()[idx], 1e-5)
+    assert report("bf16 B=32 vs B=4 cor", c32.cpu().numpy(), c4.cpu().numpy()[idx], 1e-5)
