@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 FWD_FLOP_PER_PANO = 2.0 * 71_448_920_064          # BASELINE.md section 3 / SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: FP32 matrix peak (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: BF16 dense MFMA peak (spec)
 
 
 def shard_for_rank(global_units, world, rank):
@@ -150,6 +151,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="panoramas per GPU per step (configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (default, the parity path); bf16 = the engine's bf16 inference mode")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the headline metric (default); train = one optimisation step per step")
     args = ap.parse_args()
@@ -181,6 +184,7 @@ def main():
     net = HorizonNet("resnet50", True)
     net.load_state_dict(make_state_dict(0, "random"))
     net = net.to(dev).eval()
+    net.precision = args.dtype
 
     B = args.batch
     lo, hi = shard_for_rank(B * world, world, rank)   # weak scaling: B panoramas per rank
@@ -248,7 +252,8 @@ def main():
         igemm_fl = sum(v[1] for k, v in fam.items() if "conv_igemm" in k)
         traffic = None                                   # HBM-side bytes per forward from the committed PMC passes
         tpath = os.path.join(ROOT, "profiles", "r1_v1_pmc_traffic.json")
-        if B == 32 and os.path.exists(tpath):
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        if B == 32 and args.dtype == "f32" and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("total_bytes")
         out = {
             "metric": "panoramas/s (512x1024 fwd)",
@@ -261,21 +266,37 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=32 random 512x1024 panos per GPU, ResNet-50 + height-compression + bi-LSTM forward, fp32, seeded random-init weights",
+            "config": {"workload": "BASELINE configs[1]: batch=32 random 512x1024 panos per GPU, ResNet-50 + height-compression + bi-LSTM forward, %s, seeded random-init weights"
+                                   % ("fp32" if args.dtype == "f32" else "bf16 MFMA convs (f32 accumulate, f32 LSTM/head) -- NOT the fp32 config"),
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d (independent replicas, no data-path collective)" % world},
             "roofline": {"bound": "mfma", "kernel": "hn_forward (all launches of one forward; conv_igemm_f32 family = %.0f%% of device time)" % (100.0 * igemm_ms / prof_total),
-                         "achieved": round(achieved_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": "bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate --pmc passes, profiles/r1_v1_pmc_traffic.json; Infinity-Cache hits included; algorithmic minimum 31.7 GB",
                          "algorithmic_flop_per_launch": FWD_FLOP_PER_PANO * B,
                          "launch_ms_hip_events": round(ms_per_fwd, 3),
                          "conv_igemm_f32": {"ms": round(igemm_ms, 3), "tflops": round(igemm_fl / (igemm_ms * 1e-3) / 1e12, 2),
-                                            "frac": round(igemm_fl / (igemm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                                            "frac": round(igemm_fl / (igemm_ms * 1e-3) / 1e12 / peak, 4)},
                          "breakdown": breakdown},
         }
+        if args.dtype == "f32":
+            # informational: the engine's bf16 inference mode on the same inputs (NOT the headline: configs[1] is fp32)
+            net.precision = "bf16"
+            with torch.no_grad():
+                hb, hc = net(x)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    net(x)
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t1) / args.steps
+            net.precision = "f32"
+            out["bf16_mode"] = {"value": round(B / dt, 1), "unit": "panoramas/s", "ms_per_step": round(dt * 1e3, 3),
+                                "max_abs_vs_f32_outputs": round(float(max((hb - bon).abs().max(), (hc - cor).abs().max())), 6),
+                                "note": "bf16 MFMA convs, f32 accumulate/LSTM/head; single GPU; not the fp32 configuration the headline value is quoted on"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["pano_stretch"] = pano_stretch_leg(dev)
