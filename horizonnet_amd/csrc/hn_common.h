@@ -73,7 +73,7 @@ int hn_launch_bn_bwd_apply(const float* dy, const float* ymask, const float* z, 
                            hipStream_t s);
 int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
 int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
-int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int B, int Hi, int Wi, int C, hipStream_t s);
+int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, hipStream_t s);
 int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
 int hn_launch_dropout(const float* in, float* out, long n, float p, unsigned long long seed, hipStream_t s);
 int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, const float* y, float* dy, float* dlin, float* dw,

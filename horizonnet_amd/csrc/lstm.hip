@@ -171,41 +171,45 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
     }
 }
 
-// Adjoint recurrence GEMV for one step: dh[b][dir*512 + k] = sum_n dg[b][dir*2048 + n] * Whh_dir[n][k]
-// (reference: autograd of nn.LSTM, train.py:278).  Takes Whh TRANSPOSED ([512][2048], k-major) so that the 4
-// k-columns a workgroup owns are 4 contiguous 8 KB rows.  256 workgroups x (32 b x 8 n-slices).
+// Adjoint recurrence GEMM for one step: dh[b][dir*512 + k] = sum_n dg[b][dir*2048 + n] * Whh_dir[n][k]
+// (reference: autograd of nn.LSTM, train.py:278) on the matrix cores.  Whh is given TRANSPOSED ([512][2048],
+// k-major): it is the MFMA B operand with n as the reduction index.  Grid = 2 dirs x 16 k-tiles (32 columns)
+// x 8 n-slices (256 each) = 256 workgroups; each of the 4 waves reduces 64 n with v_mfma_f32_32x32x2_f32
+// (A = dg rows, <= 32 per launch row-tile), partial tiles are combined with float atomics into the pre-zeroed dh.
 __global__ __launch_bounds__(256) void lstm_bwd_dh_kernel(const float* __restrict__ dg_f, const float* __restrict__ dg_r,
                                                           const float* __restrict__ whhT_f, const float* __restrict__ whhT_r,
                                                           float* __restrict__ dh, int B)
 {
-    const int dir = blockIdx.x & 1;
-    const int k0 = (blockIdx.x >> 1) * 4;
-    const float* wt = (dir ? whhT_r : whhT_f) + (size_t)k0 * 2048;
-    const int part = threadIdx.x & 7;
-    const int b = blockIdx.y * 32 + (threadIdx.x >> 3);
-    const int bb = b < B ? b : B - 1;
-    const float* g = (dir ? dg_r : dg_f) + (size_t)bb * 4096 + dir * 2048 + part * 256;   // each direction at its own time index
-    const float* w = wt + part * 256;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int n = 0; n < 256; n += 4) {
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + n);
+    const int bid = blockIdx.x;
+    const int dir = bid & 1;
+    const int kt = (bid >> 1) & 15;
+    const int ns = bid >> 5;                               // 0..7
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 31, half = lane >> 5;
+    const int b0 = blockIdx.y * 32;
+    const int brow = (b0 + fr) < B ? (b0 + fr) : (B - 1);  // clamped: padding rows are never stored
+    const int nbase = ns * 256 + wave * 64 + half * 4;     // + 8*j + q
+    const float* g = (dir ? dg_r : dg_f) + (size_t)brow * 4096 + dir * 2048 + nbase;
+    const float* w = (dir ? whhT_r : whhT_f) + (size_t)(kt * 32 + fr) * 2048 + nbase;
+    f32x4 ga[8], wb[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)k * 2048 + n);
-            acc[k] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
-        }
+    for (int j = 0; j < 8; ++j) {
+        ga[j] = *reinterpret_cast<const f32x4*>(g + 8 * j);
+        wb[j] = *reinterpret_cast<const f32x4*>(w + 8 * j);
     }
-    f32x4 out;
+    f32x16 acc;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float v = acc[k];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        out[k] = v;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j][q], wb[j][q], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (b < B)
+            __hip_atomic_fetch_add(dh + (size_t)b * 1024 + dir * 512 + kt * 32 + fr, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (part == 0 && b < B) *reinterpret_cast<f32x4*>(dh + (size_t)b * 1024 + dir * 512 + k0) = out;
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C)
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // whhT_f / whhT_r: the recurrent weights transposed to [512][2048]
 int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whhT_f, const float* whhT_r, float* dh, int B, hipStream_t s)
 {
+    HN_HIP(hipMemsetAsync(dh, 0, (size_t)B * 1024 * sizeof(float), s));      // partial tiles are accumulated with atomics
     hipLaunchKernelGGL(lstm_bwd_dh_kernel, dim3(256, (B + 31) / 32), dim3(256), 0, s, dg_f, dg_r, whhT_f, whhT_r, dh, B);
     HN_LAUNCH_CHECK();
     return 0;

@@ -442,7 +442,7 @@ extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* d
     // ---- max-pool + stem ----
     {
         const Unit& u = pl.units[0];
-        if ((rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
+        if ((rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
         if ((rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr))) return rc;
     }
     return 0;

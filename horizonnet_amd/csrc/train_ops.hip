@@ -151,9 +151,38 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, 
         *reinterpret_cast<f32x4*>(y + i * 4) += *reinterpret_cast<const f32x4*>(x + i * 4);
 }
 
-// max-pool 3x3/2 pad 1 adjoint (gather form, deterministic): each input pixel collects from the <= 4 windows
-// that contain it and whose arg-max (first maximum in row-major window order, as torch) it is.
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+// max-pool 3x3/2 pad 1 adjoint, deterministic, in two passes: (1) per pooled output, the input position of its
+// arg-max (first maximum in row-major window order, as torch); (2) per input pixel, gather from the <= 4 windows that
+// contain it and selected it.
+__global__ __launch_bounds__(256) void maxpool_argmax_kernel(const float* __restrict__ in, int* __restrict__ amax, int Hi, int Wi, int Ho,
+                                                             int Wo, int C, long total)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long b = t / Ho;
+        float best = -INFINITY;
+        int pos = -1;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h2 = ho * 2 - 1 + dh;
+            if ((unsigned)h2 >= (unsigned)Hi) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int w2 = wo * 2 - 1 + dw;
+                if ((unsigned)w2 >= (unsigned)Wi) continue;
+                const float u = in[((b * Hi + h2) * Wi + w2) * (long)C + c];
+                if (u > best) { best = u; pos = h2 * Wi + w2; }
+            }
+        }
+        amax[i] = pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const int* __restrict__ amax, const float* __restrict__ dout,
                                                           float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C, long total)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -163,26 +192,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         t /= Wi;
         const int hi = (int)(t % Hi);
         const long b = t / Hi;
-        const float v = in[i];
+        const int me = hi * Wi + wi;
         float g = 0.f;
-        for (int ho = (hi) / 2; ho <= (hi + 1) / 2; ++ho) {           // windows rows covering hi: 2*ho-1 <= hi <= 2*ho+1
-            if (ho < 0 || ho >= Ho) continue;
-            for (int wo = (wi) / 2; wo <= (wi + 1) / 2; ++wo) {
-                if (wo < 0 || wo >= Wo) continue;
-                // is (hi, wi) the first maximum of window (ho, wo)?
-                bool first = true;
-                for (int dh = 0; dh < 3 && first; ++dh) {
-                    const int h2 = ho * 2 - 1 + dh;
-                    if ((unsigned)h2 >= (unsigned)Hi) continue;
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const int w2 = wo * 2 - 1 + dw;
-                        if ((unsigned)w2 >= (unsigned)Wi) continue;
-                        const float u = in[((b * Hi + h2) * Wi + w2) * (long)C + c];
-                        const bool before = (h2 < hi) || (h2 == hi && w2 < wi);
-                        if (u > v || (before && u == v)) { first = false; break; }
-                    }
-                }
-                if (first) g += dout[((b * Ho + ho) * Wo + wo) * (long)C + c];
+        for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {             // windows covering row hi: 2*ho-1 <= hi <= 2*ho+1
+            if (ho >= Ho) continue;
+            for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
+                if (wo >= Wo) continue;
+                const long o = ((b * Ho + ho) * Wo + wo) * (long)C + c;
+                if (amax[o] == me) g += dout[o];
             }
         }
         din[i] = g;
@@ -399,10 +416,15 @@ int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s)
     return 0;
 }
 
-int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int B, int Hi, int Wi, int C, hipStream_t s)
+// scratch: B * (Hi/2) * (Wi/2) * C ints
+int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, hipStream_t s)
 {
     const long total = (long)B * Hi * Wi * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, in, dout, din, Hi, Wi, Hi / 2, Wi / 2, C, total);
+    const long total_o = (long)B * (Hi / 2) * (Wi / 2) * C;
+    HN_REQUIRE((long)Hi * Wi < 0x7fffffffL, "maxpool_bwd: image too large");
+    hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(grid_for(total_o, 256L * 64)), dim3(256), 0, s, in, scratch, Hi, Wi, Hi / 2, Wi / 2, C, total_o);
+    HN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, scratch, dout, din, Hi, Wi, Hi / 2, Wi / 2, C, total);
     HN_LAUNCH_CHECK();
     return 0;
 }
