@@ -293,10 +293,12 @@ int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
 {
     const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
     auto kern = conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STEM, OUT_F32>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};   // per instantiation, per device
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
         HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const int MT = hn_cdiv(a.M, BM);
     const int NT = a.Cout / BN;

@@ -27,6 +27,7 @@
 #include "hn_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -45,10 +46,13 @@ struct ConvArgs {
     int KW, sh, sw, ph, pw;
     int M, K, nk, relu, ldy;
     int xstride;         // floats between consecutive input pixels (>= Cin; lets a GEMM read a column slice)
-    int transposed;      // 1: data-gradient mode -- x is dY on the (Hi,Wi) grid, y is dX on the (Ho,Wo) grid:
-                         //    input pixel = (out + pad - tap) / stride where divisible (reference conv's adjoint)
+    // data-gradient mode (template TR): x is dY on the (Hi,Wi) grid, y is dX on the (Ho,Wo) grid.  One launch handles ONE
+    // stride-parity class of dX pixels (hi % sh == ca, wi % sw == cb) -- exactly the taps that reach that class
+    // (tdh/tdw, a sub-pixel decomposition of the strided conv's adjoint, so no multiply-by-zero work); rows m enumerate
+    // the class grid (cHo x cWo per image); input pixel = (out + pad - tap) / stride.
     int sh_log2, sw_log2;
-    int ablate;          // DEBUG ONLY (HN_CONV_ABLATE): bit0 skip in-loop global loads, bit1 skip LDS staging
+    int ca, cb, cHo, cWo;
+    int tdh[3], tdw[3], ntdh, ntdw;
     int xcd_swizzle;     // 1: remap blockIdx so each XCD (own L2) works on a contiguous run of tiles
 };
 
@@ -74,9 +78,10 @@ __device__ __forceinline__ void buf_load16_to_lds(__amdgpu_buffer_rsrc_t rsrc, f
 //              row r is stored in slot c ^ ((r >> 1) & 7) -- the permutation is applied to the per-lane
 //              SOURCE offset (the LDS side of an LDS-DMA is lane-linear) and again on the fragment read,
 //              which keeps ds_read_b128 conflict-free.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA, bool TR>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
 {
+    static_assert(!(STEM && TR), "the stem has no data gradient");
     constexpr int LDS_STRIDE = DMA ? BK : BK + 4;   // floats per LDS tile row
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     const int n0 = nt * BN;
 
     // ---- buffer descriptors (wave-uniform): A rebased at the tile's first image, W at the tile's first row ----
-    const int hw_out = p.Ho * p.Wo;
+    const int hw_out = TR ? p.cHo * p.cWo : p.Ho * p.Wo;
     const int b_first = m0 / hw_out;
     const size_t img_floats = (size_t)p.Hi * p.Wi * (STEM ? 4 : p.xstride);
     const __amdgpu_buffer_rsrc_t rsrc_a =
@@ -128,13 +133,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     for (int q = 0; q < AP; ++q) {
         const int m = m0 + lrow + 32 * q;
         if (m < p.M) {
-            const int wo = m % p.Wo;
-            const int t = m / p.Wo;
-            const int ho = t % p.Ho;
-            const int b = t / p.Ho;
+            const int gw = TR ? p.cWo : p.Wo, gh = TR ? p.cHo : p.Ho;
+            const int wo = m % gw;
+            const int t = m / gw;
+            const int ho = t % gh;
+            const int b = t / gh;
             a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
-            a_hi0[q] = p.transposed ? ho + p.ph : ho * p.sh - p.ph;
-            a_wi0[q] = p.transposed ? wo + p.pw : wo * p.sw - p.pw;
+            a_hi0[q] = TR ? p.ca + p.sh * ho + p.ph : ho * p.sh - p.ph;     // TR: dX row + pad
+            a_wi0[q] = TR ? p.cb + p.sw * wo + p.pw : wo * p.sw - p.pw;
         } else {
             a_pix0[q] = -1;
             a_hi0[q] = 0;
@@ -152,15 +158,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
         for (int q = 0; q < AP; ++q) {
             int hi, wi;
             bool ok = a_pix0[q] >= 0;
-            if (!STEM && p.transposed) {
-                const int th = a_hi0[q] - dh;                    // = ho_z * sh when this tap contributed
-                int tw = a_wi0[q] - dw;
+            if (TR) {                                            // dh / dw are INDICES into the class's tap lists
+                const int th = a_hi0[q] - p.tdh[dh];             // = ho_z * sh (divisible by construction of the class)
+                int tw = a_wi0[q] - p.tdw[dw];
                 tw = tw < 0 ? tw + p.Wo : tw;                     // circular on the dX grid (width Wo)
                 tw = tw >= p.Wo ? tw - p.Wo : tw;
-                ok = ok && th >= 0 && ((th & (p.sh - 1)) == 0) && ((tw & (p.sw - 1)) == 0);
                 hi = th >> p.sh_log2;
                 wi = tw >> p.sw_log2;
-                ok = ok && hi < p.Hi;
+                ok = ok && th >= 0 && hi < p.Hi;
             } else {
                 hi = a_hi0[q] + dh;
                 wi = a_wi0[q] + (STEM ? lcol : dw);
@@ -203,8 +208,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
             c0 += BK;
             if (c0 == p.Cin) {
                 c0 = 0;
-                if (++dw == p.KW) { dw = 0; ++dh; }
-                tap_offsets(dh, dw);
+                if (++dw == (TR ? p.ntdw : p.KW)) { dw = 0; ++dh; }
+                if (!TR || dh < p.ntdh) tap_offsets(dh, dw);
             }
         }
     };
@@ -235,9 +240,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     const int fk = (lane >> 5) * 4;
     const int fswz = (fr >> 1) & 7;  // DMA layout: slot permutation of this lane's fragment rows (same for every 32-row tile)
 
+    if (!TR || p.nk > 0) {      // a parity class no tap reaches (1x1 stride 2) has K = 0: dX = add there
     fetch(0);
     stage(0);
     __syncthreads();
+    }
 
     // Software-pipelined main loop: MFMA fragments are double-buffered in registers and the fragment
     // reads of step kk+1 are issued before the MFMAs of step kk -- including ACROSS the per-chunk
@@ -263,17 +270,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
         };
-        ldfrag(fa0, fb0, 0, 0);
+        if (!TR || p.nk > 0) ldfrag(fa0, fb0, 0, 0);
         for (int kc = 0; kc < p.nk; ++kc) {
             const int buf = kc & 1;
             const bool more = kc + 1 < p.nk;
-            if (more && !(p.ablate & 1)) fetch(kc + 1);
+            if (more) fetch(kc + 1);
             ldfrag(fa1, fb1, buf, 1);
             mma(fa0, fb0);
             ldfrag(fa0, fb0, buf, 2);
             mma(fa1, fb1);
             ldfrag(fa1, fb1, buf, 3);
-            if (more && !(p.ablate & 2)) stage(buf ^ 1);
+            if (more) stage(buf ^ 1);
             mma(fa0, fb0);
             __syncthreads();                 // chunk kc+1 staged; every wave has read all of chunk kc
             if (more) ldfrag(fa0, fb0, buf ^ 1, 0);
@@ -293,6 +300,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     static_assert(NPS >= 1, "epilogue geometry");
     const int ccol = (tid % TPR) * 4;
     const int crow = tid / TPR;
+    // output pixel of GEMM row m: dense, except in data-gradient mode where the rows enumerate one parity class
+    auto out_pix = [&](int m) -> size_t {
+        if (!TR) return (size_t)m;
+        const int wo = m % p.cWo;
+        const int t = m / p.cWo;
+        const int ho = t % p.cHo;
+        const int b = t / p.cHo;
+        return ((size_t)b * p.Ho + (p.ca + p.sh * ho)) * p.Wo + (p.cb + p.sw * wo);
+    };
     auto epilogue = [&](auto has_res) {
         constexpr bool HAS_RES = decltype(has_res)::value;
         // residual rows first: all loads in flight while the accumulators travel through LDS
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
             for (int ps = 0; ps < WAVES_M * NPS; ++ps) {
                 const int m = m0 + crow + ps * RPP;
                 const int mc = m < p.M ? m : p.M - 1;
-                rres[ps] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
+                rres[ps] = *reinterpret_cast<const f32x4*>(p.res + out_pix(mc) * p.Cout + n0 + ccol);
             }
         }
         const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 }
-                if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n0 + ccol) = v;
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.y + out_pix(m) * p.ldy + n0 + ccol) = v;
             }
         }
     };
@@ -346,26 +362,29 @@ int env_flag(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA, bool TR>
 int launch_cfg_d(const ConvArgs& a, hipStream_t s);
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool TR = false>
 int launch_cfg(const ConvArgs& a, hipStream_t s)
 {
     static const int dma = env_flag("HN_CONV_DMA", 1);
-    return dma ? launch_cfg_d<BM, BN, WAVES_M, WAVES_N, STEM, true>(a, s) : launch_cfg_d<BM, BN, WAVES_M, WAVES_N, STEM, false>(a, s);
+    if (TR) return launch_cfg_d<BM, BN, WAVES_M, WAVES_N, false, true, TR>(a, s);
+    return dma ? launch_cfg_d<BM, BN, WAVES_M, WAVES_N, STEM, true, false>(a, s) : launch_cfg_d<BM, BN, WAVES_M, WAVES_N, STEM, false, false>(a, s);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA, bool TR>
 int launch_cfg_d(const ConvArgs& a, hipStream_t s)
 {
     const size_t lds = 2 * (size_t)(BM + BN) * (DMA ? BK : BK + 4) * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, STEM, DMA>;
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
+    auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, STEM, DMA, TR>;
+    static bool attr_done[64] = {};  // per instantiation, per device (one engine per device may live in this process)
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
         HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const int MT = hn_cdiv(a.M, BM);
     const int NT = a.Cout / BN;
@@ -374,24 +393,107 @@ int launch_cfg_d(const ConvArgs& a, hipStream_t s)
     return 0;
 }
 
+// OIHW -> per-class data-gradient packing [Cin][ndh][ndw][Cout] (only the taps that reach the class)
+__global__ __launch_bounds__(256) void pack_dgrad_class_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH,
+                                                               int KW, int dh0, int dh1, int dh2, int ndh, int dw0, int dw1, int dw2, int ndw)
+{
+    const long total = (long)Cin * ndh * ndw * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Cout);
+        long t = i / Cout;
+        const int iw = (int)(t % ndw);
+        t /= ndw;
+        const int ih = (int)(t % ndh);
+        const int c = (int)(t / ndh);
+        const int dh = ih == 0 ? dh0 : (ih == 1 ? dh1 : dh2), dw = iw == 0 ? dw0 : (iw == 1 ? dw1 : dw2);
+        out[i] = w[(((long)o * Cin + c) * KH + dh) * KW + dw];
+    }
+}
+
+template <bool TR>
+int dispatch_tiles(const ConvArgs& a, int Cout, int force_tile, hipStream_t s)
+{
+    const long M = a.M;
+    if (force_tile == 1 && Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, false, TR>(a, s);
+    if (force_tile == 2 && Cout % 64 == 0) return launch_cfg<128, 64, 2, 2, false, TR>(a, s);
+    if (force_tile == 3 && Cout % 128 == 0) return launch_cfg<64, 128, 2, 2, false, TR>(a, s);
+    if (force_tile == 4 && Cout % 64 == 0) return launch_cfg<64, 64, 2, 2, false, TR>(a, s);
+    if (Cout % 128 == 0) {
+        const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 128);
+        if (blocks128 >= 512) return launch_cfg<128, 128, 2, 2, false, TR>(a, s);
+        return launch_cfg<64, 128, 2, 2, false, TR>(a, s);
+    }
+    if (Cout % 64 == 0) {
+        const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 64);
+        if (blocks128 >= 512) return launch_cfg<128, 64, 2, 2, false, TR>(a, s);
+        return launch_cfg<64, 64, 2, 2, false, TR>(a, s);
+    }
+    return launch_cfg<128, 32, 4, 1, false, TR>(a, s);
+}
+
 }  // namespace
+
+// Data gradient of a forward conv (d describes the FORWARD conv: x grid Hi x Wi x Cin -> z grid Ho x Wo x Cout).
+// dz [B][Ho][Wo][Cout] -> dx [B][Hi][Wi][Cin] (+ add).  One launch per stride-parity class; w_scratch holds the
+// per-class re-packed weights (Cout*Cin*KH*KW floats), ones/zeros are 4096-float device vectors.
+int hn_launch_conv_dgrad(const ConvDesc& d, const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch,
+                         const float* ones, const float* zeros, hipStream_t s)
+{
+    static const int xcd_swizzle = env_flag("HN_XCD_SWIZZLE", 1);
+    static const int force_tile = env_flag("HN_FORCE_TILE", 0);
+    HN_REQUIRE((d.sh == 1 || d.sh == 2) && (d.sw == 1 || d.sw == 2) && !d.stem, "conv dgrad: strides must be 1 or 2");
+    HN_REQUIRE(d.Cout % BK == 0 && d.Cin % 32 == 0, "conv dgrad: Cout %% 32 / Cin %% 32");
+    HN_REQUIRE(d.Hi % d.sh == 0 && d.Wi % d.sw == 0, "conv dgrad: input size must be a multiple of the stride");
+    float* wp = w_scratch;
+    for (int ca = 0; ca < d.sh; ++ca) {
+        for (int cb = 0; cb < d.sw; ++cb) {
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xcd_swizzle = xcd_swizzle;
+            a.x = dz; a.scale = ones; a.shift = zeros; a.res = add; a.y = dx;
+            a.Hi = d.Ho; a.Wi = d.Wo; a.Cin = d.Cout; a.Ho = d.Hi; a.Wo = d.Wi; a.Cout = d.Cin;
+            a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
+            a.sh_log2 = d.sh == 2 ? 1 : 0; a.sw_log2 = d.sw == 2 ? 1 : 0;
+            a.xstride = d.Cout; a.relu = 0; a.ldy = d.Cin;
+            a.ca = ca; a.cb = cb; a.cHo = d.Hi / d.sh; a.cWo = d.Wi / d.sw;
+            a.ntdh = a.ntdw = 0;
+            for (int t = 0; t < d.KH; ++t) if ((ca + d.ph - t) % d.sh == 0) a.tdh[a.ntdh++] = t;     // (hi + pad - dh) divisible by sh
+            for (int t = 0; t < d.KW; ++t) if ((cb + d.pw - t) % d.sw == 0) a.tdw[a.ntdw++] = t;
+            a.M = d.B * a.cHo * a.cWo;
+            a.K = a.ntdh * a.ntdw * d.Cout;
+            a.nk = a.K / BK;
+            if (a.K > 0) {
+                const long total = (long)d.Cin * a.K;
+                long g = (total + 255) / 256;
+                if (g > 4096) g = 4096;
+                hipLaunchKernelGGL(pack_dgrad_class_kernel, dim3((unsigned)g), dim3(256), 0, s, w_oihw, wp, d.Cout, d.Cin, d.KH, d.KW,
+                                   a.tdh[0], a.tdh[1], a.tdh[2], a.ntdh, a.tdw[0], a.tdw[1], a.tdw[2], a.ntdw);
+                HN_LAUNCH_CHECK();
+            }
+            a.w = wp;
+            {
+                const double span = 128.0 / ((double)a.cHo * a.cWo) + 2.0;
+                HN_REQUIRE(span * a.Hi * a.Wi * (double)a.xstride * 4.0 < 2147483648.0, "conv dgrad: image too large for 32-bit tile offsets");
+            }
+            if (int rc = dispatch_tiles<true>(a, d.Cin, force_tile, s)) return rc;
+            wp += (size_t)d.Cin * a.K;
+        }
+    }
+    return 0;
+}
 
 int hn_launch_conv(const ConvDesc& d, hipStream_t s)
 {
     static const int xcd_swizzle = env_flag("HN_XCD_SWIZZLE", 1);   // tuning knob
-    static const int ablate = env_flag("HN_CONV_ABLATE", 0);        // debug timing ablations, results invalid when != 0
     static const int force_tile = env_flag("HN_FORCE_TILE", 0);     // experiment knob: 1=128x128 2=128x64 3=64x128 4=64x64
     ConvArgs a;
     a.xcd_swizzle = xcd_swizzle;
-    a.ablate = ablate;
     a.x = d.x; a.w = d.w; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.y = d.y;
     a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
     a.xstride = d.xstride ? d.xstride : d.Cin;
-    a.transposed = d.transposed;
-    a.sh_log2 = d.sh == 2 ? 1 : 0;
-    a.sw_log2 = d.sw == 2 ? 1 : 0;
-    HN_REQUIRE(!d.transposed || ((d.sh == 1 || d.sh == 2) && (d.sw == 1 || d.sw == 2) && !d.stem), "conv dgrad: strides must be 1 or 2");
+    a.sh_log2 = a.sw_log2 = 0; a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
+    HN_REQUIRE(!d.transposed, "conv: data gradients go through hn_launch_conv_dgrad");
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;
     a.ldy = d.ldy ? d.ldy : d.Cout;
@@ -413,20 +515,5 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BK;
     HN_REQUIRE(128.0 * a.K * 4.0 < 2147483648.0, "conv: K too large for 32-bit weight-tile offsets");
-    const long M = a.M;
-    if (force_tile == 1 && d.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, false>(a, s);
-    if (force_tile == 2 && d.Cout % 64 == 0) return launch_cfg<128, 64, 2, 2, false>(a, s);
-    if (force_tile == 3 && d.Cout % 128 == 0) return launch_cfg<64, 128, 2, 2, false>(a, s);
-    if (force_tile == 4 && d.Cout % 64 == 0) return launch_cfg<64, 64, 2, 2, false>(a, s);
-    if (d.Cout % 128 == 0) {
-        const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 128);
-        if (blocks128 >= 512) return launch_cfg<128, 128, 2, 2, false>(a, s);
-        return launch_cfg<64, 128, 2, 2, false>(a, s);
-    }
-    if (d.Cout % 64 == 0) {
-        const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 64);
-        if (blocks128 >= 512) return launch_cfg<128, 64, 2, 2, false>(a, s);
-        return launch_cfg<64, 64, 2, 2, false>(a, s);
-    }
-    return launch_cfg<128, 32, 4, 1, false>(a, s);
+    return dispatch_tiles<false>(a, d.Cout, force_tile, s);
 }

@@ -232,10 +232,12 @@ int launch_wgrad(WgradArgs a, hipStream_t s)
     a.mchunk = (int)mchunk;
     const size_t lds = 2 * (size_t)WCH * ((TN + 4) + (TK + 4)) * sizeof(float);
     auto kern = conv_wgrad_kernel<TN, TK, STEM>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};   // per instantiation, per device
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
         HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(NT * KT * split)), dim3(256), lds, s, a);
     HN_LAUNCH_CHECK();

@@ -487,19 +487,16 @@ extern "C" int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const 
     HN_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin <= 4096 && Cout <= 4096, "hn_conv2d_dgrad_nhwc: channels must be multiples of 32, <= 4096");
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = hn_launch_pack_conv_dgrad(w_oihw, w_scratch, Cout, Cin, KH, KW, s))) return rc;
     // ones / zeros for the epilogue live behind the packed dgrad weights in the scratch buffer
     float* ones = w_scratch + (size_t)Cout * Cin * KH * KW;
     float* zeros = ones + 4096;
     if ((rc = hn_launch_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, ones, zeros, 4096, s))) return rc;
-    ConvDesc d;
+    ConvDesc d;                         // the FORWARD conv's geometry
     memset(&d, 0, sizeof(d));
-    d.x = dz; d.w = w_scratch; d.scale = ones; d.shift = zeros; d.res = add; d.y = dx;
-    d.B = B; d.Ho = Hx; d.Wo = Wx; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw; d.ph = KH / 2; d.pw = KW / 2;
-    d.Hi = (Hx + 2 * d.ph - KH) / sh + 1;
-    d.Wi = (Wx + 2 * d.pw - KW) / sw + 1;
-    d.Cin = Cout; d.Cout = Cin; d.relu = 0; d.ldy = Cin; d.transposed = 1;
-    return hn_launch_conv(d, s);
+    d.B = B; d.Hi = Hx; d.Wi = Wx; d.Cin = Cin; d.Cout = Cout; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw; d.ph = KH / 2; d.pw = KW / 2;
+    d.Ho = (Hx + 2 * d.ph - KH) / sh + 1;
+    d.Wo = (Wx + 2 * d.pw - KW) / sw + 1;
+    return hn_launch_conv_dgrad(d, dz, w_oihw, add, dx, w_scratch, ones, zeros, s);
 }
 
 extern "C" int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,

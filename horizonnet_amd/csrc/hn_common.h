@@ -53,6 +53,8 @@ struct ConvDesc {
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };
 int hn_launch_conv(const ConvDesc& d, hipStream_t s);
+int hn_launch_conv_dgrad(const ConvDesc& fwd, const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch,
+                         const float* ones, const float* zeros, hipStream_t s);
 int hn_launch_prep_nhwc4(const float* x, float* out, int B, int C_in, int H, int W, hipStream_t s);
 int hn_launch_maxpool(const float* in, float* out, int B, int Hi, int Wi, int C, hipStream_t s);
 int hn_launch_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int cq, int col0, hipStream_t s);

@@ -180,20 +180,15 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     return hn_launch_unpack_conv(scratch, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, u.stem ? 8 : 0, c.s);
 }
 
-// data gradient of one unit: dx = conv^T(dz) (+ add)
+// data gradient of one unit: dx = conv^T(dz) (+ add), one launch per stride-parity class
 int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, float* dx)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
-    float* wd = c.W + c.pl.wsB;
-    int rc;
-    if ((rc = hn_launch_pack_conv_dgrad(c.bound(cl.wkey + ".weight"), wd, cl.cout, cl.cin, cl.k, cl.k, c.s))) return rc;
-    ConvDesc d;
+    ConvDesc d;                         // the FORWARD conv's geometry
     memset(&d, 0, sizeof(d));
-    d.x = dz; d.w = wd; d.scale = c.P + c.a.ones_off; d.shift = c.P + c.a.zeros_off; d.res = add; d.y = dx;
-    d.B = c.B; d.Hi = u.Ho; d.Wi = u.Wo; d.Cin = cl.cout; d.Cout = cl.cin; d.KH = cl.k; d.KW = cl.k;
-    d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Hi; d.Wo = u.Wi; d.relu = 0; d.ldy = cl.cin;
-    d.transposed = 1;
-    return hn_launch_conv(d, c.s);
+    d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = cl.cin; d.Cout = cl.cout; d.KH = cl.k; d.KW = cl.k;
+    d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo;
+    return hn_launch_conv_dgrad(d, dz, c.bound(cl.wkey + ".weight"), add, dx, c.W + c.pl.wsB, c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s);
 }
 
 int gemm_rows(const float* x, int xstride, const float* w, const float* scale, const float* shift, float* y, long rows, int K, int N,
