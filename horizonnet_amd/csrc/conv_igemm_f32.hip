@@ -419,9 +419,17 @@ int dispatch_tiles(const ConvArgs& a, int Cout, int force_tile, hipStream_t s)
     if (force_tile == 3 && Cout % 128 == 0) return launch_cfg<64, 128, 2, 2, false, TR>(a, s);
     if (force_tile == 4 && Cout % 64 == 0) return launch_cfg<64, 64, 2, 2, false, TR>(a, s);
     if (Cout % 128 == 0) {
+        // measured on MI355X (B=32 sweep): 128x128 for long-K convs; the short-K 1x1 "conv3" layers (residual epilogue,
+        // K <= 512) prefer 64-row tiles (more workgroups in flight to overlap their epilogues); tiny grids go 64x64.
         const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 128);
-        if (blocks128 >= 512) return launch_cfg<128, 128, 2, 2, false, TR>(a, s);
-        return launch_cfg<64, 128, 2, 2, false, TR>(a, s);
+        if (blocks128 >= 512) {
+            if (!TR && a.res != nullptr && a.K <= 64) return launch_cfg<64, 64, 2, 2, false, TR>(a, s);
+            if (!TR && a.res != nullptr && a.K <= 512) return launch_cfg<64, 128, 2, 2, false, TR>(a, s);
+            return launch_cfg<128, 128, 2, 2, false, TR>(a, s);
+        }
+        const long blocks64 = (long)hn_cdiv(M, 64) * (Cout / 128);
+        if (blocks64 >= 512) return launch_cfg<64, 128, 2, 2, false, TR>(a, s);
+        return launch_cfg<64, 64, 2, 2, false, TR>(a, s);
     }
     if (Cout % 64 == 0) {
         const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 64);
