@@ -272,6 +272,20 @@ def test_forward_full_batch32_consistency(golden_dir):
     assert ok
 
 
+def test_forward_batch_not_multiple_of_32():
+    # B = 40: two LSTM chunks (32 + 8), ragged M tiles everywhere; every panorama must equal its B=4 result
+    net = _net(2, "random")
+    base = torch.rand(4, 3, 512, 1024, generator=torch.Generator().manual_seed(99))
+    idx = [(3 * i + 1) % 4 for i in range(40)]
+    with torch.no_grad():
+        b40, c40 = net(base[idx].to(DEV))
+        b4, c4 = net(base.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert report("B=40 vs B=4 bon", b40.cpu().numpy(), b4.cpu().numpy()[idx], 1e-5)
+    assert report("B=40 vs B=4 cor", c40.cpu().numpy(), c4.cpu().numpy()[idx], 1e-5)
+
+
 def test_module_contract_errors():
     net = _net(0, "identity")
     with pytest.raises(NotImplementedError):

@@ -175,3 +175,59 @@ def test_dropout_statistics_and_eval_after_train():
         e1, _ = net(x)
         e2, _ = net(x)
     assert torch.equal(e1, e2)                            # eval path re-packs with the updated running stats
+
+
+_DP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from horizonnet_amd import HorizonNet, broadcast_module_
+from oracle.weights import make_state_dict
+dist.init_process_group(backend="gloo")          # two ranks share the one GPU of the test box (RCCL refuses that)
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+net = HorizonNet("resnet50", True)
+net.load_state_dict(make_state_dict(21 + rank, "random"))   # different weights per rank: broadcast must fix that
+net = net.to(dev).train()
+net.bi_rnn.dropout = 0.0
+net.drop_out.p = 0.0
+broadcast_module_(net, src=0)
+xs = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(5)).to(dev)
+wb = torch.rand(2, 2, 1024, generator=torch.Generator().manual_seed(6)).to(dev) - 0.5
+def grads(x, w, sync):
+    net.sync_gradients = sync
+    for p in net.parameters():
+        p.grad = None
+    bon, cor = net(x)
+    ((bon * w).sum() + cor.sum()).backward()
+    return torch.cat([p.grad.flatten() for p in net.parameters()])
+g_dp = grads(xs[rank:rank + 1], wb[rank:rank + 1], True)          # data parallel: own shard, all-reduce(mean) inside backward
+g0 = grads(xs[0:1], wb[0:1], False)
+g1 = grads(xs[1:2], wb[1:2], False)
+want = 0.5 * (g0 + g1)
+err = float((g_dp - want).norm() / want.norm())
+allr = [None] * world
+dist.all_gather_object(allr, err)
+if rank == 0:
+    print("DPERR %%.3e %%.3e status %%d" %% (allr[0], allr[1], net.hip_status(dev)))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_data_parallel_gradients(tmp_path):
+    """The exchange step of training end to end on the GPU: two ranks, each its own panorama; the gradient every
+    rank ends up with must be the mean of the two per-shard gradients.  (BatchNorm statistics stay per replica, as in the
+    reference's DataParallel; the running-stat updates of the extra local passes are irrelevant to the gradient.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29641", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("DPERR")][0]
+    print("[parity] data-parallel gradient vs mean of shard gradients:", line)
+    e0, e1 = float(line.split()[1]), float(line.split()[2])
+    assert e0 < 1e-5 and e1 < 1e-5 and line.endswith("status 0")
