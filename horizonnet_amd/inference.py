@@ -1,0 +1,134 @@
+"""Panorama -> room-layout corners: drop-in for reference ``inference.inference`` (``inference.py:65-141``).
+
+The network forward (and the test-time flip / rotate augmentation around it) runs on the device through the HIP engine,
+the corner-peak detection runs on the device (``hn_find_peaks``), the Manhattan fit (``postproc``) on the host as in the
+reference.  ``inference_batch`` is the MI355X-shaped entry: B panoramas x A augmentations go through ONE engine forward.
+"""
+import sys
+
+import numpy as np
+import torch
+
+from . import postproc
+from .peaks import find_N_peaks as _hip_find_N_peaks
+
+
+def augment(x_img, flip, rotate):
+    """[B,3,H,W] -> ([B*(1+flip+len(rotate)),3,H,W], tags).  Same stacking order and tags as inference.py:32-43;
+    works on the tensor where it lives (host or device) instead of a numpy round trip."""
+    tags = [""]
+    views = [x_img]
+    if flip:
+        tags.append("flip")
+        views.append(torch.flip(x_img, dims=[-1]))
+    for frac in rotate:
+        shift = int(round(frac * x_img.shape[-1]))
+        tags.append("rotate %d" % shift)
+        views.append(torch.roll(x_img, shift, dims=-1))
+    return torch.cat(views, 0).float(), tags
+
+
+def augment_undo(y, tags):
+    """Inverse of `augment` on a network output [len(tags)*B, C, W] -> numpy [len(tags), B, C, W] (inference.py:46-62)."""
+    sz = y.shape[0] // len(tags)
+    out = []
+    for i, tag in enumerate(tags):
+        part = y[i * sz:(i + 1) * sz]
+        if tag == "flip":
+            part = torch.flip(part, dims=[-1])
+        elif tag.startswith("rotate"):
+            part = torch.roll(part, -int(tag.split()[-1]), dims=-1)
+        elif tag != "":
+            raise NotImplementedError()
+        out.append(part)
+    return torch.stack(out, 0).cpu().numpy()
+
+
+def visualize_a_data(x, y_bon, y_cor):
+    """Raw-output strip (dataset.py:211-229): corner probability band, white rule, dimmed panorama with the two
+    boundaries in green."""
+    img = (x.cpu().numpy().transpose([1, 2, 0]) * 255).astype(np.uint8)
+    rows = ((np.asarray(y_bon) / np.pi + 0.5) * img.shape[0]).round().astype(int)
+    band = np.zeros((30, img.shape[1], 3), np.uint8)
+    band[:] = np.asarray(y_cor)[0][None, :, None] * 255
+    rule = np.zeros((3, img.shape[1], 3), np.uint8) + 255
+    dim = (img.copy() * 0.5).astype(np.uint8)
+    cols = np.arange(rows.shape[1])
+    dim[rows[0], cols, 1] = 255
+    dim[rows[1], cols, 1] = 255
+    return np.concatenate([band, rule, dim], 0)
+
+
+def layout_from_signals(y_bon, y_cor, H=512, W=1024, force_cuboid=False, force_raw=False, min_v=None, r=0.05,
+                        peaks_fn=None):
+    """The host half of inference.py:89-141.  y_bon [2,W] float32 latitudes in radians (ceiling, floor), y_cor [W]
+    float32 corner probability -> (cor_id [2N,2] float32 normalised (x,y), z0, z1)."""
+    if peaks_fn is None:
+        peaks_fn = _hip_find_N_peaks
+    y_bon = (y_bon / np.pi + 0.5) * H - 0.5
+    y_bon[0] = np.clip(y_bon[0], 1, H / 2 - 1)
+    y_bon[1] = np.clip(y_bon[1], H / 2 + 1, H - 2)
+
+    z0 = 50
+    _, z1 = postproc.refine_by_fix_z(y_bon[0], y_bon[1], z0)
+
+    if force_raw:
+        cor = np.stack([np.arange(1024), y_bon[0]], 1)
+    else:
+        if min_v is None:
+            min_v = 0 if force_cuboid else 0.05
+        r = int(round(W * r / 2))
+        N = 4 if force_cuboid else None
+        peaks = peaks_fn(y_cor, r=r, min_v=min_v, N=N)[0]
+        tol = abs(0.16 * z1 / 1.6)
+        cor, walls = postproc.gen_ww(peaks, y_bon[0], z0, tol=tol, force_cuboid=force_cuboid)
+        if not force_cuboid:
+            plan = np.zeros((len(walls), 2), np.float32)
+            for i in range(len(walls)):
+                plan[i, walls[i]["type"]] = walls[i]["val"]
+                plan[i, walls[i - 1]["type"]] = walls[i - 1]["val"]
+            if not postproc.polygon_is_simple(plan):
+                print("Fail to generate valid general layout!! Generate cuboid as fallback.", file=sys.stderr)
+                peaks = peaks_fn(y_cor, r=r, min_v=0, N=4)[0]
+                cor, walls = postproc.gen_ww(peaks, y_bon[0], z0, tol=tol, force_cuboid=True)
+
+    cor = np.hstack([cor, postproc.infer_coory(cor[:, 1], z1 - z0, z0)[:, None]])
+    cor_id = np.zeros((len(cor) * 2, 2), np.float32)
+    cor_id[0::2, 0] = cor[:, 0]
+    cor_id[0::2, 1] = cor[:, 1]
+    cor_id[1::2, 0] = cor[:, 0]
+    cor_id[1::2, 1] = cor[:, 2]
+    cor_id[:, 0] /= W
+    cor_id[:, 1] /= H
+    return cor_id, z0, z1
+
+
+def _forward_signals(net, x, device, flip, rotate):
+    """-> (x_aug, y_bon [B,2,W] radians, y_cor [B,1,W] probability) numpy, augmentations undone and averaged."""
+    B = x.shape[0]
+    x_aug, tags = augment(x.to(device), flip, rotate)
+    y_bon, y_cor = net(x_aug)
+    y_bon = augment_undo(y_bon, tags).mean(0)
+    y_cor = augment_undo(torch.sigmoid(y_cor), tags).mean(0)
+    assert y_bon.shape[0] == B
+    return x_aug, y_bon, y_cor
+
+
+def inference(net, x, device, flip=False, rotate=[], visualize=False,
+              force_cuboid=False, force_raw=False, min_v=None, r=0.05, peaks_fn=None):
+    """Same arguments and return value as the reference: x [1,3,512,1024] -> (cor_id, z0, z1, vis_out)."""
+    H, W = tuple(x.shape[2:])
+    x_aug, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
+    vis_out = visualize_a_data(x_aug[0], y_bon[0], y_cor[0]) if visualize else None
+    cor_id, z0, z1 = layout_from_signals(y_bon[0], y_cor[0, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn)
+    return cor_id, z0, z1, vis_out
+
+
+def inference_batch(net, x, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
+                    peaks_fn=None):
+    """x [B,3,512,1024]: one engine forward for all B x augmentations, then the host fit per panorama.
+    -> list of (cor_id, z0, z1)."""
+    H, W = tuple(x.shape[2:])
+    _, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
+    return [layout_from_signals(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn)
+            for b in range(x.shape[0])]

@@ -212,11 +212,111 @@ def gen_stretch_params():
     print("stretch_params: %d rooms written" % len(cors))
 
 
+def gen_postproc():
+    """misc/post_proc.py + inference.py:65-141 on synthetic Manhattan rooms (oracle/synth_rooms.py): per-function
+    outputs of the reference, and its whole ``inference()`` driven by a signal-decoding stand-in network."""
+    import inference as ref_inf                      # reference inference.py
+    from misc import post_proc as ref_pp             # reference misc/post_proc.py
+    from oracle import synth_rooms as sr
+    import contextlib, io
+    rng = np.random.RandomState(5)
+    out, meta = {}, []
+    H, W = 512, 1024
+    j = 0
+    for case in range(64):
+        n_corners = [4, 4, 6, 6, 8, 8, 10, 4][case % 8]
+        noise = [0.0, 0.3, 0.6, 1.2][(case // 8) % 4]
+        poly = sr.manhattan_polygon(rng, n_corners)
+        rows, cor, cols = sr.render(poly, rng.uniform(1.0, 1.6), rng.uniform(1.2, 1.7), noise, rng)
+        kind = "clean"
+        if case >= 32 and case % 3 == 0 and n_corners > 4:
+            cor = sr.drop_corner(cor, cols, rng.randint(len(cols))); kind = "dropped"
+        elif case >= 32 and case % 3 == 1:
+            cor = sr.add_corner(cor, rng.uniform(0, W)); kind = "spurious"
+        x = sr.encode_image(rows, cor)
+        rec = {"case": j, "n_corners": n_corners, "noise": noise, "kind": kind, "runs": []}
+        # -- per-function outputs on the signals exactly as inference.py:89-93 prepares them
+        y_bon = (sr.SignalNet()(x)[0][0].numpy() / np.pi + 0.5) * H - 0.5
+        y_bon[0] = np.clip(y_bon[0], 1, H / 2 - 1)
+        y_bon[1] = np.clip(y_bon[1], H / 2 + 1, H - 2)
+        y_cor = torch.sigmoid(sr.SignalNet()(x)[1])[0, 0].numpy()
+        refined, z1 = ref_pp.np_refine_by_fix_z(y_bon[0], y_bon[1], 50)
+        out["x_%d" % j] = x[0, :, 0, :].numpy()
+        out["ycor_%d" % j] = y_cor                   # y_bon is exactly-rounded elementwise arithmetic on x: tests recompute it
+        out["refined_%d" % j] = refined[::8]
+        out["z1_%d" % j] = np.float64(z1)
+        out["coory_%d" % j] = ref_pp.infer_coory(y_bon[0], z1 - 50, 50)[::8]
+        tol = abs(0.16 * z1 / 1.6)
+        for cub in (True, False):
+            tag = "cub" if cub else "gen"
+            pk = ref_inf.find_N_peaks(y_cor, r=int(round(W * 0.05 / 2)), min_v=0 if cub else 0.05, N=4 if cub else None)[0]
+            out["pk_%s_%d" % (tag, j)] = pk
+            try:
+                c, walls = ref_pp.gen_ww(pk, y_bon[0], 50, tol=tol, force_cuboid=cub)
+                out["ww_%s_%d" % (tag, j)] = c
+                out["wtype_%s_%d" % (tag, j)] = np.array([w["type"] for w in walls], np.int64)
+                out["wval_%s_%d" % (tag, j)] = np.array([w["val"] for w in walls], np.float64)
+                out["wscore_%s_%d" % (tag, j)] = np.array([w["score"] for w in walls], np.float64)
+                rec["actions_" + tag] = [w.get("action", "") for w in walls]
+            except AssertionError:
+                rec["actions_" + tag] = "AssertionError"
+        # -- the whole reference inference() with the decoding stand-in network
+        runs = [dict(force_cuboid=False), dict(force_cuboid=True), dict(force_raw=True),
+                dict(force_cuboid=False, flip=True, rotate=[0.25, -0.1]), dict(force_cuboid=False, min_v=0.3, r=0.1)]
+        for k, kw in enumerate(runs):
+            err = io.StringIO()
+            try:
+                with contextlib.redirect_stderr(err):
+                    cor_id, z0, z1r, _ = ref_inf.inference(sr.SignalNet(), x, "cpu", **kw)
+                out["inf%d_%d" % (k, j)] = cor_id
+                out["infz1_%d_%d" % (k, j)] = np.float64(z1r)
+                rec["runs"].append({"kw": kw, "ok": True, "fallback": "fallback" in err.getvalue()})
+            except AssertionError:
+                rec["runs"].append({"kw": kw, "ok": False})
+        meta.append(rec)
+        j += 1
+    # -- hard cases: strong noise, missed and spurious corners; general layout only (exercises the cuboid fallback)
+    rng = np.random.RandomState(11)
+    for case in range(96):
+        poly = sr.manhattan_polygon(rng, [6, 8, 10, 12][case % 4])
+        rows, cor, cols = sr.render(poly, 1.2, 1.5, rng.choice([0.5, 1.5, 3.0]), rng)
+        for _ in range(rng.randint(0, 3)):
+            cor = sr.drop_corner(cor, cols, rng.randint(len(cols)))
+        for _ in range(rng.randint(0, 3)):
+            cor = sr.add_corner(cor, rng.uniform(0, W))
+        x = sr.encode_image(rows, cor)
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            cor_id, z0, z1r, _ = ref_inf.inference(sr.SignalNet(), x, "cpu", force_cuboid=False)
+        fallback = "fallback" in err.getvalue()
+        if not fallback and case % 3:
+            continue                                 # keep every fallback and a third of the rest
+        out["x_%d" % j] = x[0, :, 0, :].numpy()
+        out["ycor_%d" % j] = torch.sigmoid(sr.SignalNet()(x)[1])[0, 0].numpy()
+        out["inf0_%d" % j] = cor_id
+        out["infz1_0_%d" % j] = np.float64(z1r)
+        meta.append({"case": j, "kind": "hard", "runs": [{"kw": {"force_cuboid": False}, "ok": True, "fallback": fallback}]})
+        j += 1
+    np.savez_compressed(os.path.join(GOLD, "postproc.npz"), **out)
+    with open(os.path.join(GOLD, "postproc.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    acts = {}
+    for m in meta:
+        a = m.get("actions_gen", [])
+        for t in ([a] if isinstance(a, str) else a):
+            acts[t] = acts.get(t, 0) + 1
+    print("postproc: %d rooms; general-layout wall actions %s; fallbacks %d; failed runs %d" % (
+        len(meta), acts, sum(r.get("fallback", False) for m in meta for r in m["runs"]),
+        sum(not r["ok"] for m in meta for r in m["runs"])))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from oracle.hostinfo import usable_cores
     torch.set_num_threads(usable_cores())
-    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch"]
+    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc"]
+    if "postproc" in which:
+        gen_postproc()
     if "stretch" in which:
         gen_stretch_params()
     if "panostretch" in which:

@@ -390,3 +390,46 @@ def test_find_peaks_batch_sigmoid():
     for b in range(6):
         want = peaks_ref.find_N_peaks(p[b], 26, 0.05, None)[0]      # exact on the device's own f32 probabilities
         assert np.array_equal(np.where(mask[b].cpu().numpy())[0], want)
+
+
+# ---- layout inference end to end (inference.py:65-141) -------------------------------------------
+def test_inference_signalnet_on_device_matches_reference(golden_dir):
+    """inference() with the forward on the GPU and the corner peaks from hn_find_peaks == the reference's inference()
+    (fixtures from the unmodified reference; the stand-in network decodes the signals from the image)."""
+    import json
+    from horizonnet_amd.inference import inference
+    from oracle import synth_rooms as sr
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "postproc.json")))
+    worst, n_runs = 0.0, 0
+    for m in meta[::3]:
+        j = m["case"]
+        x = torch.from_numpy(np.broadcast_to(g["x_%d" % j][:, None, :], (3, 512, 1024)).copy())[None]
+        for k, run in enumerate(m["runs"]):
+            cor_id, z0, z1, _ = inference(sr.SignalNet(), x, DEV, **run["kw"])
+            want = g["inf%d_%d" % (k, j)]
+            assert cor_id.shape == want.shape, (j, run)
+            worst = max(worst, float(np.abs(cor_id - want).max()))
+            assert abs(z1 - float(g["infz1_%d_%d" % (k, j)])) < 1e-9
+            n_runs += 1
+    print("[parity] inference() on device, %d runs: max-abs corner difference %.3e (normalised coords)" % (n_runs, worst))
+    assert worst < 1e-6      # GPU log/sigmoid may differ from the CPU's by an ulp; the layout decisions must not
+
+
+def test_inference_engine_raw_layout(golden_dir):
+    """The real engine inside inference(): force_raw output (no Manhattan fit, defined for any signal) with flip +
+    rotate test-time augmentation against the same function on the reference's golden outputs."""
+    from horizonnet_amd.inference import inference, layout_from_signals
+    g = np.load(os.path.join(golden_dir, "forward_demo_seed0_bnrandom.npz"))
+    net = _net(int(g["seed"]), str(g["bn"]))
+    x = _demo_x(golden_dir)
+    with torch.no_grad():
+        cor_id, z0, z1, _ = inference(net, x, DEV, force_raw=True)
+    want, _, z1w = layout_from_signals(g["bon"][0].copy(), torch.sigmoid(torch.from_numpy(g["cor"][0, 0])).numpy(),
+                                       force_raw=True)
+    assert cor_id.shape == (2048, 2)
+    assert report("inference force_raw rows (px)", cor_id[:, 1] * 512, want[:, 1] * 512, 0.2)
+    assert abs(z1 - z1w) < 0.05 * abs(z1w)
+    with torch.no_grad():
+        aug = inference(net, x, DEV, flip=True, rotate=[0.25], force_raw=True)[0]
+    assert aug.shape == (2048, 2) and np.isfinite(aug).all()
