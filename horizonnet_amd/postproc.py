@@ -256,3 +256,12 @@ def polygon_is_simple(xy):
     gap = (idx[None, :] - idx[:, None]) % n
     far = (gap >= 2) & (gap <= n - 2)
     return not bool((meet & far).any())
+
+
+# ---- the reference's names (misc/post_proc.py), so `from horizonnet_amd import postproc as post_proc` is a drop-in ----
+np_coorx2u, np_coory2v = col_to_u, row_to_v
+np_coor2xy, np_xy2coor = pano_to_plan, plan_to_pano
+np_x_u_solve_y, np_y_u_solve_x = y_where_ray_meets_x, x_where_ray_meets_y
+mean_percentile = interquartile_mean
+np_refine_by_fix_z = refine_by_fix_z
+get_gpid = wall_groups
