@@ -1,0 +1,163 @@
+// Training-input pipeline for gfx950: one fused gather per batch replaces, per image, reference dataset.py:52
+// (uint8 HWC -> float32 / 255), :82 (Pano-Stretch = 3 x scipy map_coordinates), :88-89 (flip), :95-96 (horizontal
+// roll), :100-104 (gamma) and :123 (HWC -> CHW).  The dataset lives in HBM as uint8 HWC; the output is the float32
+// NCHW batch hn_forward / hn_train_forward consume.
+//
+// HBM-bound: 1,572,864 B read + 6,291,456 B written = 7,864,320 algorithmic bytes per 512x1024x3 image.
+// Index maps compose exactly: out[c][y][x] = stretched[y][xs][c], xs = flip ? W-1-xr : xr, xr = (x - dx) mod W.
+// Stretch coordinates are float64 in the reference's operation order (see panostretch.hip); the bilinear blend is
+// SciPy's (double accumulate, one rounding to f32).  Gamma: numpy computes float32 ** float32(p) with glibc powf;
+// here pow() runs in float64 on the f32 operands and is rounded once to f32 (<= 1 ulp from glibc, tested).
+#include "hn_common.h"
+
+namespace {
+
+constexpr int AG_ROWS = 8;
+constexpr int AG_MAXB = 64;
+
+struct AugParams {
+    double kx[AG_MAXB];
+    double ky[AG_MAXB];
+    float gamma[AG_MAXB];       // already rounded to f32 (numpy: python-float exponent joins a float32 array as float32)
+    int index[AG_MAXB];         // which dataset image
+    int roll[AG_MAXB];
+    unsigned char flip[AG_MAXB];
+    unsigned char stretch[AG_MAXB];
+    unsigned char use_gamma[AG_MAXB];
+};
+
+__device__ __forceinline__ double wrap_legacy(double c, double sz)
+{
+    if (c < 0.0) c += sz * (double)((long long)(-c / sz) + 1);
+    else if (c > sz) c -= sz * (double)((long long)(c / sz));
+    return c;
+}
+
+__global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __restrict__ data, float* __restrict__ dst,
+                                                      AugParams p, int H, int W)
+{
+#pragma clang fp contract(off)
+    __shared__ double tan_v[AG_ROWS];
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * AG_ROWS;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const double PI = 3.141592653589793;
+    if (threadIdx.x < AG_ROWS) {
+        const int y = y0 + threadIdx.x < H ? y0 + threadIdx.x : H - 1;
+        tan_v[threadIdx.x] = tan((((double)y + 0.5) / (double)H - 0.5) * PI);
+    }
+    __syncthreads();
+    if (x >= W) return;
+
+    int xs = x - p.roll[b];                       // roll normalised to [0, W) by the launcher
+    xs = xs < 0 ? xs + W : xs;
+    if (p.flip[b]) xs = W - 1 - xs;
+
+    const unsigned char* img = data + (size_t)p.index[b] * H * W * 3;
+    float* out = dst + (size_t)b * 3 * H * W;
+    const bool gam = p.use_gamma[b] != 0;
+    const double ge = (double)p.gamma[b];
+
+    if (!p.stretch[b]) {
+        for (int r = 0; r < AG_ROWS && y0 + r < H; ++r) {
+            const unsigned char* q = img + ((size_t)(y0 + r) * W + xs) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = (float)q[c] / 255.0f;
+                if (gam) v = (float)pow((double)v, ge);
+                out[((size_t)c * H + (y0 + r)) * W + x] = v;
+            }
+        }
+        return;
+    }
+
+    const double kx = p.kx[b], ky = p.ky[b];
+    const double u = (((double)xs + 0.5) / (double)W - 0.5) * 2 * PI;
+    const double sin_u = sin(u), cos_u = cos(u);
+    const double u0 = atan2(sin_u * kx / ky, cos_u);
+    const double sin_u0 = sin(u0);
+    const double refx = (u0 / (2 * PI) + 0.5) * (double)W - 0.5;
+    const double cx = wrap_legacy(refx, (double)(W - 1));
+    const double fx = floor(cx);
+    int x0 = (int)fx;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0);
+    const int x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+    const double wx1 = cx - fx, wx0 = 1.0 - wx1;
+
+    int ra0[AG_ROWS], ra1[AG_ROWS];
+    double wy[AG_ROWS];
+#pragma unroll
+    for (int r = 0; r < AG_ROWS; ++r) {
+        const double v0 = atan(tan_v[r] * sin_u0 / sin_u * ky);
+        const double refy = (v0 / PI + 0.5) * (double)H - 0.5;
+        const double cy = wrap_legacy(refy, (double)(H - 1));
+        const double fy = floor(cy);
+        int yy0 = (int)fy;
+        yy0 = yy0 < 0 ? 0 : (yy0 > H - 1 ? H - 1 : yy0);
+        const int yy1 = yy0 + 1 < H ? yy0 + 1 : H - 1;
+        ra0[r] = yy0 * W;
+        ra1[r] = yy1 * W;
+        wy[r] = cy - fy;
+    }
+    float p00[AG_ROWS][3], p01[AG_ROWS][3], p10[AG_ROWS][3], p11[AG_ROWS][3];
+#pragma unroll
+    for (int r = 0; r < AG_ROWS; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            p00[r][c] = (float)img[(size_t)(ra0[r] + x0) * 3 + c] / 255.0f;
+            p01[r][c] = (float)img[(size_t)(ra0[r] + x1) * 3 + c] / 255.0f;
+            p10[r][c] = (float)img[(size_t)(ra1[r] + x0) * 3 + c] / 255.0f;
+            p11[r][c] = (float)img[(size_t)(ra1[r] + x1) * 3 + c] / 255.0f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < AG_ROWS; ++r) {
+        if (y0 + r >= H) break;
+        const double wy1 = wy[r], wy0 = 1.0 - wy1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = 0.0;
+            t += (double)p00[r][c] * wy0 * wx0;
+            t += (double)p01[r][c] * wy0 * wx1;
+            t += (double)p10[r][c] * wy1 * wx0;
+            t += (double)p11[r][c] * wy1 * wx1;
+            float v = (float)t;
+            if (gam) v = (float)pow((double)v, ge);
+            out[((size_t)c * H + (y0 + r)) * W + x] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hn_augment_batch(const unsigned char* data, int n_images, const int* index, float* dst,
+                                const double* kx, const double* ky, const int* flip, const int* roll,
+                                const double* gamma, int B, int H, int W, void* stream)
+{
+    if (B == 0) return 0;
+    HN_REQUIRE(data && index && dst, "augment_batch: null pointer");
+    HN_REQUIRE(B > 0 && H >= 2 && W >= 2 && n_images > 0, "augment_batch: bad shape B=%d H=%d W=%d N=%d", B, H, W, n_images);
+    hipStream_t s = (hipStream_t)stream;
+    for (int b0 = 0; b0 < B; b0 += AG_MAXB) {
+        const int nb = (B - b0) < AG_MAXB ? (B - b0) : AG_MAXB;
+        AugParams p = {};
+        for (int i = 0; i < nb; ++i) {
+            const int j = b0 + i;
+            HN_REQUIRE(index[j] >= 0 && index[j] < n_images, "augment_batch: index[%d]=%d outside the dataset (%d images)", j, index[j], n_images);
+            p.index[i] = index[j];
+            p.kx[i] = kx ? kx[j] : 1.0;
+            p.ky[i] = ky ? ky[j] : 1.0;
+            HN_REQUIRE(p.kx[i] > 0.0 && p.ky[i] > 0.0, "augment_batch: kx, ky must be positive");
+            p.stretch[i] = (kx && ky && !(kx[j] == 1.0 && ky[j] == 1.0)) ? 1 : 0;   // (1, 1) = stretch disabled: exact copy
+            p.flip[i] = (flip && flip[j]) ? 1 : 0;
+            p.roll[i] = roll ? ((roll[j] % W) + W) % W : 0;
+            p.use_gamma[i] = (gamma && gamma[j] != 1.0) ? 1 : 0;
+            p.gamma[i] = gamma ? (float)gamma[j] : 1.0f;
+            HN_REQUIRE(!(p.gamma[i] <= 0.0f), "augment_batch: gamma must be positive");
+        }
+        dim3 grid((W + 255) / 256, (H + AG_ROWS - 1) / AG_ROWS, nb);
+        hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, s, data, dst + (size_t)b0 * 3 * H * W, p, H, W);
+        HN_LAUNCH_CHECK();
+    }
+    return 0;
+}

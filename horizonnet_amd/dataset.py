@@ -1,0 +1,175 @@
+"""Training data pipeline -- drop-in for reference ``dataset.PanoCorBonDataset`` (``dataset.py:12-134``) with the
+image half on the MI355X.
+
+* ``PanoCorBonDataset``: same constructor, same on-disk layout (``root/img/*.png|jpg``, ``root/label_cor/*.txt``), same
+  per-sample return value, same ``np.random`` draw order -- for code that indexes samples one by one.
+* ``DeviceBatcher``: the MI355X-shaped path.  The decoded dataset sits in HBM as uint8 (1.5 MB per panorama; a
+  20k-panorama training set is 31 GB of the 288 GB); a training batch is ONE fused launch (``hn_augment_batch``:
+  /255, Pano-Stretch, flip, roll, gamma, HWC->CHW) straight into the float32 NCHW tensor the engine consumes.  The
+  labels (<= ~30 corners and two 1024-long vectors per sample) are rasterised on the host (``labels.py``).
+
+The augmentation parameters are drawn by ``draw_augmentation`` in the reference's order (stretch: uniform, uniform,
+randint, randint; flip: randint; rotate: randint; gamma: uniform, randint), so a seeded run reproduces the reference's
+samples.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .augment import sample_stretch
+from .labels import cor_2_1d, corner_probability, find_occlusion, flip_labels, roll_labels
+from .panostretch import _stretch_corners
+
+
+def read_label(path, W=1024):
+    """label_cor text -> (cor [2N,2] float32 starting at the smallest column, occlusion flags [2N])
+    (dataset.py:56-67)."""
+    with open(path) as f:
+        cor = np.array([line.strip().split() for line in f if line.strip()], np.float32)
+    cor = np.roll(cor[:, :2], -2 * np.argmin(cor[::2, 0]), 0)
+    occlusion = find_occlusion(cor[::2].copy()).repeat(2)
+    assert (np.abs(cor[0::2, 0] - cor[1::2, 0]) > W / 100).sum() == 0, path
+    assert (cor[0::2, 1] > cor[1::2, 1]).sum() == 0, path
+    return cor, occlusion
+
+
+def draw_augmentation(cor, W, flip, rotate, gamma, stretch, max_stretch=2.0, rng=np.random):
+    """One sample's augmentation parameters, consuming random numbers exactly like dataset.py:70-104."""
+    a = {"kx": 1.0, "ky": 1.0, "flip": 0, "rotate": False, "roll": 0, "gamma": 1.0}
+    if stretch:
+        a["kx"], a["ky"] = sample_stretch(cor, max_stretch, rng)
+    if flip and rng.randint(2) == 0:
+        a["flip"] = 1
+    if rotate:
+        a["rotate"], a["roll"] = True, int(rng.randint(W))
+    if gamma:
+        p = rng.uniform(1, 2)
+        if rng.randint(2) == 0:
+            p = 1 / p
+        a["gamma"] = p
+    return a
+
+
+def make_labels(cor, occlusion, aug, H, W, p_base=0.96):
+    """Corner list + augmentation -> (bon [2,W] float64, y_cor [1,W] float64, augmented cor) (dataset.py:82-120)."""
+    if not (aug["kx"] == 1.0 and aug["ky"] == 1.0):
+        cor = _stretch_corners(cor, aug["kx"], aug["ky"], W, H)
+    bon = cor_2_1d(cor, H, W)
+    if aug["flip"]:
+        bon, cor = flip_labels(bon, cor, W)
+    if aug["rotate"]:                      # also for dx = 0: the modulo wraps columns a stretch pushed below 0
+        bon, cor = roll_labels(bon, cor, aug["roll"], W)
+    return bon, corner_probability(cor[~occlusion, 0], W, p_base), cor
+
+
+def augment_images(data, index, augs, out=None):
+    """data: cuda uint8 [N,H,W,3]; index: B ints; augs: B dicts from `draw_augmentation` -> cuda float32 [B,3,H,W]."""
+    if not (isinstance(data, torch.Tensor) and data.is_cuda and data.dtype == torch.uint8 and data.dim() == 4
+            and data.shape[3] == 3):
+        raise RuntimeError("augment_images needs a cuda/ROCm uint8 [N,H,W,3] tensor (no CPU fallback)")
+    data = data.contiguous()
+    N, H, W, _ = (int(v) for v in data.shape)
+    B = len(index)
+    if out is None:
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=data.device)
+    idx = np.ascontiguousarray(index, dtype=np.int32)
+    kx = np.array([a["kx"] for a in augs], np.float64)
+    ky = np.array([a["ky"] for a in augs], np.float64)
+    flip = np.array([a["flip"] for a in augs], np.int32)
+    roll = np.array([a["roll"] for a in augs], np.int32)
+    gam = np.array([a["gamma"] for a in augs], np.float64)
+    ip, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
+    lib = _lib.load()
+    with torch.cuda.device(data.device):
+        _lib.check(lib.hn_augment_batch(_lib.ptr(data), N, idx.ctypes.data_as(ip), _lib.ptr(out),
+                                        kx.ctypes.data_as(dp), ky.ctypes.data_as(dp), flip.ctypes.data_as(ip),
+                                        roll.ctypes.data_as(ip), gam.ctypes.data_as(dp), B, H, W,
+                                        _lib.stream_ptr(data.device)), "hn_augment_batch")
+    return out
+
+
+def _list_samples(root_dir):
+    img_dir, cor_dir = os.path.join(root_dir, "img"), os.path.join(root_dir, "label_cor")
+    names = sorted(f for f in os.listdir(img_dir) if f.endswith(".jpg") or f.endswith(".png"))
+    labels = ["%s.txt" % f[:-4] for f in names]
+    for f in labels:
+        assert os.path.isfile(os.path.join(cor_dir, f)), "%s not found" % os.path.join(cor_dir, f)
+    return img_dir, cor_dir, names, labels
+
+
+def _decode(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(path))[..., :3])
+
+
+class PanoCorBonDataset(torch.utils.data.Dataset):
+    """Per-sample interface of the reference (dataset.py:12-134): returns [x (3,H,W), bon (2,W), y_cor (1,W)] float
+    CPU tensors (+ cor, + path on request).  The image goes through the same fused HIP kernel as the batched path."""
+
+    def __init__(self, root_dir, flip=False, rotate=False, gamma=False, stretch=False, p_base=0.96, max_stretch=2.0,
+                 normcor=False, return_cor=False, return_path=False, device="cuda"):
+        self.img_dir, self.cor_dir, self.img_fnames, self.txt_fnames = _list_samples(root_dir)
+        self.flip, self.rotate, self.gamma, self.stretch = flip, rotate, gamma, stretch
+        self.p_base, self.max_stretch = p_base, max_stretch
+        self.normcor, self.return_cor, self.return_path = normcor, return_cor, return_path
+        self.device = device
+
+    def __len__(self):
+        return len(self.img_fnames)
+
+    def __getitem__(self, idx):
+        img_path = os.path.join(self.img_dir, self.img_fnames[idx])
+        img = _decode(img_path)
+        H, W = img.shape[:2]
+        cor, occlusion = read_label(os.path.join(self.cor_dir, self.txt_fnames[idx]), W)
+        aug = draw_augmentation(cor, W, self.flip, self.rotate, self.gamma, self.stretch, self.max_stretch)
+        bon, y_cor, cor = make_labels(cor, occlusion, aug, H, W, self.p_base)
+        x = augment_images(torch.from_numpy(img)[None].to(self.device), [0], [aug])[0].cpu()
+        out = [x, torch.FloatTensor(bon.copy()), torch.FloatTensor(y_cor.copy())]
+        if self.return_cor:
+            out.append(cor)
+        if self.return_path:
+            out.append(img_path)
+        return out
+
+
+class DeviceBatcher:
+    """The whole dataset decoded once into HBM (uint8), labels parsed once on the host; `batch(indices)` returns the
+    augmented training batch on the device: (x [B,3,H,W], bon [B,2,W], y_cor [B,1,W]) float32."""
+
+    def __init__(self, root_dir=None, images=None, corners=None, device="cuda", flip=False, rotate=False, gamma=False,
+                 stretch=False, p_base=0.96, max_stretch=2.0):
+        if root_dir is not None:
+            img_dir, cor_dir, names, labels = _list_samples(root_dir)
+            images = np.stack([_decode(os.path.join(img_dir, n)) for n in names])
+            parsed = [read_label(os.path.join(cor_dir, t), images.shape[2]) for t in labels]
+        else:
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+            parsed = [(np.asarray(c, np.float32), find_occlusion(np.asarray(c, np.float32)[::2].copy()).repeat(2))
+                      for c in corners]
+        self.data = torch.from_numpy(images).to(device)
+        self.labels = parsed
+        self.flip, self.rotate, self.gamma, self.stretch = flip, rotate, gamma, stretch
+        self.p_base, self.max_stretch = p_base, max_stretch
+        self.H, self.W = int(images.shape[1]), int(images.shape[2])
+
+    def __len__(self):
+        return len(self.labels)
+
+    def batch(self, indices, rng=np.random):
+        augs, bons, cors = [], [], []
+        for i in indices:
+            cor, occ = self.labels[i]
+            a = draw_augmentation(cor, self.W, self.flip, self.rotate, self.gamma, self.stretch, self.max_stretch, rng)
+            bon, y_cor, _ = make_labels(cor, occ, a, self.H, self.W, self.p_base)
+            augs.append(a)
+            bons.append(bon)
+            cors.append(y_cor)
+        x = augment_images(self.data, list(indices), augs)
+        dev = self.data.device
+        bon = torch.from_numpy(np.stack(bons).astype(np.float32)).to(dev, non_blocking=True)
+        y_cor = torch.from_numpy(np.stack(cors).astype(np.float32)).to(dev, non_blocking=True)
+        return x, bon, y_cor

@@ -134,6 +134,21 @@ int64_t hn_grad_offset(const char* name);
 int hn_pano_stretch(const float* src, float* dst, const double* kx, const double* ky,
                     int B, int H, int W, int C, void* stream);
 
+/* ---- training-input pipeline: dataset.py:52,82,88-89,95-96,100-104,123 ---------------- */
+
+/* One fused gather for a batch of B training inputs.  data: the dataset resident in HBM,
+ * [n_images][H][W][3] uint8 (decoded RGB, HWC); index[b] picks the source image.  Per sample
+ * (all HOST arrays of B entries, any may be NULL = augmentation off): kx, ky = Pano-Stretch
+ * factors (dataset.py:70-82; the pair (1, 1) means "no stretch" and copies exactly); flip != 0
+ * mirrors the columns (dataset.py:88); roll = dx of np.roll(img, dx, axis=1) (dataset.py:95);
+ * gamma = exponent p of img ** p (dataset.py:100-104; float32 pow, <= 1 ulp from glibc's).
+ * dst: [B][3][H][W] float32 in [0,1] -- what dataset.py:123 returns per sample, stacked; the
+ * layout hn_forward / hn_train_forward consume.  Order of operations = the reference's:
+ * /255 -> stretch -> flip -> roll -> gamma -> CHW. */
+int hn_augment_batch(const unsigned char* data, int n_images, const int* index, float* dst,
+                     const double* kx, const double* ky, const int* flip, const int* roll,
+                     const double* gamma, int B, int H, int W, void* stream);
+
 /* ---- corner-index extraction: inference.py:21-29 + :80 ------------------------------ */
 
 /* For each of B signals of length n (float32): optional sigmoid (apply_sigmoid != 0, as

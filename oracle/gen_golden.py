@@ -310,11 +310,85 @@ def gen_postproc():
         sum(not r["ok"] for m in meta for r in m["runs"])))
 
 
+DATASET_CONFIGS = [dict(flip=True, rotate=True, gamma=True, stretch=True), dict(),
+                   dict(stretch=True), dict(gamma=True), dict(flip=True, rotate=True)]
+
+
+def gen_dataset():
+    """dataset.py:12-134 (PanoCorBonDataset.__getitem__) on a tiny synthetic dataset in the reference's on-disk format
+    (committed under tests/golden/synth_ds), plus eval_general.layout_2_depth / eval_cuboid.eval_3diou on its rooms."""
+    import shutil
+    import dataset as ref_ds                         # reference dataset.py
+    import eval_general as ref_eg
+    import eval_cuboid as ref_ec
+    from scipy.spatial.distance import cdist as _cdist
+    from oracle import synth_rooms as sr, dataset_ref
+    from horizonnet_amd import dataset as my_ds      # host-only helpers (label parsing, draw order)
+    from PIL import Image
+    # dataset.py:109-117 passes p=1 to cdist's default euclidean metric, which SciPy >= 1.9 rejects; on 1-D points the
+    # euclidean and the intended Minkowski-1 distance are the same number, so drop the argument (environment shim)
+    ref_ds.cdist = lambda a, b, p=None: _cdist(a, b)
+    root = os.path.join(GOLD, "synth_ds")
+    shutil.rmtree(root, ignore_errors=True)
+    sr.write_dataset(root, 4, seed=4, visible_only=False, noise=0.6)
+    out, meta = {}, []
+    for ci, cfg in enumerate(DATASET_CONFIGS):
+        ds = ref_ds.PanoCorBonDataset(root, return_cor=True, **cfg)
+        for i in range(len(ds)):
+            for rep in range(2 if ci == 0 else 1):
+                seed = 1000 * ci + 10 * i + rep
+                np.random.seed(seed)
+                x, bon, y_cor, cor = ds[i]
+                key = "c%d_i%d_r%d" % (ci, i, rep)
+                # pin the oracle's image pipeline (the GPU tests' checker) on the same draws
+                np.random.seed(seed)
+                c0, _ = my_ds.read_label(os.path.join(root, "label_cor", ds.txt_fnames[i]))
+                full = dict(flip=False, rotate=False, gamma=False, stretch=False)
+                full.update(cfg)
+                a = my_ds.draw_augmentation(c0, 1024, full["flip"], full["rotate"], full["gamma"], full["stretch"])
+                src = np.array(Image.open(os.path.join(root, "img", ds.img_fnames[i])))
+                mine = dataset_ref.augment_image(src, a["kx"], a["ky"], a["flip"], a["roll"] if a["rotate"] else None, a["gamma"])
+                assert np.array_equal(mine, x.numpy()), "oracle image pipeline differs from the reference: " + key
+                out["x_" + key] = x.numpy()[:, 3::16, 5::16].copy()
+                out["xsum_" + key] = np.float64(x.numpy().astype(np.float64).sum())
+                out["bon_" + key] = bon.numpy()
+                out["ycor_" + key] = y_cor.numpy()
+                out["cor_" + key] = np.asarray(cor)
+                meta.append({"key": key, "cfg": cfg, "index": i, "seed": seed})
+    # metrics: depth maps of the ground-truth layouts and 3D IoU between jittered cuboids (Qhull reference)
+    rng = np.random.RandomState(9)
+    for i in range(4):
+        cor = np.loadtxt(os.path.join(root, "label_cor", "room_%05d.txt" % i)).astype(np.float32)
+        cor = np.roll(cor, -2 * np.argmin(cor[::2, 0]), 0)
+        try:
+            out["depth_%d" % i] = ref_eg.layout_2_depth(cor, 512, 1024)[::8, ::8].copy()
+        except AssertionError:
+            pass
+    ious = []
+    for k in range(24):
+        polys = []
+        base = sr.manhattan_polygon(rng, 4)
+        for _ in range(2):
+            q = base * rng.uniform(0.8, 1.25, (1, 2)) + rng.uniform(-0.3, 0.3, (1, 2))
+            polys.append(sr.room_corners(q, rng.uniform(1.0, 1.6), 1.6).astype(np.float64))
+        a, b = polys
+        iou = ref_ec.eval_3diou(a[1::2], a[0::2], b[1::2], b[0::2])
+        out["pair_a_%d" % k], out["pair_b_%d" % k] = a, b
+        ious.append(iou)
+    out["pair_iou3d"] = np.array(ious, np.float64)
+    np.savez_compressed(os.path.join(GOLD, "dataset.npz"), **out)
+    with open(os.path.join(GOLD, "dataset.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    print("dataset: %d samples written; cuboid-pair 3D IoU range %.1f..%.1f %%" % (len(meta), min(ious), max(ious)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from oracle.hostinfo import usable_cores
     torch.set_num_threads(usable_cores())
-    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc"]
+    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc", "dataset"]
+    if "dataset" in which:
+        gen_dataset()
     if "postproc" in which:
         gen_postproc()
     if "stretch" in which:

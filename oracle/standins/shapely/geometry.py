@@ -1,8 +1,9 @@
 """Stand-in for the two shapely names the reference imports (inference.py:10, dataset.py:9, eval_general.py).
 
-TEST INFRASTRUCTURE ONLY.  shapely is not installed offline.  ``Polygon(...).is_valid`` -- the only shapely call on the
-inference path (reference inference.py:120, "for fear self-intersection") -- is restated for a single closed ring:
-valid iff the ring has a non-zero area and no two non-adjacent edges share a point.  Everything else raises.
+TEST INFRASTRUCTURE ONLY.  shapely is not installed offline.  Two calls are restated (parity unpinned against shapely
+itself): ``Polygon(...).is_valid`` (inference.py:120, "for fear self-intersection") for a single closed ring -- valid
+iff the ring has a non-zero area and no two non-adjacent edges share a point; and ``LineString.intersects``
+(dataset.py:172-186, corner occlusion) -- two polylines share at least one point.  Everything else raises.
 """
 import numpy as np
 
@@ -52,6 +53,19 @@ class Polygon:
         raise NotImplementedError("shapely stand-in: Polygon.%s is out of scope" % name)
 
 
-class LineString:  # import-only stub
-    def __init__(self, *a, **k):
-        raise NotImplementedError("shapely stand-in: LineString is out of scope")
+class LineString:
+    """Open polyline; only ``intersects`` (dataset.py:172-186, occlusion test) is provided."""
+
+    def __init__(self, coords):
+        self._pts = np.asarray(coords, np.float64).reshape(-1, 2)
+
+    def intersects(self, other):
+        a, b = self._pts, other._pts
+        for i in range(len(a) - 1):
+            for j in range(len(b) - 1):
+                if _segments_meet(a[i], a[i + 1], b[j], b[j + 1]):
+                    return True
+        return False
+
+    def __getattr__(self, name):
+        raise NotImplementedError("shapely stand-in: LineString.%s is out of scope" % name)

@@ -33,11 +33,12 @@ def manhattan_polygon(rng, n_corners):
     return np.array(out, np.float64)
 
 
-def render(poly, z_ceil=1.2, z_floor=1.5, noise=0.0, rng=None):
-    """-> (bon [2,1024] rows of ceiling / floor boundary, cor [1024] corner probability, corner columns)."""
+def cast(poly):
+    """Per image column: horizontal distance to the first wall hit and the index of that wall (edge i -> i+1)."""
     u = ((np.arange(W) + 0.5) / W - 0.5) * 2 * np.pi
     d = np.stack([np.sin(u), -np.cos(u)], 1)                       # ray directions on the floor plan
     dist = np.full(W, np.inf)
+    wall = np.zeros(W, np.int64)
     n = len(poly)
     for i in range(n):
         a, b = poly[i], poly[(i + 1) % n]
@@ -46,8 +47,15 @@ def render(poly, z_ceil=1.2, z_floor=1.5, noise=0.0, rng=None):
         with np.errstate(divide="ignore", invalid="ignore"):
             t = (a[0] * e[1] - a[1] * e[0]) / den                  # ray parameter
             s = (a[0] * d[:, 1] - a[1] * d[:, 0]) / den            # edge parameter
-        ok = (np.abs(den) > 1e-12) & (t > 0) & (s >= -1e-9) & (s <= 1 + 1e-9)
-        dist = np.where(ok & (t < dist), t, dist)
+        ok = (np.abs(den) > 1e-12) & (t > 0) & (s >= -1e-9) & (s <= 1 + 1e-9) & (t < dist)
+        dist = np.where(ok, t, dist)
+        wall = np.where(ok, i, wall)
+    return dist, wall
+
+
+def render(poly, z_ceil=1.2, z_floor=1.5, noise=0.0, rng=None):
+    """-> (bon [2,1024] rows of ceiling / floor boundary, cor [1024] corner probability, corner columns)."""
+    dist, _ = cast(poly)
     v_c = np.arctan2(z_ceil, dist)
     v_f = np.arctan2(-z_floor, dist)
     bon = np.stack([(-v_c / np.pi + 0.5) * H - 0.5, (-v_f / np.pi + 0.5) * H - 0.5])
@@ -101,3 +109,75 @@ class SignalNet:
         bon = (x[:, :2, 0, :] - 0.5) * np.float32(np.pi)
         p = x[:, 2:3, 0, :].clamp(1e-4, 1 - 1e-4)
         return bon, torch.log(p) - torch.log1p(-p)
+
+
+def room_corners(poly, z_ceil=1.2, z_floor=1.5):
+    """Ground-truth ``label_cor`` rows of the reference's dataset format (README_PREPARE_DATASET.md:3-14): for every
+    polygon vertex (counter-clockwise = increasing longitude) the ceiling then the floor image point, float32 [2N,2],
+    starting at the smallest column."""
+    ang = np.arctan2(poly[:, 0], -poly[:, 1])
+    col = (ang / (2 * np.pi) + 0.5) * W - 0.5
+    rng_ = np.sqrt((poly ** 2).sum(1))
+    row_c = (-np.arctan2(z_ceil, rng_) / np.pi + 0.5) * H - 0.5
+    row_f = (-np.arctan2(-z_floor, rng_) / np.pi + 0.5) * H - 0.5
+    cor = np.stack([np.repeat(col, 2), np.stack([row_c, row_f], 1).reshape(-1)], 1)
+    return np.roll(cor, -2 * int(np.argmin(col)), axis=0).astype(np.float32)
+
+
+def render_image(poly, z_ceil=1.2, z_floor=1.5, rng=None, noise=6.0):
+    """A synthetic equirectangular RGB panorama [512,1024,3] uint8 of the room seen from the origin: flat-shaded walls
+    (one random colour each, darkened with grazing incidence and distance), chequered floor, plain ceiling, sensor
+    noise.  Crude, but its edges are exactly the layout's boundaries and corners."""
+    rng = rng or np.random
+    dist, wall = cast(poly)
+    n = len(poly)
+    u = ((np.arange(W) + 0.5) / W - 0.5) * 2 * np.pi
+    v = -((np.arange(H) + 0.5) / H - 0.5) * np.pi                  # latitude, positive up
+    tanv = np.tan(v)[:, None]
+    ceil_mask = tanv > (z_ceil / dist)[None, :]
+    floor_mask = tanv < (-z_floor / dist)[None, :]
+    # walls
+    e = np.roll(poly, -1, axis=0) - poly
+    nrm = np.stack([e[:, 1], -e[:, 0]], 1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ray = np.stack([np.sin(u), -np.cos(u)], 1)
+    incidence = np.abs((ray * nrm[wall]).sum(1))
+    base = rng.uniform(70, 200, (n, 3))
+    shade = (0.45 + 0.55 * incidence) * np.clip(1.6 / (0.6 + 0.35 * dist), 0.5, 1.2)
+    img = np.broadcast_to((base[wall] * shade[:, None])[None], (H, W, 3)).copy()
+    img *= (1.0 - 0.12 * np.abs(np.tan(v))[:, None, None] * 0 + 0.08 * np.sin(v)[:, None, None])
+    # floor: chequer in plan coordinates; ceiling: plain with a soft falloff
+    with np.errstate(divide="ignore"):
+        rf = np.where(floor_mask, -z_floor / np.minimum(tanv, -1e-6), 0.0)
+        rc = np.where(ceil_mask, z_ceil / np.maximum(tanv, 1e-6), 0.0)
+    px, py = rf * np.sin(u)[None, :], -rf * np.cos(u)[None, :]
+    chk = ((np.floor(px / 0.5) + np.floor(py / 0.5)) % 2)
+    fcol = rng.uniform(60, 140, 3)
+    floor_rgb = fcol[None, None, :] * (0.75 + 0.25 * chk)[..., None] * np.clip(1.4 / (0.7 + 0.3 * rf), 0.5, 1.2)[..., None]
+    ccol = rng.uniform(170, 235, 3)
+    ceil_rgb = ccol[None, None, :] * np.clip(1.3 / (0.8 + 0.15 * rc), 0.7, 1.05)[..., None]
+    img = np.where(floor_mask[..., None], floor_rgb, img)
+    img = np.where(ceil_mask[..., None], ceil_rgb, img)
+    img += rng.normal(0, noise, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def write_dataset(root, n, seed, corner_mix=(4, 4, 4, 4, 4, 6, 6, 8), visible_only=True, noise=6.0):
+    """Write n synthetic samples in the reference's on-disk layout (root/img/*.png, root/label_cor/*.txt)."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "img"), exist_ok=True)
+    os.makedirs(os.path.join(root, "label_cor"), exist_ok=True)
+    k = 0
+    while k < n:
+        poly = manhattan_polygon(rng, corner_mix[k % len(corner_mix)])
+        zc, zf = rng.uniform(1.0, 1.6), rng.uniform(1.2, 1.7)
+        cor = room_corners(poly, zc, zf)
+        if visible_only and np.any(np.diff(cor[::2, 0]) <= 0):
+            continue                                               # a reflex corner hides part of the room
+        Image.fromarray(render_image(poly, zc, zf, rng, noise)).save(os.path.join(root, "img", "room_%05d.png" % k))
+        with open(os.path.join(root, "label_cor", "room_%05d.txt" % k), "w") as f:
+            for x, y in cor:
+                f.write("%d %d\n" % (round(float(x)), round(float(y))))
+        k += 1
