@@ -91,6 +91,42 @@ def pano_stretch_leg(dev, n_img=64, iters=10):
             "max_abs_vs_oracle": err}
 
 
+def augment_leg(dev, n_img=64, iters=10):
+    """Training-input pipeline (dataset.py:52-123 image half): one fused launch per batch of 64, every augmentation on.
+    Algorithmic bytes: 512*1024*3*(1+4) = 7,864,320 per image (uint8 HWC read + f32 CHW write)."""
+    from horizonnet_amd.dataset import augment_images
+    from oracle import dataset_ref
+    g = torch.Generator().manual_seed(6)
+    data = torch.randint(0, 256, (n_img, 512, 1024, 3), generator=g, dtype=torch.uint8).to(dev)
+    rng = np.random.RandomState(6)
+    augs = [{"kx": float(rng.uniform(0.5, 2)), "ky": float(rng.uniform(0.5, 2)), "flip": int(rng.randint(2)), "rotate": True,
+             "roll": int(rng.randint(1024)), "gamma": float(rng.uniform(0.5, 2))} for _ in range(n_img)]
+    idx = list(rng.permutation(n_img))
+    out = torch.empty(n_img, 3, 512, 1024, device=dev)
+    augment_images(data, idx, augs, out=out)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        augment_images(data, idx, augs, out=out)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    gbs = n_img * 7_864_320 / (ms * 1e-3) / 1e9
+    a = augs[0]
+    src = data[idx[0]].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = dataset_ref.augment_image(src, a["kx"], a["ky"], a["flip"], a["roll"], a["gamma"])
+    cpu_s = time.perf_counter() - t0
+    got = out[0].cpu().numpy()
+    ulp = int(np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max())
+    return {"images_per_s": round(n_img / (ms * 1e-3), 1), "ms_per_batch": round(ms, 4), "batch": n_img,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)},
+            "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "images/s", "cores": 1, "kind": "port",
+                             "sample": "1 image through oracle.dataset_ref.augment_image (numpy, 1 thread)"},
+            "max_ulp_vs_oracle": ulp}
+
+
 def train_leg(dev, world, B, steps, warmup, dist):
     """Training step of reference train.py:272-281 on the engine: train-mode forward, L1(bon) + BCE-with-logits(cor)
     (train.py:53-54), backward (all 241 gradients), data-parallel all-reduce when world > 1, Adam (lr 1e-4).
@@ -300,6 +336,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["pano_stretch"] = pano_stretch_leg(dev)
+            out["augment_pipeline"] = augment_leg(dev)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -27,7 +27,7 @@ def manhattan_polygon(rng, n_corners):
             dx, dy = rng.uniform(0.4, 0.45 * abs(px)), rng.uniform(0.4, 0.45 * abs(py))
             a, b, c = (px, py - sy * dy), (px - sx * dx, py - sy * dy), (px - sx * dx, py)
             # keep counter-clockwise order around the notch
-            out += [a, b, c] if i in (1, 3) else [c, b, a]
+            out += [a, b, c] if i in (0, 2) else [c, b, a]
         else:
             out.append((px, py))
     return np.array(out, np.float64)
