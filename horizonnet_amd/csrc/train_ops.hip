@@ -32,22 +32,34 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         is = *reinterpret_cast<const f32x4*>(invstd + col);
     }
     if (rl < RL) {
-        for (long r = r0 + rl; r < r1; r += RL) {
+        // 4 rows per trip: 4 (MODE 0) or 8-12 (MODE 1) independent 16-byte loads in flight per lane
+        auto one = [&](long r, f32x4& a0, f32x4& a1) {
             f32x4 v = *reinterpret_cast<const f32x4*>(a + r * lda + col);
             if (MODE == 0) {
-                s0 += v;
-                s1 += v * v;
+                a0 += v;
+                a1 += v * v;
             } else {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * (long)C + col);
                 if (ymask) {
                     const f32x4 y = *reinterpret_cast<const f32x4*>(ymask + r * (long)C + col);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
                 }
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * (long)C + col);
-                s0 += v;
-                s1 += v * ((zz - mu) * is);
+                a0 += v;
+                a1 += v * ((zz - mu) * is);
             }
+        };
+        f32x4 p0 = s0, p1 = s1, q0 = s0, q1 = s1, w0 = s0, w1 = s1;
+        long r = r0 + rl;
+        for (; r + 3L * RL < r1; r += 4L * RL) {
+            one(r, s0, s1);
+            one(r + RL, p0, p1);
+            one(r + 2L * RL, q0, q1);
+            one(r + 3L * RL, w0, w1);
         }
+        for (; r < r1; r += RL) one(r, s0, s1);
+        s0 += p0 + q0 + w0;
+        s1 += p1 + q1 + w1;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -349,10 +361,20 @@ inline unsigned grid_for(long total, long cap = 256L * 16)
 
 }  // namespace
 
+// Rows per workgroup of the column reductions: enough workgroups (>= ~2048) to fill 256 CUs several times over
+// even for the deep layers (M = a few thousand rows), at most 1024 rows so the f32 partial sums stay short.
+static int reduce_slab(long M, int C)
+{
+    const long col_blocks = (C + 255) / 256;
+    long slab = (M * col_blocks + 2047) / 2048;
+    slab = (slab + 63) / 64 * 64;
+    return (int)(slab < 64 ? 64 : (slab > 1024 ? 1024 : slab));
+}
+
 int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s)
 {
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "col_stats: unsupported C=%d", C);
-    const int slab = 1024;
+    const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
     hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab);
@@ -364,7 +386,7 @@ int hn_launch_bn_bwd_reduce(const float* dy, const float* ymask, const float* z,
                             double* S2, long M, int C, hipStream_t s)
 {
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "bn_bwd_reduce: unsupported C=%d", C);
-    const int slab = 1024;
+    const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
     hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, ymask, z, mean, invstd, S1, S2, M, C, C, slab);
     HN_LAUNCH_CHECK();

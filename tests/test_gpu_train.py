@@ -158,6 +158,53 @@ def test_train_step_matches_oracle_autograd():
     assert ok
 
 
+def test_loss_curve_first_steps_matches_oracle():
+    """BASELINE configs[2] agreement check: the first K optimiser steps of train.py:272-281 (L1 + BCE-with-logits,
+    Adam lr 1e-4) on the engine against the same steps on the CPU float32 oracle of the reference -- same weights,
+    same batch, dropout off.  The first Adam step moves every weight by +-lr (g / sqrt(g^2)), so sign noise in
+    near-zero gradient components makes the two weight sets differ slightly; the losses must still track."""
+    K, B = 3, 2
+    sd = make_state_dict(31, "random")
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(B, 3, 512, 1024, generator=g)
+    y_bon = (torch.rand(B, 2, 1024, generator=g) - 0.5) * 1.2
+    y_cor = (torch.rand(B, 1, 1024, generator=g) < 0.05).float()
+
+    ref = {k: v.clone() for k, v in sd.items()}
+    params = [v.requires_grad_(True) for k, v in ref.items() if v.is_floating_point() and "running_" not in k]
+    opt_ref = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+    want = []
+    for _ in range(K):
+        rb, rc_ = horizonnet_ref.forward_train(x, ref, 0.1)
+        loss = F.l1_loss(rb, y_bon) + F.binary_cross_entropy_with_logits(rc_, y_cor)
+        opt_ref.zero_grad(set_to_none=True)
+        loss.backward()
+        opt_ref.step()
+        want.append(float(loss))
+
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    xd, yb, yc = x.to(DEV), y_bon.to(DEV), y_cor.to(DEV)
+    got = []
+    for _ in range(K):
+        bon, cor = net(xd)
+        loss = F.l1_loss(bon, yb) + F.binary_cross_entropy_with_logits(cor, yc)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        got.append(float(loss))
+    assert net.hip_status(DEV) == 0
+    print("[parity] loss curve, engine vs f32 oracle: " + ", ".join("%.6f / %.6f" % (a, b) for a, b in zip(got, want)))
+    assert abs(got[0] - want[0]) < 1e-5 * abs(want[0]) + 1e-6          # same weights: forward parity
+    for a, b in zip(got[1:], want[1:]):
+        assert abs(a - b) < 2e-2 * abs(b)
+    assert want[-1] < want[0] and got[-1] < got[0]                       # and both actually descend
+
+
 def test_dropout_statistics_and_eval_after_train():
     net = HorizonNet("resnet50", True)
     net.load_state_dict(make_state_dict(0, "random"))
