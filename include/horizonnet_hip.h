@@ -141,7 +141,7 @@ int hn_pano_stretch(const float* src, float* dst, const double* kx, const double
  * (all HOST arrays of B entries, any may be NULL = augmentation off): kx, ky = Pano-Stretch
  * factors (dataset.py:70-82; the pair (1, 1) means "no stretch" and copies exactly); flip != 0
  * mirrors the columns (dataset.py:88); roll = dx of np.roll(img, dx, axis=1) (dataset.py:95);
- * gamma = exponent p of img ** p (dataset.py:100-104; float32 pow, <= 1 ulp from glibc's).
+ * gamma = exponent p of img ** p (dataset.py:100-104; float32 pow, <= 1 ulp from numpy's; 0.25 <= p <= 4).
  * dst: [B][3][H][W] float32 in [0,1] -- what dataset.py:123 returns per sample, stacked; the
  * layout hn_forward / hn_train_forward consume.  Order of operations = the reference's:
  * /255 -> stretch -> flip -> roll -> gamma -> CHW. */
