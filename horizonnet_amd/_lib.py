@@ -35,6 +35,9 @@ SIGNATURES = {
     "hn_train_workspace_bytes": (_sz, [_i]),
     "hn_train_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _f, _f, _f, _c.c_uint64, _vp]),
     "hn_train_backward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _f, _c.c_uint64, _vp]),
+    "hn_train_backward_segment": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _f, _c.c_uint64, _i, _vp]),
+    "hn_grad_segments": (_i, []),
+    "hn_grad_segment_range": (_i, [_i, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "hn_grad_floats": (_sz, []),
     "hn_train_debug_unit": (_i, [_i, _i, _c.POINTER(_i64)]),
     "hn_train_debug_set": (_i, [_vp, _i, _vp, _vp]),

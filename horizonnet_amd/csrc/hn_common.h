@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // device scratch of the persistent LSTM: arrival counters + sticky status word (uint32 words)
 constexpr int HN_SYNC_WORDS = 1024;     // 4096 bytes
+constexpr int HN_GRAD_SEGMENTS = 5;     // gradient-completion segments of the backward pass (train.hip)
 constexpr int HN_STATUS_WORD = 512;
 
 static inline int hn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

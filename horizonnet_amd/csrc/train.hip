@@ -311,10 +311,17 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     return hn_launch_linear_head(W + pl.y2d, c.P + a.linw_off, c.P + a.linb_off, bon, cor, T_COLS, B, s);
 }
 
-extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
-                                 float* grads, float p_rnn, float p_head, uint64_t seed, void* stream)
+// The backward pass in gradient-completion order.  Segment boundaries are where a contiguous range of the flat gradient
+// buffer becomes final, so a data-parallel caller can start that range's all-reduce while the rest still runs:
+//   0: Linear + bi-LSTM   1: height compression (4 scales)   2: layer4   3: layer3   4: layer2, layer1, stem
+// Launches outside [seg_lo, seg_hi] are skipped; the buffer rotation (pure pointer bookkeeping) always runs.
+static int train_backward_impl(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
+                               float* grads, float p_rnn, float p_head, uint64_t seed, int seg_lo, int seg_hi, void* stream)
 {
     HN_REQUIRE(e && dbon && dcor && workspace && grads, "hn_train_backward: null argument");
+    HN_REQUIRE(0 <= seg_lo && seg_lo <= seg_hi && seg_hi < HN_GRAD_SEGMENTS, "hn_train_backward: bad segment range %d..%d", seg_lo, seg_hi);
+    int seg = 0;
+#define LIVE (seg >= seg_lo && seg <= seg_hi)
     const TrainPlan pl = make_train_plan(B);
     HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_train_backward: workspace too small");
     DeviceGuard guard(e->device);
@@ -332,7 +339,7 @@ extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* d
     double* ds = reinterpret_cast<double*>(W + pl.dstat);
 
     // ---- head: Linear + dropout ----
-    if ((rc = hn_launch_head_bwd(dbon, dcor, c.bound("linear.weight"), W + pl.y2d, G0, W + pl.dlin, c.grad("linear.weight"),
+    if (LIVE && (rc = hn_launch_head_bwd(dbon, dcor, c.bound("linear.weight"), W + pl.y2d, G0, W + pl.dlin, c.grad("linear.weight"),
                                  c.grad("linear.bias"), T_COLS, B, s)))
         return rc;
     float* dy = G0;                                   // gradient w.r.t. the (dropped) LSTM output
@@ -342,103 +349,137 @@ extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* d
     float* dx_buf[2] = {G2, G1};                      // layer 1 writes dx into G1, layer 0 into G2
     for (int l = 1; l >= 0; --l) {
         if (pdrop[l] > 0.f)
-            if ((rc = hn_launch_dropout(dy, dy, rows * 1024, pdrop[l], seed * 2 + 1 + l, s))) return rc;
+            if (LIVE && (rc = hn_launch_dropout(dy, dy, rows * 1024, pdrop[l], seed * 2 + 1 + l, s))) return rc;
         // recurrence adjoint, one time index per direction per step
         float* dgx = W + pl.gx;
-        HN_HIP(hipMemsetAsync(W + pl.dhrec, 0, (size_t)B * 1024 * sizeof(float), s));
-        HN_HIP(hipMemsetAsync(W + pl.dcrec, 0, (size_t)B * 1024 * sizeof(float), s));
+        if (LIVE) HN_HIP(hipMemsetAsync(W + pl.dhrec, 0, (size_t)B * 1024 * sizeof(float), s));
+        if (LIVE) HN_HIP(hipMemsetAsync(W + pl.dcrec, 0, (size_t)B * 1024 * sizeof(float), s));
         const std::string sf = "_l" + std::to_string(l), sr = sf + "_reverse";
         float* whhT = W + pl.wsB;                     // [2][512][2048]: recurrent weights, k-major, for the adjoint GEMV
-        if ((rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sf), whhT, 2048, 512, s))) return rc;
-        if ((rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sr), whhT + (size_t)512 * 2048, 2048, 512, s))) return rc;
+        if (LIVE && (rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sf), whhT, 2048, 512, s))) return rc;
+        if (LIVE && (rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sr), whhT + (size_t)512 * 2048, 2048, 512, s))) return rc;
         for (int step = 0; step < T_COLS; ++step) {
-            if ((rc = hn_launch_lstm_bwd_gates(W + pl.save[l], dy, W + pl.dhrec, W + pl.dcrec, dgx, T_COLS, B, step, s))) return rc;
+            if (LIVE && (rc = hn_launch_lstm_bwd_gates(W + pl.save[l], dy, W + pl.dhrec, W + pl.dcrec, dgx, T_COLS, B, step, s))) return rc;
             const int tf = T_COLS - 1 - step, tr = step;
-            if ((rc = hn_launch_lstm_bwd_dh(dgx + (size_t)tf * B * 4096, dgx + (size_t)tr * B * 4096, whhT, whhT + (size_t)512 * 2048,
+            if (LIVE && (rc = hn_launch_lstm_bwd_dh(dgx + (size_t)tf * B * 4096, dgx + (size_t)tr * B * 4096, whhT, whhT + (size_t)512 * 2048,
                                             W + pl.dhrec, B, s)))
                 return rc;
         }
         // dW_hh = sum_t dg_t^T h_{t-1}   (fwd: rows m >= B pair with y rows m - B; rev: rows m < (T-1)B pair with y rows m + B)
-        if ((rc = hn_launch_conv_wgrad(layer_out[l], dgx + (size_t)B * 4096, c.grad("bi_rnn.weight_hh" + sf), 1, 1, (int)(rows - B), 512,
+        if (LIVE && (rc = hn_launch_conv_wgrad(layer_out[l], dgx + (size_t)B * 4096, c.grad("bi_rnn.weight_hh" + sf), 1, 1, (int)(rows - B), 512,
                                        2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
             return rc;
-        if ((rc = hn_launch_conv_wgrad(layer_out[l] + (size_t)B * 1024 + 512, dgx + 2048, c.grad("bi_rnn.weight_hh" + sr), 1, 1,
+        if (LIVE && (rc = hn_launch_conv_wgrad(layer_out[l] + (size_t)B * 1024 + 512, dgx + 2048, c.grad("bi_rnn.weight_hh" + sr), 1, 1,
                                        (int)(rows - B), 512, 2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
             return rc;
         // dW_ih (both directions stacked) and the bias gradients
         float* wsc = W + pl.wsA;
-        if ((rc = hn_launch_conv_wgrad(layer_in[l], dgx, wsc, 1, 1, (int)rows, 1024, 4096, 1, 1, 1, 1, 1024, 4096, 0, s))) return rc;
-        HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sf), wsc, (size_t)2048 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
-        HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sr), wsc + (size_t)2048 * 1024, (size_t)2048 * 1024 * sizeof(float),
+        if (LIVE && (rc = hn_launch_conv_wgrad(layer_in[l], dgx, wsc, 1, 1, (int)rows, 1024, 4096, 1, 1, 1, 1, 1024, 4096, 0, s))) return rc;
+        if (LIVE) HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sf), wsc, (size_t)2048 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (LIVE) HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sr), wsc + (size_t)2048 * 1024, (size_t)2048 * 1024 * sizeof(float),
                               hipMemcpyDeviceToDevice, s));
-        HN_HIP(hipMemsetAsync(ds, 0, 4096 * sizeof(double), s));
-        if ((rc = hn_launch_col_stats(dgx, ds, nullptr, rows, 4096, 4096, s))) return rc;
-        if ((rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_ih" + sf), 2048, s))) return rc;
-        if ((rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_hh" + sf), 2048, s))) return rc;
-        if ((rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_ih" + sr), 2048, s))) return rc;
-        if ((rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_hh" + sr), 2048, s))) return rc;
+        if (LIVE) HN_HIP(hipMemsetAsync(ds, 0, 4096 * sizeof(double), s));
+        if (LIVE && (rc = hn_launch_col_stats(dgx, ds, nullptr, rows, 4096, 4096, s))) return rc;
+        if (LIVE && (rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_ih" + sf), 2048, s))) return rc;
+        if (LIVE && (rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_hh" + sf), 2048, s))) return rc;
+        if (LIVE && (rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_ih" + sr), 2048, s))) return rc;
+        if (LIVE && (rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_hh" + sr), 2048, s))) return rc;
         // dx = dg @ [W_ih_fwd; W_ih_rev]   (GEMM weights [N=1024][K=4096] = transpose of the stacked W_ih)
         float* wt = W + pl.wsB;
-        if ((rc = hn_launch_transpose(c.P + a.wih_off[l], wt, 4096, 1024, s))) return rc;
-        if ((rc = gemm_rows(dgx, 0, wt, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s))) return rc;
+        if (LIVE && (rc = hn_launch_transpose(c.P + a.wih_off[l], wt, 4096, 1024, s))) return rc;
+        if (LIVE && (rc = gemm_rows(dgx, 0, wt, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s))) return rc;
         dy = dx_buf[l];
     }
+    seg = 1;
     float* dseq = dy;                                  // = G2: gradient w.r.t. the [256*B][1024] sequence matrix
 
     // ---- height compression, all four scales: leaves d(C_s) in DC[s] ----
     for (int li = 0; li < 4; ++li) {
         const Unit& ul = pl.units[pl.ghc[li] + 3];
-        if ((rc = hn_launch_upsample_flatten_bwd(dseq, G0, B, ul.Ho, ul.Wo, a.convs[ul.ci].cout, 256 * li, s))) return rc;
+        if (LIVE && (rc = hn_launch_upsample_flatten_bwd(dseq, G0, B, ul.Ho, ul.Wo, a.convs[ul.ci].cout, 256 * li, s))) return rc;
         float* gy = G0;
         float* gz = G1;
         float* gx = G3;
         for (int k = 3; k >= 0; --k) {
             const Unit& u = pl.units[pl.ghc[li] + k];
-            if ((rc = unit_backward(c, u, gy, W + u.y, gz, nullptr))) return rc;
+            if (LIVE && (rc = unit_backward(c, u, gy, W + u.y, gz, nullptr))) return rc;
             float* out = (k == 0) ? W + pl.DC[li] : gx;
-            if ((rc = unit_dgrad(c, u, gz, nullptr, out))) return rc;
+            if (LIVE && (rc = unit_dgrad(c, u, gz, nullptr, out))) return rc;
             float* t = gy; gy = gx; gx = t;            // next unit's dy is what was just written
         }
     }
 
     // ---- backbone, layer4 -> layer1 ----
+    seg = 2;
     float* Ga = G0;
     float* Gb = G1;
     float* Gc = G2;
     float* Gd = G3;
     const size_t csz[4] = {(size_t)B * 128 * 256 * 256, (size_t)B * 64 * 128 * 512, (size_t)B * 32 * 64 * 1024, (size_t)B * 16 * 32 * 2048};
-    HN_HIP(hipMemcpyAsync(Ga, W + pl.DC[3], csz[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (LIVE) HN_HIP(hipMemcpyAsync(Ga, W + pl.DC[3], csz[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int li = 3; li >= 0; --li) {
+        seg = li == 3 ? 2 : (li == 2 ? 3 : 4);
         for (int j = kBlocks[li] - 1; j >= 0; --j) {
             const int i1 = pl.blk[li][j];
             const Unit& u1 = pl.units[i1];
             const Unit& u2 = pl.units[i1 + 1];
             const Unit& u3 = pl.units[i1 + (j == 0 ? 3 : 2)];
             // conv3 + bn3 + (add) + relu: mask = block output
-            if ((rc = unit_backward(c, u3, Ga, W + u3.y, Gb, Gc))) return rc;       // dz3 -> Gb, identity grad -> Gc
-            if ((rc = unit_dgrad(c, u3, Gb, nullptr, Gd))) return rc;               // d(t2) -> Gd
-            if ((rc = unit_backward(c, u2, Gd, W + u2.y, Ga, nullptr))) return rc;  // dz2 -> Ga
-            if ((rc = unit_dgrad(c, u2, Ga, nullptr, Gb))) return rc;               // d(t1) -> Gb
-            if ((rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> Gd
+            if (LIVE && (rc = unit_backward(c, u3, Ga, W + u3.y, Gb, Gc))) return rc;       // dz3 -> Gb, identity grad -> Gc
+            if (LIVE && (rc = unit_dgrad(c, u3, Gb, nullptr, Gd))) return rc;               // d(t2) -> Gd
+            if (LIVE && (rc = unit_backward(c, u2, Gd, W + u2.y, Ga, nullptr))) return rc;  // dz2 -> Ga
+            if (LIVE && (rc = unit_dgrad(c, u2, Ga, nullptr, Gb))) return rc;               // d(t1) -> Gb
+            if (LIVE && (rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> Gd
             if (j == 0) {
                 const Unit& ud = pl.units[pl.dsu[li]];
-                if ((rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr))) return rc;   // dz_ds -> Ga
-                if ((rc = unit_dgrad(c, ud, Ga, nullptr, Gb))) return rc;               // ds path -> Gb
-                if ((rc = unit_dgrad(c, u1, Gd, Gb, Gc))) return rc;                    // + conv1 path -> Gc
+                if (LIVE && (rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr))) return rc;   // dz_ds -> Ga
+                if (LIVE && (rc = unit_dgrad(c, ud, Ga, nullptr, Gb))) return rc;               // ds path -> Gb
+                if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gb, Gc))) return rc;                    // + conv1 path -> Gc
                 float* t = Ga; Ga = Gc; Gc = t;
             } else {
-                if ((rc = unit_dgrad(c, u1, Gd, Gc, Ga))) return rc;                    // conv1 path + identity -> Ga
+                if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gc, Ga))) return rc;                    // conv1 path + identity -> Ga
             }
         }
         if (li > 0) {   // the block input of layer li is C_{li-1}: add the height-compression branch's gradient
-            if ((rc = hn_launch_axpy(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s))) return rc;
+            if (LIVE && (rc = hn_launch_axpy(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s))) return rc;
         }
     }
     // ---- max-pool + stem ----
     {
         const Unit& u = pl.units[0];
-        if ((rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
-        if ((rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr))) return rc;
+        if (LIVE && (rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
+        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr))) return rc;
     }
+#undef LIVE
+    return 0;
+}
+
+extern "C" int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
+                                 float* grads, float p_rnn, float p_head, uint64_t seed, void* stream)
+{
+    return train_backward_impl(e, dbon, dcor, B, workspace, workspace_bytes, grads, p_rnn, p_head, seed, 0, HN_GRAD_SEGMENTS - 1, stream);
+}
+
+extern "C" int hn_train_backward_segment(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace,
+                                         size_t workspace_bytes, float* grads, float p_rnn, float p_head, uint64_t seed, int segment,
+                                         void* stream)
+{
+    return train_backward_impl(e, dbon, dcor, B, workspace, workspace_bytes, grads, p_rnn, p_head, seed, segment, segment, stream);
+}
+
+extern "C" int hn_grad_segments(void) { return HN_GRAD_SEGMENTS; }
+
+extern "C" int hn_grad_segment_range(int segment, int64_t* first, int64_t* count)
+{
+    HN_REQUIRE(segment >= 0 && segment < HN_GRAD_SEGMENTS && first && count, "hn_grad_segment_range: bad argument");
+    const Arch& a = arch();
+    const int64_t b_l3 = (int64_t)a.grad_off.at("feature_extractor.encoder.layer3.0.conv1.weight");
+    const int64_t b_l4 = (int64_t)a.grad_off.at("feature_extractor.encoder.layer4.0.conv1.weight");
+    const int64_t b_ghc = (int64_t)a.grad_off.at("reduce_height_module.ghc_lst.0.layer.0.layers.0.1.weight");
+    const int64_t b_rnn = (int64_t)a.grad_off.at("bi_rnn.weight_ih_l0");
+    const int64_t lo[HN_GRAD_SEGMENTS] = {b_rnn, b_ghc, b_l4, b_l3, 0};
+    const int64_t hi[HN_GRAD_SEGMENTS] = {(int64_t)a.grad_floats, b_rnn, b_ghc, b_l4, b_l3};
+    *first = lo[segment];
+    *count = hi[segment] - lo[segment];
     return 0;
 }

@@ -187,12 +187,28 @@ class _HipTrainStep(torch.autograd.Function):
         dcor = torch.zeros((B, 1, 1024), device=dev) if dcor is None else dcor.contiguous().float()
         ws = st.train_workspace(B)
         flat = torch.empty(st.lib.hn_grad_floats(), dtype=torch.float32, device=dev)
+        import ctypes
+        import torch.distributed as dist
+        world = dist.get_world_size(net.process_group) if (net.sync_gradients and dist.is_available() and dist.is_initialized()) else 1
+        args = (st.handle, _lib.ptr(dbon), _lib.ptr(dcor), B, _lib.ptr(ws), ws.numel(), _lib.ptr(flat), ctx.p[0], ctx.p[1], ctx.seed)
         with torch.cuda.device(dev):
-            _lib.check(st.lib.hn_train_backward(st.handle, _lib.ptr(dbon), _lib.ptr(dcor), B, _lib.ptr(ws), ws.numel(), _lib.ptr(flat),
-                                                ctx.p[0], ctx.p[1], ctx.seed, _lib.stream_ptr(dev)), "hn_train_backward")
-        if net.sync_gradients:                    # data-parallel replicas: one RCCL all-reduce (mean) of the flat buffer
-            from .parallel import allreduce_mean_
-            allreduce_mean_(flat, net.process_group)
+            if world == 1 and not getattr(net, "segmented_backward", False):
+                _lib.check(st.lib.hn_train_backward(*args, _lib.stream_ptr(dev)), "hn_train_backward")
+            else:
+                # data-parallel replicas: the backward runs in gradient-completion segments (Linear + LSTM, height
+                # compression, layer4, layer3, layer2..stem); each finished range of the flat buffer starts its RCCL
+                # all-reduce at once, overlapping with the segments still to run
+                from .parallel import allreduce_sum_async
+                works = []
+                lo, cnt = ctypes.c_int64(), ctypes.c_int64()
+                for seg in range(st.lib.hn_grad_segments()):
+                    _lib.check(st.lib.hn_train_backward_segment(*args, seg, _lib.stream_ptr(dev)), "hn_train_backward_segment")
+                    _lib.check(st.lib.hn_grad_segment_range(seg, ctypes.byref(lo), ctypes.byref(cnt)), "hn_grad_segment_range")
+                    works += allreduce_sum_async(flat[lo.value:lo.value + cnt.value], net.process_group)
+                for w in works:
+                    w.wait()
+                if world > 1:
+                    flat.mul_(1.0 / world)
         grads = []
         for (name, shape), need in zip(ctx.names, ctx.needs):
             if not need:

@@ -13,6 +13,20 @@ import torch
 DEFAULT_BUCKET_BYTES = 64 << 20
 
 
+def allreduce_sum_async(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
+    """Start the in-place sum over the ranks of `group` of a 1-D contiguous tensor, in buckets; returns the work
+    handles ([] when there is nothing to exchange).  With the nccl (= RCCL) backend the collectives run on RCCL's own
+    stream behind everything enqueued on the current stream so far -- kernels enqueued afterwards overlap with them."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    assert flat.dim() == 1 and flat.is_contiguous()
+    n = flat.numel()
+    per = max(1, bucket_bytes // flat.element_size())
+    return [dist.all_reduce(flat[lo:min(n, lo + per)], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            for lo in range(0, n, per)]
+
+
 def allreduce_mean_(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
     """In-place mean over the ranks of `group` of a 1-D contiguous tensor, in buckets.  No-op when
     torch.distributed is not initialised or the group has a single rank."""

@@ -119,6 +119,19 @@ int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, 
 int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
                       float* grads, float p_rnn, float p_head, uint64_t seed, void* stream);
 size_t hn_grad_floats(void);
+/* The same backward pass in 5 gradient-completion segments (0: Linear + bi-LSTM, 1: height
+ * compression, 2: layer4, 3: layer3, 4: layer2 + layer1 + stem), to be called in order 0..4
+ * with identical arguments.  After segment s returns (= is enqueued on `stream`) the range
+ * hn_grad_segment_range(s) of `grads` is final, so a data-parallel caller can issue that
+ * range's RCCL all-reduce while the later segments still run -- the "bucketed in reverse-layer
+ * order, overlapped with backward" exchange of reference train.py:190-192,278-280's DataParallel
+ * replacement. */
+int hn_train_backward_segment(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace,
+                              size_t workspace_bytes, float* grads, float p_rnn, float p_head,
+                              uint64_t seed, int segment, void* stream);
+int hn_grad_segments(void);
+int hn_grad_segment_range(int segment, int64_t* first, int64_t* count);
+
 /* debug taps used by the parity tests (see train.hip) */
 int hn_train_debug_unit(int B, int unit, int64_t* out8);
 int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* dz_dst);

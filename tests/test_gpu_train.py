@@ -205,6 +205,49 @@ def test_loss_curve_first_steps_matches_oracle():
     assert want[-1] < want[0] and got[-1] < got[0]                       # and both actually descend
 
 
+def test_segmented_backward_equals_monolithic():
+    """hn_train_backward_segment 0..4 (the data-parallel overlap path) == hn_train_backward: same gradients up to the
+    summation-order noise of the float atomics in the weight-gradient kernels, and the segment ranges tile the buffer."""
+    import ctypes
+    L = lib()
+    nseg = L.hn_grad_segments()
+    lo, cnt = ctypes.c_int64(), ctypes.c_int64()
+    ranges = []
+    for sgm in range(nseg):
+        _lib.check(L.hn_grad_segment_range(sgm, ctypes.byref(lo), ctypes.byref(cnt)), "range")
+        ranges.append((lo.value, cnt.value))
+    assert nseg == 5 and sorted(ranges)[0][0] == 0
+    srt = sorted(ranges)
+    assert all(srt[i][0] + srt[i][1] == srt[i + 1][0] for i in range(nseg - 1)) and srt[-1][0] + srt[-1][1] == L.hn_grad_floats()
+    assert ranges[0][0] == L.hn_grad_offset(b"bi_rnn.weight_ih_l0")            # finished first: the tail of the buffer
+
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(41, "random"))
+    net = net.to(DEV).train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(42)).to(DEV)
+    w = _rand((2, 2, 1024), 43).to(DEV)
+
+    def grads(segmented):
+        net.segmented_backward = segmented
+        for p in net.parameters():
+            p.grad = None
+        bon, cor = net(x)
+        ((bon * w).sum() + cor.sum()).backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    a, b = grads(False), grads(True)
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    # conv biases in front of a batch-statistics BN have a zero true gradient: both runs hold rounding noise there
+    rel = {k: float((a[k] - b[k]).norm() / (a[k].norm() + 1e-20)) for k in a if not k.endswith("layers.0.1.bias")}
+    worst = max(rel, key=rel.get)
+    print("[parity] segmented vs monolithic backward: worst relative L2 difference %.2e (%s)" % (rel[worst], worst))
+    assert rel[worst] < 1e-4
+    assert all(float(b[k].abs().max()) < 1e-4 for k in b if k.endswith("layers.0.1.bias"))
+
+
 def test_dropout_statistics_and_eval_after_train():
     net = HorizonNet("resnet50", True)
     net.load_state_dict(make_state_dict(0, "random"))
