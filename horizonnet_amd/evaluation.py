@@ -141,3 +141,89 @@ def test_general(dt_cor_id, gt_cor_id, w, h, losses):
 
 
 test_general.__test__ = False      # not a pytest test despite the reference's name
+
+
+# ---- cuboid metrics (eval_cuboid.py:13-145) -------------------------------------------------------------------------
+def _inward_halfspace(pa, pb, p):
+    """Plane through p, pa, pb as [a, b, c, d] with a*x + b*y + c*z + d <= 0 on the origin's side."""
+    n = np.cross(pa - p, pb - p)
+    if -n @ p > 0:
+        n = -n
+    return [n[0], n[1], n[2], -n @ p]
+
+
+def _room_halfspaces(floor_xyz, ceil_xyz):
+    """Half-spaces (3 at every floor corner, 3 at every ceiling corner) whose intersection is the room seen from the
+    camera at the origin (eval_cuboid.py:24-46)."""
+    N = len(floor_xyz)
+    hs = []
+    for i in range(N):
+        a, b = (i - 1) % N, (i + 1) % N
+        f, c = floor_xyz[i], ceil_xyz[i]
+        hs += [_inward_halfspace(floor_xyz[a], floor_xyz[b], f), _inward_halfspace(floor_xyz[a], c, f),
+               _inward_halfspace(c, floor_xyz[b], f), _inward_halfspace(ceil_xyz[a], ceil_xyz[b], c),
+               _inward_halfspace(ceil_xyz[a], f, c), _inward_halfspace(f, ceil_xyz[b], c)]
+    return np.array(hs)
+
+
+def eval_3diou(dt_floor_coor, dt_ceil_coor, gt_floor_coor, gt_ceil_coor, ch=-1.6, coorW=1024, coorH=512):
+    """3D IoU in percent of two rooms given by floor / ceiling corner pixels, camera 1.6 above the floor: volumes by
+    half-space intersection + convex hull (Qhull through SciPy, as the reference: eval_cuboid.py:49-92)."""
+    from scipy.spatial import ConvexHull, HalfspaceIntersection
+
+    def room(floor, ceil):
+        floor, ceil = np.array(floor), np.array(ceil)
+        assert (floor[:, 0] != ceil[:, 0]).sum() == 0
+        xy = postproc.pano_to_plan(floor, ch, coorW, coorH, floorW=1, floorH=1)
+        fxyz = np.hstack([xy, np.zeros((len(xy), 1)) + ch])
+        cxyz = fxyz.copy()
+        cxyz[:, 2] = np.sqrt((fxyz[:, :2] ** 2).sum(1)) * np.tan(postproc.row_to_v(ceil[:, 1], coorH))
+        return _room_halfspaces(fxyz, cxyz)
+
+    def volume(halfspaces):
+        return ConvexHull(HalfspaceIntersection(halfspaces, np.zeros(3)).intersections).volume
+
+    dt_h, gt_h = room(dt_floor_coor, dt_ceil_coor), room(gt_floor_coor, gt_ceil_coor)
+    v_in, v_dt, v_gt = volume(np.concatenate([dt_h, gt_h])), volume(dt_h), volume(gt_h)
+    return 100 * v_in / (v_dt + v_gt - v_in)
+
+
+def _boundary_rows(points, w):
+    """Row of a boundary at every column from scattered (col, row) samples (eval_cuboid.py:95-97)."""
+    points = points[np.argsort(points[:, 0])]
+    return np.interp(np.arange(w), points[:, 0], points[:, 1], period=w)
+
+
+def cuboid_metrics(dt_cor_id, z0, z1, gt_cor_id, w=1024, h=512):
+    """Corner error (% of the image diagonal), pixel surface error (% of pixels whose ceiling / wall / floor label
+    differs) and 3D IoU (%) of a predicted against a ground-truth cuboid (eval_cuboid.py:100-145)."""
+    from .labels import pano_connect_points
+    dt_cor_id, gt_cor_id = np.asarray(dt_cor_id), np.asarray(gt_cor_id)
+    ce = 100 * np.sqrt(((gt_cor_id - dt_cor_id) ** 2).sum(1)).mean() / np.sqrt(w ** 2 + h ** 2)
+
+    def trace(cor, first, z):
+        return _boundary_rows(np.concatenate([pano_connect_points(cor[j * 2 + first], cor[(j * 2 + 2 + first) % 8], z)
+                                              for j in range(4)], 0), w)
+
+    ceil_dt = trace(dt_cor_id, 0, -z0)
+    floor_dt = postproc.infer_coory(ceil_dt, z1 - z0, z0)
+    ceil_gt, floor_gt = trace(gt_cor_id, 0, -z0), trace(gt_cor_id, 1, z0)
+
+    def surface(ceil_rows, floor_rows):
+        s = np.zeros((h, w), dtype=np.int32)
+        s[np.round(ceil_rows).astype(int), np.arange(w)] = 1
+        s[np.round(floor_rows).astype(int), np.arange(w)] = 1
+        return np.cumsum(s, axis=0)
+
+    pe = 100 * (surface(ceil_dt, floor_dt) != surface(ceil_gt, floor_gt)).sum() / (h * w)
+    return {"CE": ce, "PE": pe, "3DIoU": eval_3diou(dt_cor_id[1::2], dt_cor_id[0::2], gt_cor_id[1::2], gt_cor_id[0::2])}
+
+
+def test_cuboid(dt_cor_id, z0, z1, gt_cor_id, w, h, losses):
+    """Reference signature of ``eval_cuboid.test``: appends CE / PE / 3DIoU to `losses`."""
+    m = cuboid_metrics(dt_cor_id, z0, z1, gt_cor_id, w, h)
+    for k in ("CE", "PE", "3DIoU"):
+        losses[k].append(m[k])
+
+
+test_cuboid.__test__ = False

@@ -356,6 +356,9 @@ def gen_dataset():
                 out["cor_" + key] = np.asarray(cor)
                 meta.append({"key": key, "cfg": cfg, "index": i, "seed": seed})
     # metrics: depth maps of the ground-truth layouts and 3D IoU between jittered cuboids (Qhull reference)
+    def ref_pp_np_refine(cor):
+        return ref_ec.post_proc.np_refine_by_fix_z(cor[0::2, 1].astype(np.float64), cor[1::2, 1].astype(np.float64), 50)
+
     rng = np.random.RandomState(9)
     for i in range(4):
         cor = np.loadtxt(os.path.join(root, "label_cor", "room_%05d.txt" % i)).astype(np.float32)
@@ -376,6 +379,19 @@ def gen_dataset():
         out["pair_a_%d" % k], out["pair_b_%d" % k] = a, b
         ious.append(iou)
     out["pair_iou3d"] = np.array(ious, np.float64)
+    # eval_cuboid.test end to end: a predicted cuboid as inference() would emit it (corners from the jittered box,
+    # floor rows re-derived from z1 as inference.py:129 does) against the ground truth
+    cub = []
+    for k in range(24):
+        gt, dt = out["pair_a_%d" % k].astype(np.float32), out["pair_b_%d" % k].astype(np.float32)
+        z0 = 50
+        _, z1 = ref_pp_np_refine(dt)
+        dt[1::2, 1] = ref_ec.post_proc.infer_coory(dt[0::2, 1], z1 - z0, z0)
+        losses = {"CE": [], "PE": [], "3DIoU": []}
+        ref_ec.test(dt, z0, z1, gt, 1024, 512, losses)
+        out["cub_dt_%d" % k], out["cub_z1_%d" % k] = dt, np.float64(z1)
+        cub.append([losses["CE"][0], losses["PE"][0], losses["3DIoU"][0]])
+    out["cub_metrics"] = np.array(cub, np.float64)
     np.savez_compressed(os.path.join(GOLD, "dataset.npz"), **out)
     with open(os.path.join(GOLD, "dataset.json"), "w") as f:
         json.dump(meta, f, indent=0)

@@ -107,3 +107,13 @@ def test_test_general_bookkeeping(gold):
     ev.test_general(a, a, 1024, 512, losses)
     assert abs(losses["4"]["3DIoU"][0] - 1) < 1e-12 and abs(losses["overall"]["2DIoU"][0] - 1) < 1e-12
     assert losses["4"]["rmse"] == [0.0] and losses["4"]["delta_1"] == [1.0]
+
+
+def test_cuboid_metrics_match_reference(gold):
+    """eval_cuboid.test (corner error, pixel surface error, Qhull 3D IoU) on 24 predicted / ground-truth box pairs."""
+    g, _ = gold
+    for k, (ce, pe, iou) in enumerate(g["cub_metrics"]):
+        losses = {"CE": [], "PE": [], "3DIoU": []}
+        ev.test_cuboid(g["cub_dt_%d" % k], 50, float(g["cub_z1_%d" % k]), g["pair_a_%d" % k].astype(np.float32), 1024, 512, losses)
+        assert losses["CE"][0] == ce and losses["PE"][0] == pe, k
+        assert abs(losses["3DIoU"][0] - iou) < 1e-9 * iou, k
