@@ -15,6 +15,8 @@
 // conflict-free ds_read_b32 fragment reads (lanes 0-31 row 2j, lanes 32-63 row 2j+1).
 #include "hn_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int WCH = 32;                 // m rows per chunk
@@ -60,7 +62,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
 
     const int NT = (p.Cout + TN - 1) / TN;           // Cout = 32 (ghc0.3) runs a half-empty 64-row tile
     const int KT = p.K / TK;
+    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own L2): XCD x takes a contiguous run of tile
+    // ids, so the NT*KT workgroups that stream the SAME rows of x and dZ run side by side on ONE XCD and share them
+    // through its L2.  With the plain round-robin every XCD fetched every m-range itself: 93 GB of HBM reads per
+    // training step against ~31 GB algorithmic (rocprofv3 FETCH_SIZE).
     int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int nt = bid % NT;
     bid /= NT;
     const int kt = bid % KT;
@@ -88,42 +100,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
     const int n_row = tid / N_TPR, n_col = (tid % N_TPR) * 4;
     const int k_row = tid / K_TPR, k_col = (tid % K_TPR) * 4;
 
+    // Output pixel (b, ho, wo) of each A row this thread stages, for the chunk about to be fetched.  Decomposed once
+    // (two integer divisions per row); afterwards every chunk advances all rows by WCH with compare-and-subtract wraps,
+    // so the steady-state loop has no division (they used to cost ~1/4 of the issue slots).
+    int r_wo[K_PS], r_ho[K_PS], r_b[K_PS];
+#pragma unroll
+    for (int q = 0; q < K_PS; ++q) {
+        const int m = mlo + k_row + q * K_RPP;
+        r_wo[q] = m % p.Wo;
+        const int t = m / p.Wo;
+        r_ho[q] = t % p.Ho;
+        r_b[q] = t / p.Ho - b_first;
+    }
+    const int hw_in = p.Hi * p.Wi;
+
     f32x4 rdz[N_PS], ra[K_PS];
-    auto fetch = [&](int mc) {           // chunk starting at row mc
-#pragma unroll
-        for (int q = 0; q < N_PS; ++q) {
-            const int m = mc + n_row + q * N_RPP;
-            const unsigned off = (m < mhi && n0 + n_col < p.Cout) ? (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 4u : OOB;
-            rdz[q] = wbuf_load16(rsrc_dz, off);
+    const bool wide = p.Wo >= WCH;
+    // The fetch of a chunk is split into its N_PS + K_PS row loads ("parts") so the main loop can issue one part
+    // behind each group of MFMAs: address arithmetic and load issue then run in the shadow of the matrix pipe instead
+    // of in front of it (in-order issue: as one block before the MFMAs they cost ~1/5 of every chunk).
+    auto fetch_dz = [&](int q, int mc) {
+        const int m = mc + n_row + q * N_RPP;
+        const unsigned off = (m < mhi && n0 + n_col < p.Cout) ? (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 4u : OOB;
+        rdz[q] = wbuf_load16(rsrc_dz, off);
+    };
+    auto fetch_a = [&](int q, int mc) {  // called with mc = mlo, mlo + WCH, ... in order (advances the row's pixel state)
+        const int m = mc + k_row + q * K_RPP;
+        // branch-free: the address is always formed, rows past the range / in the zero padding select the OOB offset
+        const int wo = r_wo[q], ho = r_ho[q];
+        int hi, wi;
+        if (STEM) {               // k' = kt*64 + col: dh = 2*kt + (col >= 32), horizontal tap = (col & 31) / 4
+            const int sdh = 2 * kt + (k_col >= 32 ? 1 : 0);
+            hi = sdh >= 7 ? -1 : ho * p.sh - p.ph + sdh;
+            wi = wo * p.sw - p.pw + ((k_col & 31) >> 2);
+        } else {
+            hi = ho * p.sh - p.ph + dh;
+            wi = wo * p.sw - p.pw + dw;
         }
-#pragma unroll
-        for (int q = 0; q < K_PS; ++q) {
-            const int m = mc + k_row + q * K_RPP;
-            unsigned off = OOB;
-            if (m < mhi) {
-                const int wo = m % p.Wo;
-                const int t = m / p.Wo;
-                const int ho = t % p.Ho;
-                const int b = t / p.Ho;
-                int hi, wi;
-                if (STEM) {               // k' = kt*64 + col: dh = 2*kt + (col >= 32), horizontal tap = (col & 31) / 4
-                    const int sdh = 2 * kt + (k_col >= 32 ? 1 : 0);
-                    hi = ho * p.sh - p.ph + sdh;
-                    wi = wo * p.sw - p.pw + ((k_col & 31) >> 2);
-                    if (sdh >= 7) hi = -1;
-                } else {
-                    hi = ho * p.sh - p.ph + dh;
-                    wi = wo * p.sw - p.pw + dw;
-                }
-                wi = wi < 0 ? wi + p.Wi : wi;
-                wi = wi >= p.Wi ? wi - p.Wi : wi;
-                if ((unsigned)hi < (unsigned)p.Hi) {
-                    const unsigned pix = (unsigned)((b - b_first) * p.Hi * p.Wi + hi * p.Wi + wi);
-                    off = STEM ? pix * 16u : (pix * (unsigned)p.xstride + (unsigned)(c0 + k_col)) * 4u;
-                }
-            }
-            ra[q] = wbuf_load16(rsrc_x, off);
+        wi = wi < 0 ? wi + p.Wi : wi;
+        wi = wi >= p.Wi ? wi - p.Wi : wi;
+        const unsigned pix = (unsigned)(r_b[q] * hw_in + hi * p.Wi + wi);
+        const unsigned in_off = STEM ? pix * 16u : (pix * (unsigned)p.xstride + (unsigned)(c0 + k_col)) * 4u;
+        const unsigned off = (m < mhi && (unsigned)hi < (unsigned)p.Hi) ? in_off : OOB;
+        ra[q] = wbuf_load16(rsrc_x, off);
+        // advance this row to the next chunk
+        if (wide) {                  // every layer of the network (WCH <= Wo): at most one wrap per level, as selects
+            int wn = r_wo[q] + WCH;
+            const bool wrap_w = wn >= p.Wo;
+            wn = wrap_w ? wn - p.Wo : wn;
+            const int hn = r_ho[q] + (wrap_w ? 1 : 0);
+            const bool wrap_h = hn >= p.Ho;
+            r_ho[q] = wrap_h ? 0 : hn;
+            r_b[q] += wrap_h ? 1 : 0;
+            r_wo[q] = wn;
+        } else {                     // images narrower than a chunk (tests only): decompose again
+            const int mn = m + WCH;
+            r_wo[q] = mn % p.Wo;
+            const int t = mn / p.Wo;
+            r_ho[q] = t % p.Ho;
+            r_b[q] = t / p.Ho - b_first;
         }
+    };
+    auto fetch_part = [&](int part, int mc) {
+        if (part < N_PS) fetch_dz(part, mc);
+        else if (part < N_PS + K_PS) fetch_a(part - N_PS, mc);
     };
     auto stage = [&](int buf) {
 #pragma unroll
@@ -145,27 +185,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
     const int fr = lane & 31;
     const int fh = lane >> 5;
 
-    fetch(mlo);
+#pragma unroll
+    for (int part = 0; part < N_PS + K_PS; ++part) fetch_part(part, mlo);
     stage(0);
     __syncthreads();
     int buf = 0;
     for (int mc = mlo; mc < mhi; mc += WCH) {
         const bool more = mc + WCH < mhi;
-        if (more) fetch(mc + WCH);
+        static_assert(N_PS + K_PS <= WCH / 2, "one fetch part per MFMA group");
         const float* dz_s = s_dz0 + buf * WCH * SN + fh * SN + wi_ * WN + fr;
         const float* a_s = s_a0 + buf * WCH * SK + fh * SK + wj_ * WK + fr;
+        // fragments double-buffered in registers: the LDS reads of step kk+1 are issued before the MFMAs of step kk
+        // (without this every 4-MFMA group waited for its own ds_reads: ~1/3 of the MFMA pipe idle)
+        float fa[2][TI], fb[2][TJ];
+        auto ldfrag = [&](int slot, int kk) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[slot][i] = dz_s[kk * 2 * SN + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[slot][j] = a_s[kk * 2 * SK + j * 32];
+        };
+        ldfrag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < WCH / 2; ++kk) {
-            float fa[TI], fb[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = dz_s[kk * 2 * SN + i * 32];
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = a_s[kk * 2 * SK + j * 32];
+            if (kk + 1 < WCH / 2) ldfrag((kk + 1) & 1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+            if (more) fetch_part(kk, mc + WCH);      // next chunk's loads, one row per MFMA group
         }
         if (more) stage(buf ^ 1);
         __syncthreads();
@@ -223,7 +272,8 @@ int launch_wgrad(WgradArgs a, hipStream_t s)
 {
     const int NT = (a.Cout + TN - 1) / TN, KT = a.K / TK;
     // split the reduction so that ~2048 workgroups exist, each with >= 8 chunks
-    long split = 2048 / ((long)NT * KT);
+    static const long target = getenv("HN_WGRAD_WGS") ? atol(getenv("HN_WGRAD_WGS")) : 2048;
+    long split = target / ((long)NT * KT);
     if (split < 1) split = 1;
     long mchunk = (a.M + split - 1) / split;
     if (mchunk < 8 * WCH) mchunk = 8 * WCH;
