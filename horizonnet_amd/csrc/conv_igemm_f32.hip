@@ -42,6 +42,8 @@ struct ConvArgs {
     const float* shift;
     const float* res;
     float* y;
+    double* stat_sum;    // optional per-channel sum / sum of squares of the stored output rows (see the epilogue)
+    double* stat_sq;
     int Hi, Wi, Cin, Ho, Wo, Cout;
     int KW, sh, sw, ph, pw;
     int M, K, nk, relu, ldy;
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
         }
         const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
         const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};     // this thread's 4 columns over its rows
 #pragma unroll
         for (int h = 0; h < WAVES_M; ++h) {
             if (h > 0) __syncthreads();          // previous pass fully read before it is overwritten
@@ -349,7 +352,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 }
-                if (m < p.M) *reinterpret_cast<f32x4*>(p.y + out_pix(m) * p.ldy + n0 + ccol) = v;
+                if (m < p.M) {
+                    *reinterpret_cast<f32x4*>(p.y + out_pix(m) * p.ldy + n0 + ccol) = v;
+                    st1 += v;
+                    st2 += v * v;
+                }
+            }
+        }
+        // Train-mode BatchNorm statistics of the tile (reference model.py's nn.BatchNorm2d in training): the RPP
+        // threads that own the same 4 columns reduce through LDS, one double atomic per column per workgroup.
+        // Saves the separate pass that re-read the whole conv output.
+        if (p.stat_sum) {
+            __syncthreads();
+            float* red = smem;                       // [2][RPP][BN]
+            *reinterpret_cast<f32x4*>(red + crow * BN + ccol) = st1;
+            *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol) = st2;
+            __syncthreads();
+            if (tid < BN) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) {
+                    a1 += red[r * BN + tid];
+                    a2 += red[(RPP + r) * BN + tid];
+                }
+                atomicAdd(p.stat_sum + n0 + tid, (double)a1);
+                atomicAdd(p.stat_sq + n0 + tid, (double)a2);
             }
         }
     };
@@ -497,6 +524,8 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     ConvArgs a;
     a.xcd_swizzle = xcd_swizzle;
     a.x = d.x; a.w = d.w; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.y = d.y;
+    a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq;
+    HN_REQUIRE((d.stat_sum == nullptr) == (d.stat_sq == nullptr), "conv: stat_sum and stat_sq come together");
     a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
     a.xstride = d.xstride ? d.xstride : d.Cin;

@@ -50,6 +50,8 @@ struct ConvDesc {
     int ldy;             // output row stride (floats)
     int stem;            // 1 = stem addressing (NHWC4 input, K = 7 rows x (8 taps x 4))
     int xstride;         // floats between input pixels (0 = Cin)
+    double* stat_sum;    // optional [Cout]: += column sums of the stored output (train-mode BatchNorm statistics, fused in the epilogue)
+    double* stat_sq;     // optional [Cout]: += column sums of squares
     int transposed;      // 1 = data-gradient mode: x = dY [B][Hi][Wi][Cin(=Cout of the fwd conv)], y = dX [B][Ho][Wo][Cout(=Cin fwd)],
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };

@@ -126,10 +126,16 @@ int conv_z(const Ctx& c, const Unit& u)
     d.res = nullptr; d.y = c.W + u.z;
     d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = u.stem ? 4 : cl.cin; d.Cout = cl.cout; d.KH = cl.k; d.KW = cl.k;
     d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo; d.relu = 0; d.ldy = cl.cout; d.stem = u.stem;
+    // batch statistics of z come out of the conv epilogue (sum / sum of squares per channel, double atomics)
+    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
+    HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)cl.cout * sizeof(double), c.s));
+    d.stat_sum = ds;
+    d.stat_sq = ds + cl.cout;
     return hn_launch_conv(d, c.s);
 }
 
-// z -> batch statistics -> y = act(bn(z) (+res)); updates the running statistics in place
+// batch statistics (left in `dstat` by conv_z of the same unit, which must be the last conv launched) ->
+// y = act(bn(z) (+res)); updates the running statistics in place
 int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float momentum)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
@@ -137,8 +143,6 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
     float* st = c.W + u.st;
     int rc;
-    HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
-    if ((rc = hn_launch_col_stats(c.W + u.z, ds, ds + C, u.M, C, C, c.s))) return rc;
     if ((rc = hn_launch_bn_finalize(ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
                                     c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
                                     st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
