@@ -66,14 +66,14 @@ int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r
 int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh_f, const float* whh_r, float* dh, int B, hipStream_t s);
 int hn_launch_transpose(const float* in, float* out, int R, int C, hipStream_t s);
 int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s);
-int hn_launch_bn_bwd_reduce(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd, double* S1,
+int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd, double* S1,
                             double* S2, long M, int C, hipStream_t s);
 int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float* a, float* b, float* save_mean, float* save_invstd, int C,
                           hipStream_t s);
-int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, long M, int C, int relu,
-                         hipStream_t s);
-int hn_launch_bn_bwd_apply(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd,
+int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, long M, int C,
+                         int relu, hipStream_t s);
+int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, long M, int C,
                            hipStream_t s);
 int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);

@@ -17,7 +17,7 @@ struct Unit {
     int Hi, Wi, sh, sw, Ho, Wo;
     int relu;                      // ReLU directly after this unit's BN (conv3 / downsample: 0)
     int stem;
-    size_t x, z, y, st;            // float offsets: input, pre-BN, post-activation, [mean|invstd|a|b]
+    size_t x, z, y, st, mk;        // float offsets: input, pre-BN, post-activation, [mean|invstd|a|b], ReLU bit mask (1 byte per 4 outputs)
     long M;
 };
 
@@ -50,6 +50,7 @@ TrainPlan make_train_plan(int B)
         u.z = take((size_t)u.M * c.cout);
         u.y = take((size_t)u.M * c.cout);
         u.st = take(4 * (size_t)c.cout);
+        u.mk = take(((size_t)u.M * c.cout / 4 + 3) / 4);
         p.units.push_back(u);
         return (int)p.units.size() - 1;
     };
@@ -147,7 +148,7 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
                                     c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
                                     st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
         return rc;
-    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, u.M, C, relu, c.s);
+    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, reinterpret_cast<unsigned char*>(c.W + u.mk), u.M, C, relu, c.s);
 }
 
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
@@ -159,12 +160,14 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     const int C = cl.cout;
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
     const float* st = c.W + u.st;
+    // ymask != null: the unit ends in a ReLU; the adjoint reads the bit mask its affine_act pass stored (1/16 of y's bytes)
+    const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
     HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
-    if ((rc = hn_launch_bn_bwd_reduce(dy, ymask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.s))) return rc;
+    if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
-    if ((rc = hn_launch_bn_bwd_apply(dy, ymask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M, dz, dpre,
+    if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M, dz, dpre,
                                      u.M, C, c.s)))
         return rc;
     if (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) {

@@ -9,10 +9,10 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Column reductions over a row-major [M][C] matrix.  MODE 0: sum(a), sum(a*a)           (BN statistics, bias grads)
-//                                                    MODE 1: sum(g), sum(g * (z - mean) * invstd)   with g = dy * (y > 0 | 1)
+//                                                    MODE 1: sum(g), sum(g * (z - mean) * invstd)   with g = dy * (ReLU mask | 1)
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ ymask,
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const unsigned char* __restrict__ bmask,
                                                          const float* __restrict__ z, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, double* __restrict__ out0,
                                                          double* __restrict__ out1, long M, int C, int lda, int slab)
@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                 a1 += v * v;
             } else {
                 const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * (long)C + col);
-                if (ymask) {
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(ymask + r * (long)C + col);
+                if (bmask) {                 // ReLU mask of the forward pass, 4 bits per float4 (affine_act_kernel)
+                    const unsigned mk = bmask[(r * (long)C + col) >> 2];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
+                    for (int k = 0; k < 4; ++k) v[k] = (mk >> k) & 1u ? v[k] : 0.f;
                 }
                 a0 += v;
                 a1 += v * ((zz - mu) * is);
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sum, con
 // y = act(z * a[c] + b[c] (+ res))
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
-                                                         float* __restrict__ y, long total4, int C4, int relu)
+                                                         float* __restrict__ y, unsigned char* __restrict__ bmask, long total4, int C4,
+                                                         int relu)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
@@ -115,15 +116,20 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
         v = v * *reinterpret_cast<const f32x4*>(a + c) + *reinterpret_cast<const f32x4*>(b + c);
         if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
         if (relu) {
+            unsigned mk = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            for (int k = 0; k < 4; ++k) {
+                mk |= (v[k] > 0.f ? 1u : 0u) << k;
+                v[k] = fmaxf(v[k], 0.f);
+            }
+            if (bmask) bmask[i] = (unsigned char)mk;     // the adjoint reads 1 byte instead of 16 (y > 0)
         }
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
     }
 }
 
 // BN backward apply: g = dy * mask;  dz = gamma*invstd * (g - S1/N - zhat * S2/N);  optional dpre = g (identity branch)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ bmask,
                                                            const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ S1, const double* __restrict__ S2, double n,
@@ -132,10 +138,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
-        if (ymask) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(ymask + i * 4);
+        if (bmask) {
+            const unsigned mk = bmask[i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
+            for (int k = 0; k < 4; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
         }
         const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
         f32x4 o;
@@ -376,19 +382,19 @@ int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int 
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "col_stats: unsupported C=%d", C);
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
-    hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr,
+    hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, s, a, (const unsigned char*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
-int hn_launch_bn_bwd_reduce(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd, double* S1,
+int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd, double* S1,
                             double* S2, long M, int C, hipStream_t s)
 {
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "bn_bwd_reduce: unsupported C=%d", C);
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
-    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, ymask, z, mean, invstd, S1, S2, M, C, C, slab);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, bmask, z, mean, invstd, S1, S2, M, C, C, slab);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -403,21 +409,21 @@ int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, cons
     return 0;
 }
 
-int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, long M, int C, int relu,
-                         hipStream_t s)
+int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, long M, int C,
+                         int relu, hipStream_t s)
 {
     const long total4 = M * C / 4;
-    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, total4, C / 4, relu);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, bmask, total4, C / 4, relu);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
-int hn_launch_bn_bwd_apply(const float* dy, const float* ymask, const float* z, const float* mean, const float* invstd,
+int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, long M, int C,
                            hipStream_t s)
 {
     const long total4 = M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, ymask, z, mean, invstd, gamma, S1, S2, n, dz,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, bmask, z, mean, invstd, gamma, S1, S2, n, dz,
                        dpre, total4, C / 4);
     HN_LAUNCH_CHECK();
     return 0;
