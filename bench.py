@@ -333,7 +333,7 @@ def main():
             out["bf16_mode"] = {"value": round(B / dt, 1), "unit": "panoramas/s", "ms_per_step": round(dt * 1e3, 3),
                                 "max_abs_vs_f32_outputs": round(float(max((hb - bon).abs().max(), (hc - cor).abs().max())), 6),
                                 "note": "bf16 MFMA convs, f32 accumulate/LSTM/head; single GPU; not the fp32 configuration the headline value is quoted on"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU reference leg runs on rank 0 of the single-GPU job only
             out["cpu_baseline"] = cpu_baseline()
             out["pano_stretch"] = pano_stretch_leg(dev)
             out["augment_pipeline"] = augment_leg(dev)
