@@ -15,6 +15,7 @@
 #include "hn_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -39,6 +40,12 @@ struct ConvArgsH {
     int M, K, nk, relu, ldy;
     int xstride;
     int xcd_swizzle;
+    double* stat_sum;    // optional per-channel sum / sum of squares of the stored rows (train-mode BatchNorm statistics)
+    double* stat_sq;
+    // data-gradient mode (template TR), see conv_igemm_f32.hip: one launch = one stride-parity class of dX pixels
+    int sh_log2, sw_log2;
+    int ca, cb, cHo, cWo;
+    int tdh[3], tdw[3], ntdh, ntdw;
 };
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, unsigned voff, unsigned soff)
@@ -57,9 +64,12 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32>
+// OUT_F32: the output AND the residual are float32 (train-mode z / dX (+ identity gradient), LSTM gate pre-activations).
+// TR: data-gradient mode (x = dY bf16 on the (Hi,Wi) grid, y = dX on the (Ho,Wo) grid, per-class tap lists).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32, bool TR>
 __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
 {
+    static_assert(!(STEM && TR), "the stem has no data gradient");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
-    const int hw_out = p.Ho * p.Wo;
+    const int hw_out = TR ? p.cHo * p.cWo : p.Ho * p.Wo;
     const int b_first = m0 / hw_out;
     const size_t img_elems = (size_t)p.Hi * p.Wi * (STEM ? 8 : p.xstride);
     const __amdgpu_buffer_rsrc_t rsrc_a =
@@ -104,13 +114,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     for (int q = 0; q < AP; ++q) {
         const int m = m0 + lrow + 32 * q;
         if (m < p.M) {
-            const int wo = m % p.Wo;
-            const int t = m / p.Wo;
-            const int ho = t % p.Ho;
-            const int b = t / p.Ho;
+            const int gw = TR ? p.cWo : p.Wo, gh = TR ? p.cHo : p.Ho;
+            const int wo = m % gw;
+            const int t = m / gw;
+            const int ho = t % gh;
+            const int b = t / gh;
             a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
-            a_hi0[q] = ho * p.sh - p.ph;
-            a_wi0[q] = wo * p.sw - p.pw;
+            a_hi0[q] = TR ? p.ca + p.sh * ho + p.ph : ho * p.sh - p.ph;
+            a_wi0[q] = TR ? p.cb + p.sw * wo + p.pw : wo * p.sw - p.pw;
         } else {
             a_pix0[q] = -1;
             a_hi0[q] = 0;
@@ -125,11 +136,23 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     auto tap_offsets = [&](int dh, int dw) {
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
-            const int hi = a_hi0[q] + dh;
-            int wi = a_wi0[q] + (STEM ? lcol : dw);
-            wi = wi < 0 ? wi + p.Wi : wi;
-            wi = wi >= p.Wi ? wi - p.Wi : wi;
-            const bool ok = (a_pix0[q] >= 0) && ((unsigned)hi < (unsigned)p.Hi);
+            int hi, wi;
+            bool ok = a_pix0[q] >= 0;
+            if (TR) {                                            // dh / dw index the class's tap lists
+                const int th = a_hi0[q] - p.tdh[dh];
+                int tw = a_wi0[q] - p.tdw[dw];
+                tw = tw < 0 ? tw + p.Wo : tw;                     // circular on the dX grid (width Wo)
+                tw = tw >= p.Wo ? tw - p.Wo : tw;
+                hi = th >> p.sh_log2;
+                wi = tw >> p.sw_log2;
+                ok = ok && th >= 0 && hi < p.Hi;
+            } else {
+                hi = a_hi0[q] + dh;
+                wi = a_wi0[q] + (STEM ? lcol : dw);
+                wi = wi < 0 ? wi + p.Wi : wi;
+                wi = wi >= p.Wi ? wi - p.Wi : wi;
+                ok = ok && ((unsigned)hi < (unsigned)p.Hi);
+            }
             const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
             const unsigned off = STEM ? pix * 16u : (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u;
             a_off[q] = ok ? off : OOB;
@@ -153,8 +176,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
             c0 += BKE;
             if (c0 == p.Cin) {
                 c0 = 0;
-                if (++dw == p.KW) { dw = 0; ++dh; }
-                tap_offsets(dh, dw);
+                if (++dw == (TR ? p.ntdw : p.KW)) { dw = 0; ++dh; }
+                if (!TR || dh < p.ntdh) tap_offsets(dh, dw);
             }
         }
     };
@@ -171,9 +194,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     const int half = lane >> 5;
     const int fswz = (fr >> 1) & 7;
 
-    fetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!TR || p.nk > 0) {      // a parity class no tap reaches (1x1 stride 2) has K = 0: dX = add there
+        fetch(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     {
         u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
@@ -194,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                                         acc[i][j], 0, 0, 0);
         };
-        ldfrag(fa0, fb0, 0, 0);
+        if (!TR || p.nk > 0) ldfrag(fa0, fb0, 0, 0);
         for (int kc = 0; kc < p.nk; ++kc) {
             const int buf = kc & 1;
             const bool more = kc + 1 < p.nk;
@@ -223,17 +248,34 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     float* cs = reinterpret_cast<float*>(smem);
     const int ccol = (tid % TPR) * 8;
     const int crow = tid / TPR;
+    // output pixel of GEMM row m: dense, except in data-gradient mode where the rows enumerate one parity class
+    auto out_pix = [&](int m) -> size_t {
+        if (!TR) return (size_t)m;
+        const int wo = m % p.cWo;
+        const int t = m / p.cWo;
+        const int ho = t % p.cHo;
+        const int b = t / p.cHo;
+        return ((size_t)b * p.Ho + (p.ca + p.sh * ho)) * p.Wo + (p.cb + p.sw * wo);
+    };
     auto epilogue = [&](auto has_res) {
         constexpr bool HAS_RES = decltype(has_res)::value;
-        u32x4 rres[HAS_RES ? WAVES_M * NPS : 1];
+        u32x4 rres[HAS_RES ? WAVES_M * NPS : 1];            // bf16 residual: 8 channels
+        f32x4 rres_lo[HAS_RES && OUT_F32 ? WAVES_M * NPS : 1], rres_hi[HAS_RES && OUT_F32 ? WAVES_M * NPS : 1];   // f32 residual
         if (HAS_RES) {
 #pragma unroll
             for (int ps = 0; ps < WAVES_M * NPS; ++ps) {
                 const int m = m0 + (ps / NPS) * EROWS + crow + (ps % NPS) * RPP;
                 const int mc = m < p.M ? m : p.M - 1;
-                rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
+                if (OUT_F32) {
+                    const float* rp = reinterpret_cast<const float*>(p.res) + out_pix(mc) * p.Cout + n0 + ccol;
+                    rres_lo[ps] = *reinterpret_cast<const f32x4*>(rp);
+                    rres_hi[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                } else {
+                    rres[ps] = *reinterpret_cast<const u32x4*>(p.res + out_pix(mc) * p.Cout + n0 + ccol);
+                }
             }
         }
+        f32x4 st1a = {0.f, 0.f, 0.f, 0.f}, st1b = st1a, st2a = st1a, st2b = st1a;     // BN statistics of this thread's 8 columns
         const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
         const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol + 4);
         const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
@@ -262,37 +304,65 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                 v0 = v0 * sc0 + sf0;
                 v1 = v1 * sc1 + sf1;
                 if (HAS_RES) {
-                    const u32x4 rr = rres[h * NPS + ps];
-                    v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
-                    v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+                    if (OUT_F32) {
+                        v0 += rres_lo[h * NPS + ps];
+                        v1 += rres_hi[h * NPS + ps];
+                    } else {
+                        const u32x4 rr = rres[h * NPS + ps];
+                        v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
+                        v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+                    }
                 }
                 if (p.relu) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
                 }
                 if (m < p.M) {
+                    st1a += v0; st1b += v1;
+                    st2a += v0 * v0; st2b += v1 * v1;
                     if (OUT_F32) {
-                        float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n0 + ccol;
+                        float* yo = reinterpret_cast<float*>(p.y) + out_pix(m) * p.ldy + n0 + ccol;
                         *reinterpret_cast<f32x4*>(yo) = v0;
                         *reinterpret_cast<f32x4*>(yo + 4) = v1;
                     } else {
                         u32x4 o;
                         o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                         o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + n0 + ccol) = o;
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + out_pix(m) * p.ldy + n0 + ccol) = o;
                     }
                 }
+            }
+        }
+        if (p.stat_sum) {        // see conv_igemm_f32.hip: per-channel sums of the stored tile -> one f64 atomic per channel
+            __syncthreads();
+            float* red = cs;                         // [2][RPP][BN]
+            if (crow < RPP) {
+                *reinterpret_cast<f32x4*>(red + crow * BN + ccol) = st1a;
+                *reinterpret_cast<f32x4*>(red + crow * BN + ccol + 4) = st1b;
+                *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol) = st2a;
+                *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol + 4) = st2b;
+            }
+            __syncthreads();
+            if (tid < BN) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) {
+                    a1 += red[r * BN + tid];
+                    a2 += red[(RPP + r) * BN + tid];
+                }
+                atomicAdd(p.stat_sum + n0 + tid, (double)a1);
+                atomicAdd(p.stat_sq + n0 + tid, (double)a2);
             }
         }
     };
     if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32, bool TR = false>
 int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
 {
     const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    auto kern = conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STEM, OUT_F32>;
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STEM, OUT_F32, TR>;
     static bool attr_done[64] = {};   // per instantiation, per device
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));
@@ -307,21 +377,21 @@ int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
     return 0;
 }
 
-template <bool OUT_F32>
-int dispatch(const ConvArgsH& a, const ConvDesc& d, hipStream_t s)
+template <bool OUT_F32, bool TR = false>
+int dispatch(const ConvArgsH& a, int Cout, hipStream_t s)
 {
     const long M = a.M;
-    if (d.Cout % 128 == 0) {
-        const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 128);
-        if (blocks128 >= 512) return launch_cfg_h<128, 128, 2, 2, false, OUT_F32>(a, s);
-        return launch_cfg_h<64, 128, 2, 2, false, OUT_F32>(a, s);
+    if (Cout % 128 == 0) {
+        const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 128);
+        if (blocks128 >= 512) return launch_cfg_h<128, 128, 2, 2, false, OUT_F32, TR>(a, s);
+        return launch_cfg_h<64, 128, 2, 2, false, OUT_F32, TR>(a, s);
     }
-    if (d.Cout % 64 == 0) {
-        const long blocks128 = (long)hn_cdiv(M, 128) * (d.Cout / 64);
-        if (blocks128 >= 512) return launch_cfg_h<128, 64, 2, 2, false, OUT_F32>(a, s);
-        return launch_cfg_h<64, 64, 2, 2, false, OUT_F32>(a, s);
+    if (Cout % 64 == 0) {
+        const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 64);
+        if (blocks128 >= 512) return launch_cfg_h<128, 64, 2, 2, false, OUT_F32, TR>(a, s);
+        return launch_cfg_h<64, 64, 2, 2, false, OUT_F32, TR>(a, s);
     }
-    return launch_cfg_h<128, 32, 4, 1, false, OUT_F32>(a, s);
+    return launch_cfg_h<128, 32, 4, 1, false, OUT_F32, TR>(a, s);
 }
 
 // ---- bf16 helper kernels -------------------------------------------------------------------------
@@ -433,6 +503,24 @@ __global__ __launch_bounds__(256) void pack_conv_bf16_kernel(const float* __rest
     }
 }
 
+// OIHW f32 -> per-class data-gradient packing [Cin][ndh][ndw][Cout] in bf16 (only the taps that reach the class)
+__global__ __launch_bounds__(256) void pack_dgrad_class_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout, int Cin,
+                                                                    int KH, int KW, int dh0, int dh1, int dh2, int ndh, int dw0, int dw1,
+                                                                    int dw2, int ndw)
+{
+    const long total = (long)Cin * ndh * ndw * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Cout);
+        long t = i / Cout;
+        const int iw = (int)(t % ndw);
+        t /= ndw;
+        const int ih = (int)(t % ndh);
+        const int c = (int)(t / ndh);
+        const int dh = ih == 0 ? dh0 : (ih == 1 ? dh1 : dh2), dw = iw == 0 ? dw0 : (iw == 1 ? dw1 : dw2);
+        out[i] = (u16)(pack_bf16(w[(((long)o * Cin + c) * KH + dh) * KW + dw], 0.f) & 0xffffu);
+    }
+}
+
 inline unsigned grid_for(long total, long cap = 256L * 16)
 {
     long g = (total + 255) / 256;
@@ -457,23 +545,75 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;
     a.ldy = d.ldy ? d.ldy : d.Cout;
+    a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq;
+    a.sh_log2 = a.sw_log2 = a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
+    for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;
+    HN_REQUIRE(!d.res || !out_f32, "conv bf16: a residual with float32 output is only used by the data-gradient launcher");
     {
         const double span = 128.0 / ((double)d.Ho * d.Wo) + 2.0;
         HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 8 : a.xstride) * 2.0 < 2147483648.0, "conv bf16: image too large for 32-bit tile offsets");
     }
     if (d.stem) {
         HN_REQUIRE(d.KH == 7 && d.KW == 7 && d.Cout == 64, "stem conv bf16: expects 7x7, Cout=64");
-        HN_REQUIRE(!out_f32 && d.Ho * d.Wo >= 128, "stem conv bf16: bf16 output, image >= one tile");
+        HN_REQUIRE(d.Ho * d.Wo >= 128, "stem conv bf16: image >= one tile");
         a.K = 7 * BKE;
         a.nk = 7;
-        return launch_cfg_h<128, 64, 2, 2, true, false>(a, s);
+        return out_f32 ? launch_cfg_h<128, 64, 2, 2, true, true>(a, s) : launch_cfg_h<128, 64, 2, 2, true, false>(a, s);
     }
     HN_REQUIRE(d.Cin % BKE == 0, "conv bf16: Cin=%d must be a multiple of %d", d.Cin, BKE);
     HN_REQUIRE(d.Cout % 32 == 0, "conv bf16: Cout=%d must be a multiple of 32", d.Cout);
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BKE;
     HN_REQUIRE(128.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
-    return out_f32 ? dispatch<true>(a, d, s) : dispatch<false>(a, d, s);
+    return out_f32 ? dispatch<true>(a, d.Cout, s) : dispatch<false>(a, d.Cout, s);
+}
+
+// Data gradient of a forward conv on the bf16 matrix cores (see hn_launch_conv_dgrad in conv_igemm_f32.hip):
+// dz_h: bf16 [B][Ho][Wo][Cout]; w_oihw: the float32 master weights (re-packed per class into w_scratch as bf16);
+// add (optional) and dx are float32.  Needs Cout %% 64 == 0 (one K chunk = 64 bf16 channels of one tap).
+int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
+                              const float* ones, const float* zeros, hipStream_t s)
+{
+    static const char* env = getenv("HN_XCD_SWIZZLE");
+    HN_REQUIRE((d.sh == 1 || d.sh == 2) && (d.sw == 1 || d.sw == 2) && !d.stem, "conv dgrad bf16: strides must be 1 or 2");
+    HN_REQUIRE(d.Cout % BKE == 0 && d.Cin % 32 == 0, "conv dgrad bf16: Cout %% 64 / Cin %% 32");
+    HN_REQUIRE(d.Hi % d.sh == 0 && d.Wi % d.sw == 0, "conv dgrad bf16: input size must be a multiple of the stride");
+    u16* wp = reinterpret_cast<u16*>(w_scratch);
+    for (int ca = 0; ca < d.sh; ++ca) {
+        for (int cb = 0; cb < d.sw; ++cb) {
+            ConvArgsH a;
+            memset(&a, 0, sizeof(a));
+            a.xcd_swizzle = env ? atoi(env) : 1;
+            a.x = reinterpret_cast<const u16*>(dz_h); a.scale = ones; a.shift = zeros;
+            a.res = reinterpret_cast<const u16*>(add);        // float32 in OUT_F32 mode (the kernel reinterprets)
+            a.y = dx;
+            a.Hi = d.Ho; a.Wi = d.Wo; a.Cin = d.Cout; a.Ho = d.Hi; a.Wo = d.Wi; a.Cout = d.Cin;
+            a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
+            a.sh_log2 = d.sh == 2 ? 1 : 0; a.sw_log2 = d.sw == 2 ? 1 : 0;
+            a.xstride = d.Cout; a.relu = 0; a.ldy = d.Cin;
+            a.ca = ca; a.cb = cb; a.cHo = d.Hi / d.sh; a.cWo = d.Wi / d.sw;
+            for (int t = 0; t < d.KH; ++t) if ((ca + d.ph - t) % d.sh == 0) a.tdh[a.ntdh++] = t;
+            for (int t = 0; t < d.KW; ++t) if ((cb + d.pw - t) % d.sw == 0) a.tdw[a.ntdw++] = t;
+            a.M = d.B * a.cHo * a.cWo;
+            a.K = a.ntdh * a.ntdw * d.Cout;
+            a.nk = a.K / BKE;
+            if (a.K > 0) {
+                const long total = (long)d.Cin * a.K;
+                hipLaunchKernelGGL(pack_dgrad_class_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, w_oihw, wp, d.Cout, d.Cin, d.KH,
+                                   d.KW, a.tdh[0], a.tdh[1], a.tdh[2], a.ntdh, a.tdw[0], a.tdw[1], a.tdw[2], a.ntdw);
+                HN_LAUNCH_CHECK();
+            }
+            a.w = wp;
+            {
+                const double span = 128.0 / ((double)a.cHo * a.cWo) + 2.0;
+                HN_REQUIRE(span * a.Hi * a.Wi * (double)a.xstride * 2.0 < 2147483648.0, "conv dgrad bf16: image too large for 32-bit tile offsets");
+                HN_REQUIRE(128.0 * a.K * 2.0 < 2147483648.0, "conv dgrad bf16: K too large");
+            }
+            if (int rc = dispatch<true, true>(a, d.Cin, s)) return rc;
+            wp += (size_t)d.Cin * a.K;
+        }
+    }
+    return 0;
 }
 
 int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s)

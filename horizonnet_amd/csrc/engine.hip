@@ -499,6 +499,30 @@ extern "C" int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const 
     return hn_launch_conv_dgrad(d, dz, w_oihw, add, dx, w_scratch, ones, zeros, s);
 }
 
+// bf16-MFMA form of the data gradient: dz is rounded to bf16 (into the scratch), weights re-packed per class as bf16,
+// add / dx stay float32.  w_scratch: Cout*Cin*KH*KW + 8192 floats (weights + ones/zeros) followed by B*Ho*Wo*Cout/2 floats.
+extern "C" int hn_conv2d_dgrad_nhwc_bf16(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
+                                         int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream)
+{
+    HN_REQUIRE(dz && w_oihw && dx && w_scratch, "hn_conv2d_dgrad_nhwc_bf16: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_dgrad_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
+    HN_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 4096 && Cout <= 4096, "hn_conv2d_dgrad_nhwc_bf16: Cin %% 32, Cout %% 64, <= 4096");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    float* ones = w_scratch + (size_t)Cout * Cin * KH * KW;
+    float* zeros = ones + 4096;
+    if ((rc = hn_launch_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, ones, zeros, 4096, s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = B; d.Hi = Hx; d.Wi = Wx; d.Cin = Cin; d.Cout = Cout; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw; d.ph = KH / 2; d.pw = KW / 2;
+    d.Ho = (Hx + 2 * d.ph - KH) / sh + 1;
+    d.Wo = (Wx + 2 * d.pw - KW) / sw + 1;
+    void* dz_h = zeros + 4096;
+    const long n = (long)B * d.Ho * d.Wo * Cout;
+    if ((rc = hn_launch_f32_to_bf16(dz, dz_h, n, s))) return rc;
+    return hn_launch_conv_dgrad_bf16(d, dz_h, w_oihw, add, dx, w_scratch, ones, zeros, s);
+}
+
 extern "C" int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
                                     int Cout, int KH, int KW, int sh, int sw, int stem, void* stream)
 {

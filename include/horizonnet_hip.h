@@ -220,6 +220,12 @@ int hn_linear_head(const float* y, const float* w, const float* bias, float* bon
 int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
                          int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
 
+/* The same data gradient on the bf16 matrix cores (train_precision "bf16"): dz is rounded to bf16, the weights are
+ * re-packed per stride-parity class as bf16, accumulation / add / dx stay float32.  Cout %% 64 == 0.
+ * w_scratch: Cout*Cin*KH*KW + 8192 floats followed by B*Ho*Wo*Cout/2 floats (the bf16 copy of dz). */
+int hn_conv2d_dgrad_nhwc_bf16(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
+                              int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
+
 /* Weight gradient of hn_conv2d_nhwc / the stem conv: dw_oihw [Cout][Cin][KH][KW] = sum_m dz[m][n] * patch(x)[m][k].
  * stem != 0: x is the NHWC4 normalised image and the conv is the 7x7/2 stem.  scratch: Cout*max(KH*KW*Cin, 256) floats. */
 int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,

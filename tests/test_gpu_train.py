@@ -73,6 +73,28 @@ def test_conv_dgrad_wgrad_stage(case):
     assert ok
 
 
+@pytest.mark.parametrize("case", [c for c in GRAD_CASES if c[5] % 64 == 0], ids=[c[0] for c in GRAD_CASES if c[5] % 64 == 0])
+def test_conv_dgrad_bf16_stage(case):
+    """Data gradient on the bf16 matrix cores == torch autograd on the bf16-rounded operands (products of bf16 values are
+    exact in f32, so only the f32 summation order differs)."""
+    name, B, H, W, cin, cout, k, stride = case
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    r16 = lambda t: t.bfloat16().float()                                                    # noqa: E731
+    x = _rand((B, H, W, cin), 1).requires_grad_(True)
+    w = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    w16 = r16(w).requires_grad_(True)
+    y = _conv_ref(x, w16, (sh, sw))
+    dz = _rand(tuple(y.shape), 3)
+    add = _rand((B, H, W, cin), 4)
+    y.backward(r16(dz))
+    dzd, wd, addd = dz.contiguous().to(DEV), w.to(DEV), add.to(DEV)
+    dx = torch.full((B, H, W, cin), float("nan"), device=DEV)
+    scr = torch.empty(cout * cin * k * k + 8192 + dz.numel() // 2 + 64, device=DEV)
+    _lib.check(lib().hn_conv2d_dgrad_nhwc_bf16(P(dzd), P(wd), P(addd), P(dx), P(scr), B, H, W, cin, cout, k, k, sh, sw, sp()), "dgrad bf16")
+    torch.cuda.synchronize()
+    assert report("dgrad bf16 " + name, dx.cpu().numpy(), (x.grad + add).numpy(), 3e-5 * max(1.0, float(x.grad.abs().max())))
+
+
 def test_stem_wgrad_stage():
     B, H, W = 2, 32, 64
     x = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5))
