@@ -127,7 +127,7 @@ def augment_leg(dev, n_img=64, iters=10):
             "max_ulp_vs_oracle": ulp}
 
 
-def train_leg(dev, world, B, steps, warmup, dist):
+def train_leg(dev, world, B, steps, warmup, dist, dtype="f32"):
     """Training step of reference train.py:272-281 on the engine: train-mode forward, L1(bon) + BCE-with-logits(cor)
     (train.py:53-54), backward (all 241 gradients), data-parallel all-reduce when world > 1, Adam (lr 1e-4).
     float32; synthetic inputs and labels resident in HBM."""
@@ -137,6 +137,7 @@ def train_leg(dev, world, B, steps, warmup, dist):
     net = HorizonNet("resnet50", True)
     net.load_state_dict(make_state_dict(0, "random"))
     net = net.to(dev).train()
+    net.train_precision = dtype          # bf16: forward + data-gradient convs on the bf16 matrix cores, rest f32
     broadcast_module_(net)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), fused=True)
     g = torch.Generator().manual_seed(2000 + (dist.get_rank() if dist else 0))
@@ -172,8 +173,9 @@ def train_leg(dev, world, B, steps, warmup, dist):
     flop = 3.0 * FWD_FLOP_PER_PANO * B * world * steps          # fwd + dgrad + wgrad
     return {"metric": "training panoramas/s (512x1024, fwd+bwd+Adam)", "value": round(B * world * steps / wall, 2),
             "unit": "panoramas/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train.py step on synthetic data (L1 + BCE losses, Adam), fp32 -- BASELINE configs[2] is bf16 batch 64; this is the fp32 engine",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "train.py step on synthetic data (L1 + BCE losses, Adam); %s (BASELINE configs[2]: bf16, batch 64)"
+                                   % ("float32 engine" if dtype == "f32" else "bf16 MFMA forward + data-gradient convs, f32 accumulation / BN / weight gradients / LSTM / master weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (RCCL all-reduce of the flat 326 MB gradient buffer)" % world},
             "roofline": {"bound": "mfma", "achieved": round(flop / wall / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flop / wall / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None},
@@ -207,7 +209,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     if args.mode == "train":
-        out = train_leg(dev, world, args.batch, args.steps, args.warmup, dist)
+        out = train_leg(dev, world, args.batch, args.steps, args.warmup, dist, args.dtype)
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:

@@ -38,9 +38,11 @@ SIGNATURES = {
     "hn_train_backward_segment": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _f, _c.c_uint64, _i, _vp]),
     "hn_grad_segments": (_i, []),
     "hn_grad_segment_range": (_i, [_i, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "hn_set_train_precision": (_i, [_vp, _i]),
     "hn_grad_floats": (_sz, []),
     "hn_train_debug_unit": (_i, [_i, _i, _c.POINTER(_i64)]),
     "hn_train_debug_set": (_i, [_vp, _i, _vp, _vp]),
+    "hn_train_debug_set2": (_i, [_vp, _i, _vp, _vp]),
     "hn_grad_offset": (_i64, [_c.c_char_p]),
     "hn_conv2d_dgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_conv2d_dgrad_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -30,6 +30,12 @@ const HOff& hoff()
     return H;
 }
 
+}  // namespace
+
+size_t hn_bf16_conv_offset(int ci) { return hoff().conv[ci]; }
+
+namespace {
+
 struct PlanH {                     // byte offsets
     size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y1h, y2, total;
 };

@@ -58,10 +58,14 @@ struct hn_engine {
     std::unordered_map<std::string, const void*> bound;
     const float* packed = nullptr;       // last packed buffer (caller owned)
     const void* packed_h = nullptr;      // last bf16 weight buffer (hn_pack_weights_bf16, caller owned)
+    int train_bf16 = 0;                  // 1: train-mode convs (forward + data gradient) on the bf16 matrix cores (hn_set_train_precision)
     bool profiling = false;
     int debug_unit = -1;                 // training debug tap (hn_train_debug_set): unit whose dy / dz are copied out
     float* debug_dy = nullptr;
     float* debug_dz = nullptr;
+    int debug_unit2 = -1;                // second tap (hn_train_debug_set2): lets a test read two units of the SAME backward pass
+    float* debug_dy2 = nullptr;
+    float* debug_dz2 = nullptr;
     std::vector<ProfEntry> prof;         // entries of the last profiled hn_forward
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -94,3 +98,5 @@ struct ProfScope {
     }
 };
 
+// element offset of conv `ci`'s packed bf16 weights inside the hn_pack_weights_bf16 buffer (engine_bf16.hip)
+size_t hn_bf16_conv_offset(int ci);

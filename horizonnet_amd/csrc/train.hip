@@ -18,12 +18,14 @@ struct Unit {
     int relu;                      // ReLU directly after this unit's BN (conv3 / downsample: 0)
     int stem;
     size_t x, z, y, st, mk;        // float offsets: input, pre-BN, post-activation, [mean|invstd|a|b], ReLU bit mask (1 byte per 4 outputs)
+    size_t xh, yh;                 // float offsets of the bf16 copies of the input / of y (train_precision bf16)
     long M;
 };
 
 struct TrainPlan {
     std::vector<Unit> units;
     int blk[4][6], dsu[4], ghc[4];         // unit indices
+    size_t xn8, poolh, dzh[2];             // bf16: NHWC8 normalised image, max-pool output, two dz staging buffers
     size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
     size_t gmax;
 };
@@ -39,7 +41,8 @@ TrainPlan make_train_plan(int B)
     const size_t b = (size_t)B;
     p.sync = take(HN_SYNC_WORDS);
     p.xn = take(b * IMG_H * IMG_W * 4);
-    auto add_unit = [&](int ci, size_t x, int Hi, int Wi, int sh, int sw, int relu, int stem) {
+    p.xn8 = take(b * IMG_H * IMG_W * 4);          // 8 bf16 per pixel
+    auto add_unit = [&](int ci, size_t x, size_t xh, int Hi, int Wi, int sh, int sw, int relu, int stem) {
         const ConvLayer& c = a.convs[ci];
         Unit u;
         u.ci = ci; u.Hi = Hi; u.Wi = Wi; u.sh = sh; u.sw = sw; u.relu = relu; u.stem = stem;
@@ -47,36 +50,41 @@ TrainPlan make_train_plan(int B)
         u.Wo = (Wi + 2 * (c.k / 2) - c.k) / sw + 1;
         u.M = (long)B * u.Ho * u.Wo;
         u.x = x;
+        u.xh = xh;
         u.z = take((size_t)u.M * c.cout);
         u.y = take((size_t)u.M * c.cout);
         u.st = take(4 * (size_t)c.cout);
         u.mk = take(((size_t)u.M * c.cout / 4 + 3) / 4);
+        u.yh = take((size_t)u.M * c.cout / 2);
         p.units.push_back(u);
         return (int)p.units.size() - 1;
     };
-    const int us = add_unit(a.stem, p.xn, IMG_H, IMG_W, 2, 2, 1, 1);
+    const int us = add_unit(a.stem, p.xn, p.xn8, IMG_H, IMG_W, 2, 2, 1, 1);
     (void)us;
     p.pool = take(b * 128 * 256 * 64);
-    size_t cur = p.pool;
+    p.poolh = take(b * 128 * 256 * 64 / 2);
+    size_t cur = p.pool, curh = p.poolh;
     int H = 128, W = 256;
     for (int li = 0; li < 4; ++li) {
         for (int j = 0; j < kBlocks[li]; ++j) {
             const int stride = (j == 0 && li > 0) ? 2 : 1;
-            const int c1 = add_unit(a.block_first[li][j], cur, H, W, 1, 1, 1, 0);
-            const int c2 = add_unit(a.block_first[li][j] + 1, p.units[c1].y, H, W, stride, stride, 1, 0);
-            if (j == 0) p.dsu[li] = add_unit(a.block_down[li], cur, H, W, stride, stride, 0, 0);
+            const int c1 = add_unit(a.block_first[li][j], cur, curh, H, W, 1, 1, 1, 0);
+            const int c2 = add_unit(a.block_first[li][j] + 1, p.units[c1].y, p.units[c1].yh, H, W, stride, stride, 1, 0);
+            if (j == 0) p.dsu[li] = add_unit(a.block_down[li], cur, curh, H, W, stride, stride, 0, 0);
             H /= stride;
             W /= stride;
-            const int c3 = add_unit(a.block_first[li][j] + 2, p.units[c2].y, H, W, 1, 1, 0, 0);
+            const int c3 = add_unit(a.block_first[li][j] + 2, p.units[c2].y, p.units[c2].yh, H, W, 1, 1, 0, 0);
             p.blk[li][j] = c1;                    // c2 = c1 + 1; (ds = c1 + 2 when j == 0); c3 = last
             cur = p.units[c3].y;
+            curh = p.units[c3].yh;
         }
-        size_t gin = cur;
+        size_t gin = cur, ginh = curh;
         int gh = H;
         for (int k = 0; k < 4; ++k) {
-            const int u = add_unit(a.ghc_first[li] + k, gin, gh, W, 2, 1, 1, 0);
+            const int u = add_unit(a.ghc_first[li] + k, gin, ginh, gh, W, 2, 1, 1, 0);
             if (k == 0) p.ghc[li] = u;
             gin = p.units[u].y;
+            ginh = p.units[u].yh;
             gh /= 2;
         }
     }
@@ -92,6 +100,7 @@ TrainPlan make_train_plan(int B)
     p.dlin = take(rows * 12);
     p.gmax = b * 256 * 512 * 64;                 // largest gradient tensor: d(stem output)
     for (int i = 0; i < 4; ++i) p.G[i] = take(p.gmax);
+    for (int i = 0; i < 2; ++i) p.dzh[i] = take(p.gmax / 2);
     const size_t csz[4] = {b * 128 * 256 * 256, b * 64 * 128 * 512, b * 32 * 64 * 1024, b * 16 * 32 * 2048};
     for (int i = 0; i < 4; ++i) p.DC[i] = take(csz[i]);
     p.dhrec = take(b * 1024);
@@ -132,6 +141,13 @@ int conv_z(const Ctx& c, const Unit& u)
     HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)cl.cout * sizeof(double), c.s));
     d.stat_sum = ds;
     d.stat_sq = ds + cl.cout;
+    if (c.e->train_bf16) {     // bf16 operands on the matrix cores (the unit's input has a bf16 copy, weights packed by
+                               // hn_pack_weights_bf16), float32 accumulation, float32 z
+        d.x = c.W + u.xh;
+        d.w = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci));
+        d.Cin = u.stem ? 8 : cl.cin;
+        return hn_launch_conv_bf16(d, 1, c.s);
+    }
     return hn_launch_conv(d, c.s);
 }
 
@@ -148,14 +164,17 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
                                     c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
                                     st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
         return rc;
-    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, reinterpret_cast<unsigned char*>(c.W + u.mk), u.M, C, relu, c.s);
+    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, reinterpret_cast<unsigned char*>(c.W + u.mk),
+                                c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.s);
 }
 
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
 // tensor or null).  Produces dz (gradient w.r.t. the conv output), optional dpre (masked dy, the identity-branch
 // gradient), and the parameter gradients.
-int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre)
+int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0)
 {
+    // bf16 mode: dz is also written as bf16 (slot 0 / 1 of the staging buffers) for this unit's data-gradient GEMM
+    void* dz_h = (c.e->train_bf16 && dzh_slot >= 0 && c.a.convs[u.ci].cout % 64 == 0) ? c.W + c.pl.dzh[dzh_slot] : nullptr;
     const ConvLayer& cl = c.a.convs[u.ci];
     const int C = cl.cout;
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
@@ -168,11 +187,15 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
     if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M, dz, dpre,
-                                     u.M, C, c.s)))
+                                     dz_h, u.M, C, c.s)))
         return rc;
     if (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) {
         if (c.e->debug_dy) HN_HIP(hipMemcpyAsync(c.e->debug_dy, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         if (c.e->debug_dz) HN_HIP(hipMemcpyAsync(c.e->debug_dz, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+    }
+    if (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]) {
+        if (c.e->debug_dy2) HN_HIP(hipMemcpyAsync(c.e->debug_dy2, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        if (c.e->debug_dz2) HN_HIP(hipMemcpyAsync(c.e->debug_dz2, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     }
     if (cl.has_bias) {
         double* db = ds + 2 * 4096;
@@ -188,13 +211,16 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
 }
 
 // data gradient of one unit: dx = conv^T(dz) (+ add), one launch per stride-parity class
-int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, float* dx)
+int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, float* dx, int dzh_slot = 0)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
     ConvDesc d;                         // the FORWARD conv's geometry
     memset(&d, 0, sizeof(d));
     d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = cl.cin; d.Cout = cl.cout; d.KH = cl.k; d.KW = cl.k;
     d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo;
+    if (c.e->train_bf16 && cl.cout % 64 == 0)      // (ghc0.3 has Cout = 32: stays on the f32 path)
+        return hn_launch_conv_dgrad_bf16(d, c.W + c.pl.dzh[dzh_slot], c.bound(cl.wkey + ".weight"), add, dx, c.W + c.pl.wsB,
+                                         c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s);
     return hn_launch_conv_dgrad(d, dz, c.bound(cl.wkey + ".weight"), add, dx, c.W + c.pl.wsB, c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s);
 }
 
@@ -237,6 +263,20 @@ extern "C" int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* 
     return 0;
 }
 
+extern "C" int hn_train_debug_set2(hn_engine* e, int unit, float* dy_dst, float* dz_dst)
+{
+    HN_REQUIRE(e != nullptr, "hn_train_debug_set2: null engine");
+    e->debug_unit2 = unit; e->debug_dy2 = dy_dst; e->debug_dz2 = dz_dst;
+    return 0;
+}
+
+extern "C" int hn_set_train_precision(hn_engine* e, int bf16)
+{
+    HN_REQUIRE(e != nullptr && (bf16 == 0 || bf16 == 1), "hn_set_train_precision: bad argument");
+    e->train_bf16 = bf16;
+    return 0;
+}
+
 extern "C" size_t hn_grad_floats(void) { return arch().grad_floats; }
 
 extern "C" int64_t hn_grad_offset(const char* name)
@@ -266,12 +306,17 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
 
     // stem
-    if ((rc = hn_launch_prep_nhwc4(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
+    if ((rc = hn_launch_prep_nhwc4(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;          // f32: the stem's weight gradient reads it
+    if (e->train_bf16) {
+        HN_REQUIRE(e->packed_h != nullptr, "hn_train_forward: train_precision bf16 needs hn_pack_weights_bf16");
+        if ((rc = hn_launch_prep_nhwc8_bf16(x, W + pl.xn8, B, C_in, IMG_H, IMG_W, s))) return rc;
+    }
     {
         const Unit& u = pl.units[0];
         if ((rc = conv_z(c, u))) return rc;
         if ((rc = bn_forward(c, u, nullptr, 1, bn_momentum))) return rc;
         if ((rc = hn_launch_maxpool(W + u.y, W + pl.pool, B, 256, 512, 64, s))) return rc;
+        if (e->train_bf16 && (rc = hn_launch_f32_to_bf16(W + pl.pool, W + pl.poolh, (long)B * 128 * 256 * 64, s))) return rc;
     }
     // backbone + height compression
     for (int li = 0; li < 4; ++li) {
@@ -439,8 +484,8 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             if (LIVE && (rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> Gd
             if (j == 0) {
                 const Unit& ud = pl.units[pl.dsu[li]];
-                if (LIVE && (rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr))) return rc;   // dz_ds -> Ga
-                if (LIVE && (rc = unit_dgrad(c, ud, Ga, nullptr, Gb))) return rc;               // ds path -> Gb
+                if (LIVE && (rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr, 1))) return rc;   // dz_ds -> Ga (bf16 slot 1: slot 0 still holds dz1)
+                if (LIVE && (rc = unit_dgrad(c, ud, Ga, nullptr, Gb, 1))) return rc;             // ds path -> Gb
                 if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gb, Gc))) return rc;                    // + conv1 path -> Gc
                 float* t = Ga; Ga = Gc; Gc = t;
             } else {
@@ -455,7 +500,7 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     {
         const Unit& u = pl.units[0];
         if (LIVE && (rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
-        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr))) return rc;
+        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1))) return rc;
     }
 #undef LIVE
     return 0;

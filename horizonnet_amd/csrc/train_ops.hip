@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sum, con
 // y = act(z * a[c] + b[c] (+ res))
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
-                                                         float* __restrict__ y, unsigned char* __restrict__ bmask, long total4, int C4,
-                                                         int relu)
+                                                         float* __restrict__ y, unsigned char* __restrict__ bmask,
+                                                         unsigned short* __restrict__ y_h, long total4, int C4, int relu)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
@@ -125,6 +125,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
             if (bmask) bmask[i] = (unsigned char)mk;     // the adjoint reads 1 byte instead of 16 (y > 0)
         }
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
+        if (y_h) {                   // bf16 copy for the next conv's matrix-core operand (train_precision bf16)
+            unsigned lo, hi;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+            *reinterpret_cast<uint2*>(y_h + i * 4) = make_uint2(lo, hi);
+        }
     }
 }
 
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ S1, const double* __restrict__ S2, double n,
-                                                           float* __restrict__ dz, float* __restrict__ dpre, long total4, int C4)
+                                                           float* __restrict__ dz, float* __restrict__ dpre,
+                                                           unsigned short* __restrict__ dz_h, long total4, int C4)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
@@ -153,6 +160,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o[k] = gamma[c + k] * is * (g[k] - m1 - zh * m2);
         }
         *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+        if (dz_h) {                  // bf16 copy for the data-gradient GEMM's matrix-core operand
+            unsigned lo, hi;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+            *reinterpret_cast<uint2*>(dz_h + i * 4) = make_uint2(lo, hi);
+        }
         if (dpre) *reinterpret_cast<f32x4*>(dpre + i * 4) = g;
     }
 }
@@ -409,22 +422,23 @@ int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, cons
     return 0;
 }
 
-int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, long M, int C,
-                         int relu, hipStream_t s)
+int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
+                         long M, int C, int relu, hipStream_t s)
 {
     const long total4 = M * C / 4;
-    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, bmask, total4, C / 4, relu);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, bmask,
+                       reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
-                           const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, long M, int C,
-                           hipStream_t s)
+                           const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
+                           int C, hipStream_t s)
 {
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, bmask, z, mean, invstd, gamma, S1, S2, n, dz,
-                       dpre, total4, C / 4);
+                       dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4);
     HN_LAUNCH_CHECK();
     return 0;
 }

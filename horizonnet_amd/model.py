@@ -161,6 +161,12 @@ class _HipTrainStep(torch.autograd.Function):
     def forward(ctx, net, x, *params):
         st = net._hip_state(x.device)
         B, C_in = int(x.shape[0]), int(x.shape[1])
+        if net.train_precision not in ("f32", "bf16"):
+            raise ValueError("train_precision must be 'f32' or 'bf16'")
+        bf16 = net.train_precision == "bf16"
+        if bf16:
+            net._pack_bf16(st, x.device)
+        _lib.check(st.lib.hn_set_train_precision(st.handle, int(bf16)), "hn_set_train_precision")
         ws = st.train_workspace(B)
         bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
         cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
@@ -251,7 +257,9 @@ class HorizonNet(nn.Module):
             self.linear.bias[2 * self.step_cols:3 * self.step_cols].fill_(0.425)
         self._hip_states = {}
         self._train_steps = 0
-        self.precision = "f32"              # "f32" (exact, the parity path) or "bf16" (eval-mode inference only)
+        self.precision = "f32"              # eval mode: "f32" (exact, the parity path) or "bf16"
+        self.train_precision = "f32"        # train mode: "f32", or "bf16" = forward + data-gradient convs on the bf16 matrix
+                                            # cores (f32 accumulation, BN / weight gradients / LSTM / master weights stay f32)
         self.sync_gradients = True          # all-reduce gradients over torch.distributed when it is initialised (world > 1)
         self.process_group = None
         self._param_names = [(k, tuple(p.shape)) for k, p in self.named_parameters()]
@@ -285,6 +293,14 @@ class HorizonNet(nn.Module):
             st.signature = sig
         return st
 
+    def _pack_bf16(self, st, device):
+        if st.packed_h is None:
+            st.packed_h = torch.empty(st.lib.hn_packed_bf16_bytes(), dtype=torch.uint8, device=device)
+        if st.signature_h != st.signature:
+            _lib.check(st.lib.hn_pack_weights_bf16(st.handle, _lib.ptr(st.packed_h), st.packed_h.numel(),
+                                                   _lib.stream_ptr(device)), "hn_pack_weights_bf16")
+            st.signature_h = st.signature
+
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_hip_states"] = {}
@@ -315,12 +331,7 @@ class HorizonNet(nn.Module):
             bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
             cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
             if self.precision == "bf16":
-                if st.packed_h is None:
-                    st.packed_h = torch.empty(st.lib.hn_packed_bf16_bytes(), dtype=torch.uint8, device=x.device)
-                if st.signature_h != st.signature:
-                    _lib.check(st.lib.hn_pack_weights_bf16(st.handle, _lib.ptr(st.packed_h), st.packed_h.numel(),
-                                                           _lib.stream_ptr(x.device)), "hn_pack_weights_bf16")
-                    st.signature_h = st.signature
+                self._pack_bf16(st, x.device)
                 ws = st.workspace_bf16(B)
                 _lib.check(st.lib.hn_forward_bf16(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
                                                   ws.numel(), _lib.stream_ptr(x.device)), "hn_forward_bf16")

@@ -119,6 +119,14 @@ int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, 
 int hn_train_backward(hn_engine* e, const float* dbon, const float* dcor, int B, void* workspace, size_t workspace_bytes,
                       float* grads, float p_rnn, float p_head, uint64_t seed, void* stream);
 size_t hn_grad_floats(void);
+/* Train-step precision: bf16 = 1 runs the convolutions of hn_train_forward and their data gradients in
+ * hn_train_backward on the bf16 matrix cores (bf16 operands, float32 accumulation): activations and dz get a bf16
+ * copy written by the producing element-wise pass, weights come from hn_pack_weights_bf16 (call it after every
+ * optimiser step).  BatchNorm, the weight gradients, the bi-LSTM, the head and the master weights stay float32 --
+ * the mixed-precision recipe of the reference's autocast (train.py:51,273), with bf16 instead of fp16 (no GradScaler).
+ * Default 0 = everything float32. */
+int hn_set_train_precision(hn_engine* e, int bf16);
+
 /* The same backward pass in 5 gradient-completion segments (0: Linear + bi-LSTM, 1: height
  * compression, 2: layer4, 3: layer3, 4: layer2 + layer1 + stem), to be called in order 0..4
  * with identical arguments.  After segment s returns (= is enqueued on `stream`) the range
@@ -135,6 +143,7 @@ int hn_grad_segment_range(int segment, int64_t* first, int64_t* count);
 /* debug taps used by the parity tests (see train.hip) */
 int hn_train_debug_unit(int B, int unit, int64_t* out8);
 int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* dz_dst);
+int hn_train_debug_set2(hn_engine* e, int unit, float* dy_dst, float* dz_dst);   /* a second unit of the same backward pass */
 int64_t hn_grad_offset(const char* name);
 
 /* ---- second boundary: misc/panostretch.py:81-102 (image half of pano_stretch) ------- */

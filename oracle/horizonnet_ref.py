@@ -20,7 +20,34 @@ def lr_pad(x, p):
     return torch.cat([x[..., -p:], x, x[..., :p]], dim=3)
 
 
-_TRAIN = {"on": False, "momentum": 0.1}     # set by forward_train(): batch statistics + running-stat update
+_TRAIN = {"on": False, "momentum": 0.1, "bf16_convs": False}     # set by forward_train(): batch statistics + running-stat update
+
+
+def _r16(t):
+    """Round to bfloat16 (nearest even) and back: the storage precision of the engine's bf16 operands."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _ConvBf16Operands(torch.autograd.Function):
+    """What the engine's train_precision "bf16" computes for one convolution, restated with torch ops: forward and data
+    gradient see bf16-ROUNDED operands (x, w, dz) with exact products and wide accumulation; the weight gradient is
+    formed from the unrounded x and dz (the engine's wgrad stays float32).  round_bwd False = the one layer whose data
+    gradient stays on the f32 path (ghc0.3, Cout = 32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, round_bwd):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, round_bwd, b is not None)
+        return F.conv2d(_r16(x), _r16(w), b, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        stride, padding, round_bwd, has_b = ctx.cfg
+        wq, dq = (_r16(w), _r16(dz)) if round_bwd else (w, dz)
+        dx = torch.nn.grad.conv2d_input(x.shape, wq, dq, stride=stride, padding=padding)
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dz, stride=stride, padding=padding)
+        return dx, dw, (dz.sum((0, 2, 3)) if has_b else None), None, None, None
 
 
 def _bn(x, sd, k):
@@ -35,6 +62,8 @@ def _conv(x, sd, k, stride, ks):
     p = ks // 2
     if p:
         x = lr_pad(x, p)
+    if _TRAIN["on"] and _TRAIN["bf16_convs"]:
+        return _ConvBf16Operands.apply(x, w, b, stride, (p, 0), w.shape[0] % 64 == 0)
     return F.conv2d(x, w, b, stride=stride, padding=(p, 0))
 
 
@@ -133,14 +162,14 @@ def forward(x, sd, taps=None):
         return lin[:, 1:], lin[:, :1]                                        # bon, cor
 
 
-def forward_train(x, sd, momentum=0.1):
+def forward_train(x, sd, momentum=0.1, bf16_convs=False):
     """Train-mode forward WITH autograd (reference train.py:44-58 calls net(x) with net.train()): batch-statistics
     BatchNorm (running stats in `sd` are updated in place), dropout disabled (p = 0: the parity tests compare
     deterministic arithmetic; dropout is checked statistically).  Tensors in `sd` that require grad get .grad from
     a backward() on the returned (bon, cor)."""
     if x.shape[2] != 512 or x.shape[3] != 1024:
         raise NotImplementedError()
-    _TRAIN["on"], _TRAIN["momentum"] = True, momentum
+    _TRAIN["on"], _TRAIN["momentum"], _TRAIN["bf16_convs"] = True, momentum, bool(bf16_convs)
     try:
         xn = prepare_x(x)                      # dtype follows x: float32 = the reference, float64 = ground truth for tests
         feats = backbone(xn, sd)
@@ -153,11 +182,7 @@ def forward_train(x, sd, momentum=0.1):
         return lin[:, 1:], lin[:, :1]
     finally:
         _TRAIN["on"] = False
-
-
-def _r16(t):
-    """Round to bfloat16 (nearest even) and back: the storage precision of the engine's bf16 mode."""
-    return t.bfloat16().float()
+        _TRAIN["bf16_convs"] = False
 
 
 def forward_bf16_emulated(x, sd):
