@@ -45,6 +45,7 @@ SIGNATURES = {
     "hn_train_debug_set2": (_i, [_vp, _i, _vp, _vp]),
     "hn_grad_offset": (_i64, [_c.c_char_p]),
     "hn_conv2d_dgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hn_conv2d_wgrad_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_conv2d_dgrad_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_conv2d_wgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_pano_stretch": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _i, _i, _i, _i, _vp]),

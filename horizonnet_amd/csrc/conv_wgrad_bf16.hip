@@ -1,0 +1,268 @@
+// Weight-gradient GEMM for gfx950 on the bf16 matrix cores, f32 accumulation:
+//
+//   dW[n][k'] = sum_m dZ[m][n] * A[m][k']      m = output pixel (the REDUCTION index), n = output channel,
+//                                              k' = (dh, dw, c) tap x input channel
+//
+// bf16 form of conv_wgrad_f32.hip for train_precision "bf16" (reference: autograd of the convolutions under autocast,
+// train.py:51,273-280).  Same decomposition (grid = n-tiles x k'-tiles x split of the m range, float atomics into the
+// packed f32 gradient), bf16 operands: dZ and the layer input both exist as NHWC bf16 copies written by the BN-adjoint
+// / affine passes.
+//
+// The catch: the reduction index m is the SLOW index of both NHWC operands, while v_mfma_f32_32x32x16_bf16 wants 8
+// consecutive k per lane.  The tiles are therefore staged exactly as they lie in memory -- LDS images [m][n] and
+// [m][k'] filled with coalesced 16-byte row segments -- and transposed on the way out of LDS by the CDNA4 transpose
+// read ds_read_b64_tr_b16: within a group of 16 lanes, lane r supplies the address of 4 contiguous bf16 and lane i
+// receives element (i % 4) of lanes i/4, i/4 + 4, i/4 + 8, i/4 + 12 (measured, tools/probe/tr16_probe.hip).  Pointing
+// lane r at image row mb + r/4, columns nb + 4 (r % 4) .. +3 makes lane i receive rows mb..mb+3 of column nb + i:
+// a 4 (m) x 16 (n) block delivered column-wise.  Two such reads give the 8 consecutive m of one MFMA operand lane.
+// Image rows are 320 bytes apart (256 data + 64 pad): the 4 rows x 2 sixteen-column halves a 32-lane pass touches
+// land in 8 disjoint 8-dword bank groups.
+#include "hn_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int WCHB = 32;                // m rows per chunk = two k16 steps
+constexpr int PITCH = 320;              // bytes per LDS image row (128 bf16 + pad)
+constexpr unsigned OOB = 0x80000000u;
+
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgsH {
+    const u16* x;        // NHWC bf16 input of the forward conv [B][Hi][Wi][Cin]
+    const u16* dz;       // bf16 gradient w.r.t. the conv output [M][Cout]
+    float* dw;           // packed f32 [Cout][K], pre-zeroed, accumulated with atomics
+    int Hi, Wi, Cin, Ho, Wo, Cout;
+    int KW, sh, sw, ph, pw;
+    int M, K, mchunk;
+};
+
+__device__ __forceinline__ u32x4 hbuf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+}
+
+// 8 consecutive m (image rows mb .. mb+7) of column nb + (lane & 15) [+16 for the odd 16-lane group]: one MFMA operand
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const char* p = img + (mb + 8 * (g >> 1) + (r >> 2)) * PITCH + (nb + 16 * (g & 1) + 4 * (r & 3)) * 2;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * PITCH));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+#else
+    return bf16x8{};
+#endif
+}
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
+{
+    static_assert(TN == 128 && TK == 128 || TN == 64 || TK == 64, "tile");
+    constexpr int WN = TN / 2, WK = TK / 2;          // wave tile (2 x 2 waves)
+    constexpr int TI = WN / 32, TJ = WK / 32;
+    constexpr int N_TPR = TN / 8, K_TPR = TK / 8;    // loader threads per image row (16 bytes = 8 bf16 each)
+    constexpr int N_RPP = 256 / N_TPR, K_RPP = 256 / K_TPR;
+    constexpr int N_PS = WCHB / N_RPP, K_PS = WCHB / K_RPP;
+    static_assert(N_PS >= 1 && K_PS >= 1, "loader geometry");
+    constexpr int IMG = WCHB * PITCH;                // bytes per operand image
+
+    extern __shared__ __attribute__((aligned(16))) char hsmem[];
+    char* s_dz0 = hsmem;                             // [2][IMG]
+    char* s_a0 = hsmem + 2 * IMG;                    // [2][IMG]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wi_ = wave >> 1, wj_ = wave & 1;
+
+    const int NT = p.Cout / TN;
+    const int KT = p.K / TK;
+    int bid = blockIdx.x;                            // XCD-aware order, see conv_wgrad_f32.hip
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % NT;
+    bid /= NT;
+    const int kt = bid % KT;
+    const int sp = bid / KT;
+    const int n0 = nt * TN;
+    const int k0 = kt * TK;
+    const int mlo = sp * p.mchunk;
+    const int mhi = (mlo + p.mchunk) < p.M ? (mlo + p.mchunk) : p.M;
+    if (mlo >= mhi) return;
+
+    const int tap = k0 / p.Cin;                      // the whole k' tile lies inside one filter tap (TK | Cin)
+    const int c0 = k0 % p.Cin;
+    const int dh = tap / p.KW;
+    const int dw = tap % p.KW;
+
+    const int hw_out = p.Ho * p.Wo;
+    const int b_first = mlo / hw_out;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * p.Cin;
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_dz =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.dz + (size_t)mlo * p.Cout), 0, 0x7fffffff, 0x00020000);
+
+    const int n_row = tid / N_TPR, n_col = (tid % N_TPR) * 8;
+    const int k_row = tid / K_TPR, k_col = (tid % K_TPR) * 8;
+
+    int r_wo[K_PS], r_ho[K_PS], r_b[K_PS];
+#pragma unroll
+    for (int q = 0; q < K_PS; ++q) {
+        const int m = mlo + k_row + q * K_RPP;
+        r_wo[q] = m % p.Wo;
+        const int t = m / p.Wo;
+        r_ho[q] = t % p.Ho;
+        r_b[q] = t / p.Ho - b_first;
+    }
+    const int hw_in = p.Hi * p.Wi;
+    const bool wide = p.Wo >= WCHB;
+
+    u32x4 rdz[N_PS], ra[K_PS];
+    auto fetch = [&](int mc) {
+#pragma unroll
+        for (int q = 0; q < N_PS; ++q) {
+            const int m = mc + n_row + q * N_RPP;
+            const unsigned off = m < mhi ? (unsigned)((size_t)(m - mlo) * p.Cout + n0 + n_col) * 2u : OOB;
+            rdz[q] = hbuf_load16(rsrc_dz, off);
+        }
+#pragma unroll
+        for (int q = 0; q < K_PS; ++q) {
+            const int m = mc + k_row + q * K_RPP;
+            const int hi = r_ho[q] * p.sh - p.ph + dh;
+            int wi = r_wo[q] * p.sw - p.pw + dw;
+            wi = wi < 0 ? wi + p.Wi : wi;
+            wi = wi >= p.Wi ? wi - p.Wi : wi;
+            const unsigned pix = (unsigned)(r_b[q] * hw_in + hi * p.Wi + wi);
+            const unsigned in_off = (pix * (unsigned)p.Cin + (unsigned)(c0 + k_col)) * 2u;
+            ra[q] = hbuf_load16(rsrc_x, (m < mhi && (unsigned)hi < (unsigned)p.Hi) ? in_off : OOB);
+            if (wide) {
+                int wn = r_wo[q] + WCHB;
+                const bool wrap_w = wn >= p.Wo;
+                wn = wrap_w ? wn - p.Wo : wn;
+                const int hn = r_ho[q] + (wrap_w ? 1 : 0);
+                const bool wrap_h = hn >= p.Ho;
+                r_ho[q] = wrap_h ? 0 : hn;
+                r_b[q] += wrap_h ? 1 : 0;
+                r_wo[q] = wn;
+            } else {
+                const int mn = m + WCHB;
+                r_wo[q] = mn % p.Wo;
+                const int t = mn / p.Wo;
+                r_ho[q] = t % p.Ho;
+                r_b[q] = t / p.Ho - b_first;
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < N_PS; ++q)
+            *reinterpret_cast<u32x4*>(s_dz0 + buf * IMG + (n_row + q * N_RPP) * PITCH + n_col * 2) = rdz[q];
+#pragma unroll
+        for (int q = 0; q < K_PS; ++q)
+            *reinterpret_cast<u32x4*>(s_a0 + buf * IMG + (k_row + q * K_RPP) * PITCH + k_col * 2) = ra[q];
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    fetch(mlo);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mc = mlo; mc < mhi; mc += WCHB) {
+        const bool more = mc + WCHB < mhi;
+        if (more) fetch(mc + WCHB);
+        const char* dz_s = s_dz0 + buf * IMG;
+        const char* a_s = s_a0 + buf * IMG;
+#pragma unroll
+        for (int s = 0; s < WCHB / 16; ++s) {
+            bf16x8 fa[TI], fb[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = tr_frag(dz_s, 16 * s, wi_ * WN + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = tr_frag(a_s, 16 * s, wj_ * WK + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    const int fr = lane & 31;
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wi_ * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int k = k0 + wj_ * WK + j * 32 + fr;
+                __hip_atomic_fetch_add(p.dw + (size_t)n * p.K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+}
+
+template <int TN, int TK>
+int launch_wgrad_h(WgradArgsH a, hipStream_t s)
+{
+    const int NT = a.Cout / TN, KT = a.K / TK;
+    long split = 2048 / ((long)NT * KT);
+    if (split < 1) split = 1;
+    long mchunk = (a.M + split - 1) / split;
+    if (mchunk < 8 * WCHB) mchunk = 8 * WCHB;
+    mchunk = (mchunk + WCHB - 1) / WCHB * WCHB;
+    split = (a.M + mchunk - 1) / mchunk;
+    a.mchunk = (int)mchunk;
+    const size_t lds = 4 * (size_t)WCHB * PITCH;
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK>), dim3((unsigned)(NT * KT * split)), dim3(256), lds, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// x_h, dz_h: NHWC bf16; dw_packed: hn_packed_conv_weight_floats() floats, zeroed here and accumulated by the kernel.
+// Needs Cout %% 64 == 0 and Cin %% 64 == 0 (every conv of the network except the 7x7 stem and ghc0.3, which keep the f32
+// kernel).
+int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
+                              int sh, int sw, hipStream_t s)
+{
+    HN_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad bf16: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
+    WgradArgsH a;
+    a.x = reinterpret_cast<const u16*>(x_h); a.dz = reinterpret_cast<const u16*>(dz_h); a.dw = dw_packed;
+    a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KW = KW; a.sh = sh; a.sw = sw; a.ph = KH / 2; a.pw = KW / 2;
+    a.Ho = (Hi + 2 * a.ph - KH) / sh + 1;
+    a.Wo = (Wi + 2 * a.pw - KW) / sw + 1;
+    a.M = B * a.Ho * a.Wo;
+    a.K = KH * KW * Cin;
+    a.mchunk = 0;
+    HN_REQUIRE((double)B * Hi * Wi * Cin * 2.0 < 2147483648.0 && (double)a.M * Cout * 2.0 < 4294967296.0,
+               "wgrad bf16: batch too large for 32-bit tile offsets");
+    HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
+    if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad_h<128, 128>(a, s);
+    if (Cout % 128 == 0) return launch_wgrad_h<128, 64>(a, s);
+    if (Cin % 128 == 0) return launch_wgrad_h<64, 128>(a, s);
+    return launch_wgrad_h<64, 64>(a, s);
+}

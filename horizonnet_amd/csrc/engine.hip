@@ -523,6 +523,24 @@ extern "C" int hn_conv2d_dgrad_nhwc_bf16(const float* dz, const float* w_oihw, c
     return hn_launch_conv_dgrad_bf16(d, dz_h, w_oihw, add, dx, w_scratch, ones, zeros, s);
 }
 
+// bf16-MFMA form of the weight gradient: x and dz are rounded to bf16 into the scratch, accumulation and dw stay float32.
+// scratch: Cout*KH*KW*Cin floats (packed dw) followed by (B*Hi*Wi*Cin + B*Ho*Wo*Cout) / 2 floats.
+extern "C" int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
+                                         int Cout, int KH, int KW, int sh, int sw, void* stream)
+{
+    HN_REQUIRE(x && dz && dw_oihw && scratch, "hn_conv2d_wgrad_nhwc_bf16: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_wgrad_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = (Hi + 2 * (KH / 2) - KH) / sh + 1, Wo = (Wi + 2 * (KW / 2) - KW) / sw + 1;
+    const long nx = (long)B * Hi * Wi * Cin, nz = (long)B * Ho * Wo * Cout;
+    float* xh = scratch + (size_t)Cout * KH * KW * Cin;
+    float* zh = xh + (nx + 1) / 2 + 64;
+    int rc;
+    if ((rc = hn_launch_f32_to_bf16(x, xh, nx, s)) || (rc = hn_launch_f32_to_bf16(dz, zh, nz, s))) return rc;
+    if ((rc = hn_launch_conv_wgrad_bf16(xh, zh, scratch, B, Hi, Wi, Cin, Cout, KH, KW, sh, sw, s))) return rc;
+    return hn_launch_unpack_conv(scratch, dw_oihw, Cout, Cin, KH, KW, 0, s);
+}
+
 extern "C" int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
                                     int Cout, int KH, int KW, int sh, int sw, int stem, void* stream)
 {

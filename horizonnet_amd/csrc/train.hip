@@ -205,7 +205,11 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     }
     // weight gradient (packed layout) -> OIHW
     float* scratch = c.W + c.pl.wsA;
-    if ((rc = hn_launch_conv_wgrad(c.W + u.x, dz, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, 0, 0, u.stem, c.s)))
+    if (dz_h && !u.stem && cl.cin % 64 == 0) {     // bf16 mode: both operands exist as bf16 copies (input: u.xh, dz: staging slot)
+        if ((rc = hn_launch_conv_wgrad_bf16(c.W + u.xh, dz_h, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, c.s)))
+            return rc;
+    } else if ((rc = hn_launch_conv_wgrad(c.W + u.x, dz, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, 0, 0, u.stem,
+                                          c.s)))
         return rc;
     return hn_launch_unpack_conv(scratch, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, u.stem ? 8 : 0, c.s);
 }

@@ -235,6 +235,11 @@ int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const float* add,
 int hn_conv2d_dgrad_nhwc_bf16(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
                               int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
 
+/* The weight gradient on the bf16 matrix cores: x and dz are rounded to bf16, products exact, accumulation and dw float32.
+ * Cin %% 64 == 0, Cout %% 64 == 0.  scratch: Cout*KH*KW*Cin floats followed by (B*Hi*Wi*Cin + B*Ho*Wo*Cout) / 2 + 128 floats. */
+int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
+                              int Cout, int KH, int KW, int sh, int sw, void* stream);
+
 /* Weight gradient of hn_conv2d_nhwc / the stem conv: dw_oihw [Cout][Cin][KH][KW] = sum_m dz[m][n] * patch(x)[m][k].
  * stem != 0: x is the NHWC4 normalised image and the conv is the 7x7/2 stem.  scratch: Cout*max(KH*KW*Cin, 256) floats. */
 int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,

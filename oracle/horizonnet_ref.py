@@ -30,9 +30,9 @@ def _r16(t):
 
 class _ConvBf16Operands(torch.autograd.Function):
     """What the engine's train_precision "bf16" computes for one convolution, restated with torch ops: forward and data
-    gradient see bf16-ROUNDED operands (x, w, dz) with exact products and wide accumulation; the weight gradient is
-    formed from the unrounded x and dz (the engine's wgrad stays float32).  round_bwd False = the one layer whose data
-    gradient stays on the f32 path (ghc0.3, Cout = 32)."""
+    gradient see bf16-ROUNDED operands (x, w, dz) with exact products and wide accumulation, and so does the weight
+    gradient (bf16 x and dz) -- except for the 7x7 stem (3 input channels) whose weight gradient, and ghc0.3 (Cout = 32,
+    round_bwd False) whose data and weight gradients, stay on the float32 kernels."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, round_bwd):
@@ -46,7 +46,8 @@ class _ConvBf16Operands(torch.autograd.Function):
         stride, padding, round_bwd, has_b = ctx.cfg
         wq, dq = (_r16(w), _r16(dz)) if round_bwd else (w, dz)
         dx = torch.nn.grad.conv2d_input(x.shape, wq, dq, stride=stride, padding=padding)
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dz, stride=stride, padding=padding)
+        dw = torch.nn.grad.conv2d_weight(_r16(x), w.shape, dq, stride=stride, padding=padding) if round_bwd and x.shape[1] % 64 == 0 \
+            else torch.nn.grad.conv2d_weight(x, w.shape, dz, stride=stride, padding=padding)
         return dx, dw, (dz.sum((0, 2, 3)) if has_b else None), None, None, None
 
 

@@ -95,6 +95,33 @@ def test_conv_dgrad_bf16_stage(case):
     assert report("dgrad bf16 " + name, dx.cpu().numpy(), (x.grad + add).numpy(), 3e-5 * max(1.0, float(x.grad.abs().max())))
 
 
+WGRAD_BF16_CASES = [c for c in GRAD_CASES if c[4] % 64 == 0 and c[5] % 64 == 0] + [
+    ("layer1 conv2 64->64 big M", 2, 64, 128, 64, 64, 3, 1),
+    ("layer2.0 conv2 128->128 s2", 2, 32, 64, 128, 128, 3, 2),
+    ("1x1 256->64", 2, 16, 64, 256, 64, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_BF16_CASES, ids=[c[0] for c in WGRAD_BF16_CASES])
+def test_conv_wgrad_bf16_stage(case):
+    """Weight gradient on the bf16 matrix cores (transpose-read operands) == torch autograd on the bf16-rounded x and
+    dz: products of bf16 values are exact in f32, only the summation order differs."""
+    name, B, H, W, cin, cout, k, stride = case
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    r16 = lambda t: t.bfloat16().float()                                                    # noqa: E731
+    x = _rand((B, H, W, cin), 1)
+    w = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k)).requires_grad_(True)
+    y = _conv_ref(r16(x), w, (sh, sw))
+    dz = _rand(tuple(y.shape), 3)
+    y.backward(r16(dz))
+    xd, dzd = x.to(DEV), dz.contiguous().to(DEV)
+    dw = torch.full((cout, cin, k, k), float("nan"), device=DEV)
+    scr = torch.empty(cout * k * k * cin + (x.numel() + dz.numel()) // 2 + 256, device=DEV)
+    _lib.check(lib().hn_conv2d_wgrad_nhwc_bf16(P(xd), P(dzd), P(dw), P(scr), B, H, W, cin, cout, k, k, sh, sw, sp()), "wgrad bf16")
+    torch.cuda.synchronize()
+    assert report("wgrad bf16 " + name, dw.cpu().numpy(), w.grad.numpy(), 3e-5 * max(1.0, float(w.grad.abs().max())))
+
+
 def test_stem_wgrad_stage():
     B, H, W = 2, 32, 64
     x = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5))
@@ -346,7 +373,7 @@ def test_bf16_train_units_locally_consistent():
       * the consumer's z        == conv(bf16(producer y), bf16(w)) (+ bias)          (bf16 MFMA forward, f32 out)
       * the saved mean / invstd == batch statistics of that z                        (statistics fused in the epilogue)
       * the producer's dy       == conv_transpose(bf16(consumer dz), bf16(w))        (bf16 MFMA data gradient)
-      * the consumer's dW       == wgrad(producer y, consumer dz) in float32         (weight gradient stays f32)"""
+      * the consumer's dW       == wgrad(bf16(producer y), bf16(consumer dz))        (bf16 MFMA weight gradient, f32 accumulation)"""
     import ctypes
     from oracle.weights import conv_specs
     B = 1
@@ -425,9 +452,8 @@ def test_bf16_train_units_locally_consistent():
         ok &= report("bf16 train invstd %s" % cn[-31:], cons["invstd"].numpy(), inv.numpy(), 1e-3 * float(inv.abs().max()))
         z_want.backward(r16(cons["dz"]))
         ok &= report("bf16 train dy  %s" % pn[-34:], prod["dy"].numpy(), yin.grad.numpy(), 2e-3 * float(yin.grad.abs().max()))
-        y32 = prod["y"].clone().requires_grad_(True)                       # weight gradient: unrounded operands, f32
-        w32 = w.clone().requires_grad_(True)
-        _conv_ref(y32, w32, stride).backward(cons["dz"])
+        w32 = w.clone().requires_grad_(True)                               # weight gradient: bf16 operands, exact products
+        _conv_ref(r16(prod["y"]), w32, stride).backward(r16(cons["dz"]))
         ok &= report("bf16 train dW  %s" % cn[-34:], cons["grads"][cn + ".weight"].numpy(), w32.grad.numpy(), 2e-4 * float(w32.grad.abs().max()))
     assert ok
 

@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1200)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--train-precision", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = forward + data-gradient convs on the bf16 matrix cores (net.train_precision)")
     ap.add_argument("--time-limit", type=float, default=150.0, help="seconds of training after which the loop stops")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "config5.json"))
     args = ap.parse_args()
@@ -105,6 +107,7 @@ def main():
     torch.manual_seed(0)
     np.random.seed(0)
     net = HorizonNet("resnet50", True).to(dev).train()
+    net.train_precision = args.train_precision
     opt = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.999), fused=True)
     train = DeviceBatcher(images=tr_img, corners=tr_cor, device=dev, flip=True, rotate=True, gamma=True, stretch=True)
     curve, n_seen = [], 0
@@ -132,7 +135,7 @@ def main():
     assert net.hip_status(dev) == 0
     res["train"] = {"steps": step + 1, "batch": args.batch, "seconds": round(wall, 1),
                     "panoramas_per_s_incl_data_pipeline": round(n_seen / wall, 1),
-                    "host_label_seconds": round(t_data, 1), "dtype": "f32",
+                    "host_label_seconds": round(t_data, 1), "dtype": args.train_precision,
                     "augmentations": "flip+rotate+gamma+pano-stretch (hn_augment_batch)", "loss_curve_step_bon_cor": curve}
     print("train:", json.dumps(res["train"])[:400], flush=True)
 
