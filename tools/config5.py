@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--train-precision", choices=["f32", "bf16"], default="f32",
                     help="bf16 = forward + data-gradient convs on the bf16 matrix cores (net.train_precision)")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--time-limit", type=float, default=150.0, help="seconds of training after which the loop stops")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "config5.json"))
     args = ap.parse_args()
@@ -104,8 +105,8 @@ def main():
     res["render_s"] = round(time.perf_counter() - t0, 1)
 
     # ---- configs[2]: training with every augmentation on ------------------------------------------------------------
-    torch.manual_seed(0)
-    np.random.seed(0)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
     net = HorizonNet("resnet50", True).to(dev).train()
     net.train_precision = args.train_precision
     opt = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.999), fused=True)
@@ -119,6 +120,8 @@ def main():
         idx = np.random.randint(len(train), size=args.batch)
         x, y_bon, y_cor = train.batch(idx)
         t_data += time.perf_counter() - td
+        for g_ in opt.param_groups:                       # polynomial decay of train.py (misc/utils.py:35-46, power 0.9)
+            g_["lr"] = args.lr * (1.0 - step / float(args.steps)) ** 0.9
         bon, cor = net(x)
         l_bon, l_cor = F.l1_loss(bon, y_bon), F.binary_cross_entropy_with_logits(cor, y_cor)
         loss = l_bon + l_cor
