@@ -67,15 +67,15 @@ int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh
 int hn_launch_transpose(const float* in, float* out, int R, int C, hipStream_t s);
 int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s);
 int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd, double* S1,
-                            double* S2, long M, int C, hipStream_t s);
+                            double* S2, long M, int C, int z_bf16, hipStream_t s);
 int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float* a, float* b, float* save_mean, float* save_invstd, int C,
                           hipStream_t s);
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
-                         long M, int C, int relu, hipStream_t s);
+                         long M, int C, int relu, int z_bf16, hipStream_t s);
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
-                           int C, hipStream_t s);
+                           int C, int z_bf16, hipStream_t s);
 int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
 int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
 int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, hipStream_t s);

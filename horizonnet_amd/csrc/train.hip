@@ -146,7 +146,7 @@ int conv_z(const Ctx& c, const Unit& u)
         d.x = c.W + u.xh;
         d.w = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci));
         d.Cin = u.stem ? 8 : cl.cin;
-        return hn_launch_conv_bf16(d, 1, c.s);
+        return hn_launch_conv_bf16(d, 0, c.s);     // z itself is stored as bf16 (its statistics come from the f32 accumulators)
     }
     return hn_launch_conv(d, c.s);
 }
@@ -165,7 +165,7 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
                                     st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
         return rc;
     return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, reinterpret_cast<unsigned char*>(c.W + u.mk),
-                                c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.s);
+                                c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.e->train_bf16, c.s);
 }
 
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
@@ -183,11 +183,16 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
     HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
-    if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.s))) return rc;
+    if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
-    if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M, dz, dpre,
-                                     dz_h, u.M, C, c.s)))
+    // bf16 mode: when both GEMMs of this unit read the bf16 copy and nothing else needs the float32 dz (no conv bias, no
+    // debug tap), it is not written at all (4 of the pass's ~16 bytes per element)
+    const bool tapped = (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) ||
+                        (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]);
+    const bool f32_dz_needed = !(dz_h && !u.stem && cl.cin % 64 == 0) || cl.has_bias || tapped;
+    if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M,
+                                     f32_dz_needed ? dz : nullptr, dpre, dz_h, u.M, C, c.e->train_bf16, c.s)))
         return rc;
     if (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) {
         if (c.e->debug_dy) HN_HIP(hipMemcpyAsync(c.e->debug_dy, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));

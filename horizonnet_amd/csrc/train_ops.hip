@@ -11,11 +11,20 @@ namespace {
 // Column reductions over a row-major [M][C] matrix.  MODE 0: sum(a), sum(a*a)           (BN statistics, bias grads)
 //                                                    MODE 1: sum(g), sum(g * (z - mean) * invstd)   with g = dy * (ReLU mask | 1)
 // ------------------------------------------------------------------------------------------------
+// 4 consecutive z values starting at element index e: float32, or bf16 (train_precision bf16 stores the conv output z as bf16)
+__device__ __forceinline__ f32x4 load_z4(const float* z, long e, int z_bf16)
+{
+    if (!z_bf16) return *reinterpret_cast<const f32x4*>(z + e);
+    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(z) + e);
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u), __builtin_bit_cast(float, v.y << 16),
+                 __builtin_bit_cast(float, v.y & 0xffff0000u)};
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const unsigned char* __restrict__ bmask,
                                                          const float* __restrict__ z, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, double* __restrict__ out0,
-                                                         double* __restrict__ out1, long M, int C, int lda, int slab)
+                                                         double* __restrict__ out1, long M, int C, int lda, int slab, int z_bf16)
 {
     __shared__ float red[2][256 * 4];
     const int CQ = (C < 256 ? C : 256) / 4;      // column quads per workgroup
@@ -39,7 +48,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                 a0 += v;
                 a1 += v * v;
             } else {
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * (long)C + col);
+                const f32x4 zz = load_z4(z, r * (long)C + col, z_bf16);
                 if (bmask) {                 // ReLU mask of the forward pass, 4 bits per float4 (affine_act_kernel)
                     const unsigned mk = bmask[(r * (long)C + col) >> 2];
 #pragma unroll
@@ -108,11 +117,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sum, con
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
                                                          float* __restrict__ y, unsigned char* __restrict__ bmask,
-                                                         unsigned short* __restrict__ y_h, long total4, int C4, int relu)
+                                                         unsigned short* __restrict__ y_h, long total4, int C4, int relu, int z_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+        f32x4 v = load_z4(z, i * 4, z_bf16);
         v = v * *reinterpret_cast<const f32x4*>(a + c) + *reinterpret_cast<const f32x4*>(b + c);
         if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
         if (relu) {
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ S1, const double* __restrict__ S2, double n,
                                                            float* __restrict__ dz, float* __restrict__ dpre,
-                                                           unsigned short* __restrict__ dz_h, long total4, int C4)
+                                                           unsigned short* __restrict__ dz_h, long total4, int C4, int z_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
         }
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 zz = load_z4(z, i * 4, z_bf16);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const float m1 = (float)(S1[c + k] / n), m2 = (float)(S2[c + k] / n);
             o[k] = gamma[c + k] * is * (g[k] - m1 - zh * m2);
         }
-        *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+        if (dz) *reinterpret_cast<f32x4*>(dz + i * 4) = o;       // null: only the bf16 copy is consumed (bf16 wgrad + dgrad)
         if (dz_h) {                  // bf16 copy for the data-gradient GEMM's matrix-core operand
             unsigned lo, hi;
             asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
@@ -396,18 +405,18 @@ int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int 
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
     hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, s, a, (const unsigned char*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab);
+                       (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab, 0);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
 int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd, double* S1,
-                            double* S2, long M, int C, hipStream_t s)
+                            double* S2, long M, int C, int z_bf16, hipStream_t s)
 {
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "bn_bwd_reduce: unsupported C=%d", C);
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
-    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, bmask, z, mean, invstd, S1, S2, M, C, C, slab);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, bmask, z, mean, invstd, S1, S2, M, C, C, slab, z_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -423,22 +432,22 @@ int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, cons
 }
 
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
-                         long M, int C, int relu, hipStream_t s)
+                         long M, int C, int relu, int z_bf16, hipStream_t s)
 {
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, bmask,
-                       reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu);
+                       reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu, z_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
-                           int C, hipStream_t s)
+                           int C, int z_bf16, hipStream_t s)
 {
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, bmask, z, mean, invstd, gamma, S1, S2, n, dz,
-                       dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4);
+                       dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4, z_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -178,7 +178,7 @@ class _HipTrainStep(torch.autograd.Function):
                                            p_rnn, p_head, float(momentum), seed, _lib.stream_ptr(x.device)), "hn_train_forward")
         torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         net._train_steps += 1                                    # running stats changed under torch's feet
-        ctx.net, ctx.B, ctx.seed, ctx.p = net, B, seed, (p_rnn, p_head)
+        ctx.net, ctx.B, ctx.seed, ctx.p, ctx.bf16 = net, B, seed, (p_rnn, p_head), bf16
         ctx.names = net._param_names
         ctx.needs = [p.requires_grad for p in params]
         return bon, cor
@@ -192,6 +192,7 @@ class _HipTrainStep(torch.autograd.Function):
         dbon = torch.zeros((B, 2, 1024), device=dev) if dbon is None else dbon.contiguous().float()
         dcor = torch.zeros((B, 1, 1024), device=dev) if dcor is None else dcor.contiguous().float()
         ws = st.train_workspace(B)
+        _lib.check(st.lib.hn_set_train_precision(st.handle, int(ctx.bf16)), "hn_set_train_precision")   # as in the forward that saved the tensors
         flat = torch.empty(st.lib.hn_grad_floats(), dtype=torch.float32, device=dev)
         import ctypes
         import torch.distributed as dist

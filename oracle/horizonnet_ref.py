@@ -38,7 +38,7 @@ class _ConvBf16Operands(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, padding, round_bwd):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, round_bwd, b is not None)
-        return F.conv2d(_r16(x), _r16(w), b, stride=stride, padding=padding)
+        return _r16(F.conv2d(_r16(x), _r16(w), b, stride=stride, padding=padding))     # z is stored as bf16 too
 
     @staticmethod
     def backward(ctx, dz):
