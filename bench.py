@@ -177,8 +177,12 @@ def train_leg(dev, world, B, steps, warmup, dist, dtype="f32"):
             "config": {"workload": "train.py step on synthetic data (L1 + BCE losses, Adam); %s (BASELINE configs[2]: bf16, batch 64)"
                                    % ("float32 engine" if dtype == "f32" else "bf16 MFMA forward + data-gradient convs, f32 accumulation / BN / weight gradients / LSTM / master weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (RCCL all-reduce of the flat 326 MB gradient buffer)" % world},
-            "roofline": {"bound": "mfma", "achieved": round(flop / wall / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flop / wall / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None},
+            "roofline": {"bound": "mfma", "achieved": round(flop / wall / 1e12, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flop / wall / 1e12 / (PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
+                         "traffic": None,
+                         "note": "whole step (3 x forward flop) against the dense MFMA peak of the GEMM dtype; in bf16 mode the step is bound by "
+                                 "the float32 element-wise passes and LDS bandwidth, see DESIGN.md 4c" if dtype != "f32" else "whole step, 3 x forward flop"},
             "final_loss": float(loss)}
 
 
