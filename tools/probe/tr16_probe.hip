@@ -1,3 +1,5 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -o tr16_probe tr16_probe.hip ; run on an MI355X.  Output pinned the lane mapping
+// used by csrc/conv_wgrad_bf16.hip: within 16 lanes, lane i receives element i%4 of lanes i/4, i/4+4, i/4+8, i/4+12.
 // Probe of ds_read_b64_tr_b16 (gfx950): which LDS elements does lane l receive?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
