@@ -398,11 +398,70 @@ def gen_dataset():
     print("dataset: %d samples written; cuboid-pair 3D IoU range %.1f..%.1f %%" % (len(meta), min(ious), max(ious)))
 
 
+def gen_train():
+    """The training step of reference train.py:44-58 (feed_forward: L1 + BCE-with-logits on net(x) in train mode) and
+    its backward pass on the unmodified reference module: pins oracle.forward_train (batch-statistics BN, running-stat
+    update) and its autograd -- the checker of the engine's training step -- against the reference."""
+    import torch.nn.functional as F
+    import model as ref_model
+    B = 2
+    sd = make_state_dict(31, "random")
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(B, 3, 512, 1024, generator=g)
+    y_bon = (torch.rand(B, 2, 1024, generator=g) - 0.5) * 1.2
+    y_cor = (torch.rand(B, 1, 1024, generator=g) < 0.05).float()
+    net = ref_model.HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.bi_rnn.dropout = 0.0             # dropout off: deterministic arithmetic (masks are checked statistically on the GPU)
+    net.drop_out.p = 0.0
+    bon, cor = net(x)
+    loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)     # train.py:53-56
+    loss.backward()
+    ref_g = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    ref_sd_after = {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    obon, ocor = horizonnet_ref.forward_train(x, osd, 0.1)
+    oloss = F.l1_loss(obon, y_bon) + F.binary_cross_entropy_with_logits(ocor, y_cor)
+    oloss.backward()
+    worst, worst_k = 0.0, ""
+    for k, gref in ref_g.items():
+        n = float(gref.norm())
+        if n < 1e-9 or k.endswith("layers.0.1.bias"):      # conv bias in front of a batch-statistics BN: true gradient 0, noise only
+            continue
+        e = float((osd[k].grad - gref).norm()) / n
+        if e > worst:
+            worst, worst_k = e, k
+    d_rm = max(float((osd[k] - ref_sd_after[k]).abs().max()) for k in osd if k.endswith("running_mean") or k.endswith("running_var"))
+    print("train step oracle-vs-reference: loss %.7f vs %.7f, outputs %.2e / %.2e, worst gradient L2-rel %.2e (%s), running stats %.2e" % (
+        float(oloss), float(loss), float((obon - bon).abs().max()), float((ocor - cor).abs().max()), worst, worst_k, d_rm))
+    assert abs(float(oloss) - float(loss)) < 1e-5 and worst < 5e-3 and d_rm < 1e-4, "oracle training step deviates from the reference"
+    out = {"loss": np.float64(float(loss)), "bon": bon.detach().numpy(), "cor": cor.detach().numpy()}
+    names = list(ref_g.keys())
+    out["grad_norm"] = np.array([float(ref_g[k].double().norm()) for k in names], np.float64)
+    out["grad_sum"] = np.array([float(ref_g[k].double().sum()) for k in names], np.float64)
+    for k in ("linear.weight", "bi_rnn.bias_ih_l1", "reduce_height_module.ghc_lst.3.layer.3.layers.0.1.weight",
+              "feature_extractor.encoder.layer4.2.bn3.weight", "feature_extractor.encoder.conv1.1.weight"):
+        t = ref_g[k].flatten()
+        out["grad:" + k] = t[:: max(1, t.numel() // 4096)].numpy().copy()
+    out["rm:bn1"] = ref_sd_after["feature_extractor.encoder.bn1.running_mean"].numpy()
+    out["rv:bn1"] = ref_sd_after["feature_extractor.encoder.bn1.running_var"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "train_step_seed31.npz"), **out)
+    with open(os.path.join(GOLD, "train_step_seed31.json"), "w") as f:
+        json.dump({"names": names, "B": B, "weights_seed": 31, "data_seed": 32}, f)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from oracle.hostinfo import usable_cores
     torch.set_num_threads(usable_cores())
-    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc", "dataset"]
+    which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc", "dataset", "train"]
+    if "train" in which:
+        gen_train()
     if "dataset" in which:
         gen_dataset()
     if "postproc" in which:

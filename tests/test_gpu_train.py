@@ -207,6 +207,50 @@ def test_train_step_matches_oracle_autograd():
     assert ok
 
 
+def test_train_step_matches_reference_golden(golden_dir):
+    """The engine's float32 training step against the UNMODIFIED reference module (train mode, train.py's loss,
+    tests/golden/train_step_seed31.npz): loss, outputs, the norm and sum of every parameter gradient, sampled entries."""
+    import json
+    g = np.load(os.path.join(golden_dir, "train_step_seed31.npz"))
+    names = json.load(open(os.path.join(golden_dir, "train_step_seed31.json")))["names"]
+    sd = make_state_dict(31, "random")
+    gen = torch.Generator().manual_seed(32)
+    x = torch.rand(2, 3, 512, 1024, generator=gen)
+    y_bon = (torch.rand(2, 2, 1024, generator=gen) - 0.5) * 1.2
+    y_cor = (torch.rand(2, 1, 1024, generator=gen) < 0.05).float()
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    bon, cor = net(x.to(DEV))
+    loss = F.l1_loss(bon, y_bon.to(DEV)) + F.binary_cross_entropy_with_logits(cor, y_cor.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    ok = report("train step bon vs reference golden", bon.detach().cpu().numpy(), g["bon"], 1e-3)
+    ok &= report("train step cor vs reference golden", cor.detach().cpu().numpy(), g["cor"], 1e-3)
+    params = dict(net.named_parameters())
+    worst = (0.0, "")
+    for i, k in enumerate(names):
+        if k.endswith("layers.0.1.bias"):
+            continue
+        n = float(params[k].grad.double().norm())
+        e = abs(n - g["grad_norm"][i]) / g["grad_norm"][i]
+        worst = max(worst, (e, k))
+    print("[parity] gradient norms vs the reference: worst relative difference %.2e (%s)" % worst)
+    ok &= worst[0] < 2e-2                      # ReLU-mask flips of a few pixels weigh most on BN parameters of small layers
+    for k in ("linear.weight", "bi_rnn.bias_ih_l1", "reduce_height_module.ghc_lst.3.layer.3.layers.0.1.weight",
+              "feature_extractor.encoder.conv1.1.weight"):
+        t = params[k].grad.flatten().cpu()
+        got = t[:: max(1, t.numel() // 4096)].numpy()
+        want = g["grad:" + k]
+        # (the stem's gradient sums over 131072 pixels per image: a handful of ReLU-mask flips moves single entries by ~2 %)
+        ok &= report("train step grad sample " + k[-40:], got, want, (6e-2 if "conv1.1" in k else 2e-2) * float(np.abs(want).max()))
+    assert ok
+
+
 def test_loss_curve_first_steps_matches_oracle():
     """BASELINE configs[2] agreement check: the first K optimiser steps of train.py:272-281 (L1 + BCE-with-logits,
     Adam lr 1e-4) on the engine against the same steps on the CPU float32 oracle of the reference -- same weights,

@@ -106,3 +106,37 @@ def test_maximum_filter_window_kat():
     s[1020] = 1.0
     m = peaks_ref.maximum_filter_wrap(s, 26)
     assert set(np.where(m == 1.0)[0]) == set((np.arange(1008, 1034) % 1024).tolist())
+
+
+def _train_case():
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(2, 3, 512, 1024, generator=g)
+    y_bon = (torch.rand(2, 2, 1024, generator=g) - 0.5) * 1.2
+    y_cor = (torch.rand(2, 1, 1024, generator=g) < 0.05).float()
+    return make_state_dict(31, "random"), x, y_bon, y_cor
+
+
+def test_train_step_oracle_matches_reference_golden(golden_dir):
+    """oracle.forward_train + autograd == the unmodified reference module in train mode with train.py's loss
+    (tests/golden/train_step_seed31.npz, generated by gen_golden.py train): loss, outputs, every gradient norm."""
+    import torch.nn.functional as F
+    torch.set_num_threads(usable_cores())
+    g = np.load(os.path.join(golden_dir, "train_step_seed31.npz"))
+    names = json.load(open(os.path.join(golden_dir, "train_step_seed31.json")))["names"]
+    sd, x, y_bon, y_cor = _train_case()
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    bon, cor = horizonnet_ref.forward_train(x, osd, 0.1)
+    loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert np.abs(bon.detach().numpy() - g["bon"]).max() < 1e-5 and np.abs(cor.detach().numpy() - g["cor"]).max() < 1e-5
+    for i, k in enumerate(names):
+        if k.endswith("layers.0.1.bias"):          # true gradient is zero (conv bias in front of batch-stat BN)
+            continue
+        n = float(osd[k].grad.double().norm())
+        assert abs(n - g["grad_norm"][i]) <= 1e-3 * g["grad_norm"][i] + 1e-9, k
+    assert np.abs(osd["feature_extractor.encoder.bn1.running_mean"].numpy() - g["rm:bn1"]).max() < 1e-6
+    assert np.abs(osd["feature_extractor.encoder.bn1.running_var"].numpy() - g["rv:bn1"]).max() < 1e-6
