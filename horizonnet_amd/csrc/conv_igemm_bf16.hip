@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                     for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
                 }
                 if (m < p.M) {
-                    st1a += v0; st1b += v1;
-                    st2a += v0 * v0; st2b += v1 * v1;
+                    if (p.stat_sum) {            // wave-uniform: inference launches skip the statistics arithmetic
+                        st1a += v0; st1b += v1;
+                        st2a += v0 * v0; st2b += v1 * v1;
+                    }
                     if (OUT_F32) {
                         float* yo = reinterpret_cast<float*>(p.y) + out_pix(m) * p.ldy + n0 + ccol;
                         *reinterpret_cast<f32x4*>(yo) = v0;

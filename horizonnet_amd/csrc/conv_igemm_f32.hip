@@ -354,8 +354,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
                 }
                 if (m < p.M) {
                     *reinterpret_cast<f32x4*>(p.y + out_pix(m) * p.ldy + n0 + ccol) = v;
-                    st1 += v;
-                    st2 += v * v;
+                    if (p.stat_sum) {            // wave-uniform: inference launches skip the statistics arithmetic
+                        st1 += v;
+                        st2 += v * v;
+                    }
                 }
             }
         }
