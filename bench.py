@@ -127,15 +127,31 @@ def augment_leg(dev, n_img=64, iters=10):
             "max_ulp_vs_oracle": ulp}
 
 
+def seeded_net(seed=0):
+    """HorizonNet with seeded random-init weights (there is no checkpoint offline): the module's own initialisation
+    under torch.manual_seed, plus randomised BatchNorm affine / running statistics so that the folded-BN epilogues and
+    the activations are not the trivial identity case.  Self-contained: the benchmarked legs do not touch oracle/."""
+    from horizonnet_amd import HorizonNet
+    torch.manual_seed(seed)
+    net = HorizonNet("resnet50", True)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.2 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+    return net
+
+
 def train_leg(dev, world, B, steps, warmup, dist, dtype="f32"):
     """Training step of reference train.py:272-281 on the engine: train-mode forward, L1(bon) + BCE-with-logits(cor)
     (train.py:53-54), backward (all 241 gradients), data-parallel all-reduce when world > 1, Adam (lr 1e-4).
     float32; synthetic inputs and labels resident in HBM."""
     import torch.nn.functional as F
-    from horizonnet_amd import HorizonNet, broadcast_module_
-    from oracle.weights import make_state_dict
-    net = HorizonNet("resnet50", True)
-    net.load_state_dict(make_state_dict(0, "random"))
+    from horizonnet_amd import broadcast_module_
+    net = seeded_net(0)
     net = net.to(dev).train()
     net.train_precision = dtype          # bf16: forward + data-gradient convs on the bf16 matrix cores, rest f32
     broadcast_module_(net)
@@ -221,10 +237,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    from horizonnet_amd import HorizonNet
-    from oracle.weights import make_state_dict       # seeded random-init weights (no checkpoint offline)
-    net = HorizonNet("resnet50", True)
-    net.load_state_dict(make_state_dict(0, "random"))
+    net = seeded_net(0)                              # seeded random-init weights (no checkpoint offline)
     net = net.to(dev).eval()
     net.precision = args.dtype
 
@@ -338,6 +351,7 @@ def main():
             net.precision = "f32"
             out["bf16_mode"] = {"value": round(B / dt, 1), "unit": "panoramas/s", "ms_per_step": round(dt * 1e3, 3),
                                 "max_abs_vs_f32_outputs": round(float(max((hb - bon).abs().max(), (hc - cor).abs().max())), 6),
+                                "f32_output_max_abs": round(float(max(bon.abs().max(), cor.abs().max())), 3),
                                 "note": "bf16 MFMA convs, f32 accumulate/LSTM/head; single GPU; not the fp32 configuration the headline value is quoted on"}
         if not args.no_cpu_baseline and world == 1:     # the CPU reference leg runs on rank 0 of the single-GPU job only
             out["cpu_baseline"] = cpu_baseline()
