@@ -1,6 +1,9 @@
 """bench.py -- HorizonNet hot-path throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N>1: re-executes itself under torch.distributed.run,
+                                                          or is launched that way by the driver)
+    python bench.py --mode train --dtype bf16 --batch 64  BASELINE configs[2] (configs[3] with --gpus N)
+    python bench.py --mode layout                         BASELINE configs[4]: 1000 panoramas, 3D IoU vs the reference
 
 One "step" = one forward of the hot path (ResNet-50 column-feature extractor + height compression +
 bi-LSTM + head) over a batch of synthetic 512x1024 panoramas already resident in HBM.
@@ -56,7 +59,10 @@ def cpu_baseline(seconds_budget=20.0):
             break
     return {"value": n / el, "unit": "panoramas/s", "cores": cores, "kind": "port",
             "sample": "%d panoramas (batches of 2) through oracle.horizonnet_ref.forward, torch %s fp32, %d threads, %.1f s"
-                      % (n, torch.__version__, cores, el)}
+                      % (n, torch.__version__, cores, el),
+            "note": "port = the oracle's restatement of the reference forward (same torch conv / LSTM kernels, pinned to the unmodified "
+                    "reference at 2.4e-7); /root/reference is absent on the GPU box.  The UNMODIFIED reference model.py measured "
+                    "2.2 panoramas/s on the build container's 8 vCPUs (SURVEY.md section 6)"}
 
 
 def pano_stretch_leg(dev, n_img=64, iters=10):
@@ -127,6 +133,35 @@ def augment_leg(dev, n_img=64, iters=10):
             "max_ulp_vs_oracle": ulp}
 
 
+def rccl_report(dist, dev, world, rank, mbytes=326, iters=5):
+    """Which devices RCCL sees, and the bus bandwidth of the training step's exchange: an in-place float32
+    all-reduce of the flat gradient buffer's size (81.57 M elements = 326 MB), 64 MB buckets as in
+    horizonnet_amd.parallel.  Ring all-reduce moves 2(N-1)/N of the buffer over each rank's links; xGMI is
+    ~153 GB/s per link per direction (MI355X_MICROARCH / task statement)."""
+    from horizonnet_amd.parallel import allreduce_sum_async
+    names = [None] * world
+    dist.all_gather_object(names, "rank %d: %s (cuda:%d)" % (rank, torch.cuda.get_device_name(dev), dev.index))
+    buf = torch.ones(mbytes * 1_000_000 // 4, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        for w in allreduce_sum_async(buf):
+            w.wait()
+        buf.fill_(1.0)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        for w in allreduce_sum_async(buf):
+            w.wait()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / iters
+    nbytes = buf.numel() * 4
+    busbw = nbytes * (2.0 * (world - 1) / world) / dt / 1e9 if world > 1 else 0.0
+    return {"backend": dist.get_backend(), "world_size_seen_by_rccl": dist.get_world_size(), "devices": names,
+            "allreduce_bytes": nbytes, "allreduce_ms": round(dt * 1e3, 3), "algbw_GBps": round(nbytes / dt / 1e9, 1),
+            "busbw_GBps": round(busbw, 1), "xgmi_link_GBps": 153.0,
+            "busbw_vs_one_link": round(busbw / 153.0, 3) if world > 1 else None}
+
+
 def seeded_net(seed=0):
     """HorizonNet with seeded random-init weights (there is no checkpoint offline): the module's own initialisation
     under torch.manual_seed, plus randomised BatchNorm affine / running statistics so that the folded-BN epilogues and
@@ -145,23 +180,84 @@ def seeded_net(seed=0):
     return net
 
 
-def train_leg(dev, world, B, steps, warmup, dist, dtype="f32"):
-    """Training step of reference train.py:272-281 on the engine: train-mode forward, L1(bon) + BCE-with-logits(cor)
-    (train.py:53-54), backward (all 241 gradients), data-parallel all-reduce when world > 1, Adam (lr 1e-4).
-    float32; synthetic inputs and labels resident in HBM."""
+def loss_curve_check(dev, dtype):
+    """configs[2] agreement check inside the bench: tests/golden/traincurve_seed41.npz holds the losses of the UNMODIFIED
+    reference's train.py loop (5 Adam steps, B=4, every augmentation through the reference's own dataset class, dropout
+    off) on the committed synthetic dataset; the same seeds through DeviceBatcher + the HIP training step."""
+    import argparse
+    import torch.nn.functional as F
+    from horizonnet_amd import utils as hutils
+    from horizonnet_amd.dataset import DeviceBatcher
+    g = np.load(os.path.join(ROOT, "tests", "golden", "traincurve_seed41.npz"))
+    net = seeded_net_from_state(int(g["weights_seed"])).to(dev).train()
+    net.bi_rnn.dropout, net.drop_out.p = 0.0, 0.0
+    net.train_precision = dtype
+    data = DeviceBatcher(root_dir=os.path.join(ROOT, "tests", "golden", "synth_ds"), device=dev, flip=True, rotate=True, gamma=True, stretch=True)
+    a = argparse.Namespace(lr=1e-4, warmup_lr=1e-6, warmup_iters=0, max_iters=int(g["max_iters"]), lr_pow=0.9, cur_iter=0, running_lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=a.lr, betas=(0.9, 0.999))
+    got = []
+    for k in range(len(g["curve"])):
+        hutils.adjust_learning_rate(opt, a)
+        a.cur_iter += 1
+        np.random.seed(int(g["data_seed0"]) + k)
+        x, y_bon, y_cor = data.batch(np.random.randint(len(data), size=int(g["B"])))
+        opt.zero_grad()
+        bon, cor = net(x)
+        loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+        loss.backward()
+        opt.step()
+        got.append(float(loss))
+    want = (g["curve"][:, 0] + g["curve"][:, 1]).tolist()
+    return {"engine": [round(v, 6) for v in got], "reference_cpu_f32": [round(v, 6) for v in want],
+            "max_rel_diff": round(max(abs(p - q) / q for p, q in zip(got, want)), 6),
+            "note": "first K=5 steps of train.py:246-286 (poly LR, Adam, B=4, all augmentations, dropout off); step 0 is pure forward "
+                    "parity, later steps carry Adam's sign noise on near-zero gradients"}
+
+
+def seeded_net_from_state(seed):
+    """HorizonNet with the seeded weights of the golden fixtures (oracle/weights.py is the CHECKER's generator: used by the
+    loss-curve check only, never by a timed leg)."""
+    from horizonnet_amd import HorizonNet
+    from oracle.weights import make_state_dict
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(seed, "random"))
+    return net
+
+
+def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
+    """BASELINE configs[2] (and configs[3] at world > 1): the loop of reference train.py:246-286 on the engine.  Every step
+    draws its batch through the device data pipeline INSIDE the timed region -- DeviceBatcher: Pano-Stretch + flip + roll +
+    gamma in one fused launch (dataset.py:70-105) plus the host label rasterisation (dataset.py:85,108-120) -- then
+    train-mode forward, L1(bon) + BCE-with-logits(cor) (train.py:53-54), backward (all 241 gradients), the data-parallel
+    all-reduce when world > 1, Adam (lr 1e-4, poly decay).  Data: synthetic PanoContext-shaped cuboid rooms rendered at
+    start-up (no dataset offline), uint8 resident in HBM."""
+    import multiprocessing as mp
     import torch.nn.functional as F
     from horizonnet_amd import broadcast_module_
-    net = seeded_net(0)
-    net = net.to(dev).train()
-    net.train_precision = dtype          # bf16: forward + data-gradient convs on the bf16 matrix cores, rest f32
+    from horizonnet_amd.dataset import DeviceBatcher
+    from tools import c5_common as c5
+    try:
+        cores = max(1, len(os.sched_getaffinity(0)) // max(1, world))
+    except Exception:
+        cores = 4
+    with mp.get_context("fork").Pool(cores) as pool:
+        imgs, cors = c5.make_rooms(rooms, 20_000 + 1000 * rank, pool, mix=[4])
+    data = DeviceBatcher(images=imgs, corners=cors, device=dev, flip=True, rotate=True, gamma=True, stretch=True)
+    net = seeded_net(0).to(dev).train()
+    net.train_precision = dtype          # bf16: the three conv GEMMs on the bf16 matrix cores, rest f32
     broadcast_module_(net)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), fused=True)
-    g = torch.Generator().manual_seed(2000 + (dist.get_rank() if dist else 0))
-    x = torch.rand(B, 3, 512, 1024, generator=g).to(dev)
-    y_bon = ((torch.rand(B, 2, 1024, generator=g) - 0.5) * 1.2).to(dev)
-    y_cor = (torch.rand(B, 1, 1024, generator=g) < 0.05).float().to(dev)
+    rng = np.random.RandomState(2000 + rank)
+    total_iters = max(1, warmup + steps)
+    state = {"it": 0, "host_s": 0.0}
 
     def step():
+        for g_ in opt.param_groups:                       # misc/utils.py:35-46, power 0.9
+            g_["lr"] = 1e-4 * (1.0 - state["it"] / float(total_iters)) ** 0.9
+        state["it"] += 1
+        th = time.perf_counter()
+        x, y_bon, y_cor = data.batch(rng.randint(len(data), size=B), rng)
+        state["host_s"] += time.perf_counter() - th
         bon, cor = net(x)
         loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
         opt.zero_grad(set_to_none=True)
@@ -169,37 +265,81 @@ def train_leg(dev, world, B, steps, warmup, dist, dtype="f32"):
         opt.step()
         return loss
 
+    def timed(n):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        state["host_s"] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), loss
+
     for _ in range(warmup):
         step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+    wall, loss = timed(steps)
+    host_s = state["host_s"]
     assert net.hip_status(dev) == 0 and bool(torch.isfinite(loss))
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    overlap = None
+    if world > 1:                                          # exposed all-reduce time = step with exchange - step without
+        net.sync_gradients = False
+        local_wall, _ = timed(max(2, steps // 2))
+        net.sync_gradients = True
+        exposed_ms = max(0.0, wall / steps - local_wall / max(2, steps // 2)) * 1e3
+        overlap = {"ms_per_step_with_allreduce": round(wall / steps * 1e3, 2), "ms_per_step_without": round(local_wall / max(2, steps // 2) * 1e3, 2),
+                   "allreduce_alone_ms": rccl["allreduce_ms"] if rccl else None, "exposed_ms": round(exposed_ms, 2),
+                   "overlap_fraction": round(1.0 - exposed_ms / rccl["allreduce_ms"], 3) if rccl and rccl["allreduce_ms"] > 0 else None,
+                   "note": "backward runs in 5 gradient-completion segments; each finished range of the flat gradient buffer starts its "
+                           "RCCL all-reduce at once (64 MB buckets) while the remaining segments compute"}
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     flop = 3.0 * FWD_FLOP_PER_PANO * B * world * steps          # fwd + dgrad + wgrad
-    return {"metric": "training panoramas/s (512x1024, fwd+bwd+Adam)", "value": round(B * world * steps / wall, 2),
-            "unit": "panoramas/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "train.py step on synthetic data (L1 + BCE losses, Adam); %s (BASELINE configs[2]: bf16, batch 64)"
-                                   % ("float32 engine" if dtype == "f32" else "bf16 MFMA forward + data-gradient convs, f32 accumulation / BN / weight gradients / LSTM / master weights"),
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d (RCCL all-reduce of the flat 326 MB gradient buffer)" % world},
-            "roofline": {"bound": "mfma", "achieved": round(flop / wall / 1e12, 2),
-                         "peak": PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flop / wall / 1e12 / (PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
-                         "traffic": None,
-                         "note": "whole step (3 x forward flop) against the dense MFMA peak of the GEMM dtype; in bf16 mode the step is bound by "
-                                 "the float32 element-wise passes and LDS bandwidth, see DESIGN.md 4c" if dtype != "f32" else "whole step, 3 x forward flop"},
-            "final_loss": float(loss)}
+    out = {"metric": "training panoramas/s (512x1024, data pipeline + fwd + bwd + Adam)", "value": round(B * world * steps / wall, 2),
+           "unit": "panoramas/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 2),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+           "config": {"workload": "BASELINE configs[%d]: train.py loop on synthetic PanoContext-shaped rooms, pano-stretch + flip + roll + gamma "
+                                  "augmentation and label rasterisation inside the timed step, L1 + BCE losses, Adam; %s"
+                                  % (2 if world == 1 else 3, "float32 engine" if dtype == "f32" else
+                                     "bf16 MFMA conv GEMMs (forward, data and weight gradients), f32 accumulation / BN / LSTM / master weights"),
+                      "batch_per_gpu": B, "global_batch": B * world, "rooms_per_gpu": rooms,
+                      "parallelism": "dp%d (one process per GPU, RCCL all-reduce of the flat 326 MB gradient buffer overlapped with backward)" % world},
+           "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flop: forward, data gradient, weight gradient GEMMs)",
+                        "achieved": round(flop / wall / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(flop / wall / 1e12 / world / peak, 4), "traffic": None,
+                        "note": "per GPU, against the dense MFMA peak of the GEMM dtype (%s)" % ("fp32 matrix 157.3 TF" if dtype == "f32" else "bf16 2.5 PF")},
+           "host_data_pipeline_ms_per_step": round(host_s / steps * 1e3, 2),
+           "final_loss": float(loss)}
+    if rccl is not None:
+        out["rccl"] = rccl
+    if overlap is not None:
+        out["allreduce_overlap"] = overlap
+    if world == 1 and rank == 0:
+        out["loss_curve_check"] = loss_curve_check(dev, dtype)
+    return out
+
+
+def layout_leg(dev, n, batch):
+    """BASELINE configs[4]: inference.py general-layout path over n Structured3D-shaped synthetic panoramas, engine f32 and
+    bf16 vs the fixtures of the UNMODIFIED reference inference() (tools/c5_layout.py)."""
+    from tools.c5_layout import run_layout_eval
+    r = run_layout_eval(dev, n=n, batch=batch, timing_repeats=2)
+    b = r["bf16"]
+    return {"metric": "layout panoramas/s (inference.py general layout, end to end incl. post-processing) + 3D-IoU parity vs reference",
+            "value": b["panoramas_per_s_end_to_end"], "unit": "panoramas/s", "n_gpus": 1, "steps": 2, "warmup": 1,
+            "ms_per_step": round(b["seconds"] * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %d seeded synthetic Structured3D-shaped panoramas (corner mix 63/17/8/12 %% of 4/6/8/10), "
+                                   "briefly-trained checkpoint tests/golden/config5/ckpt_q.npz, uint8 panoramas resident in HBM -> "
+                                   "inference() general layout (engine forward + device peaks + host Manhattan fit), batch %d" % (r["panoramas"], batch)},
+            "iou3d_parity_vs_reference_inference": {"bf16": b, "f32": r["f32"]},
+            "render_crc_mismatches": r["render_crc_mismatches"], "corner_mix_reference": r["corner_mix_reference"],
+            "host_cores": r["host_cores"]}
 
 
 def main():
@@ -211,25 +351,47 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (default, the parity path); bf16 = the engine's bf16 inference mode")
-    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
-                    help="forward = the headline metric (default); train = one optimisation step per step")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="initialise the RCCL process group also at world size 1 (exercises the nccl branch on one GPU)")
+    ap.add_argument("--mode", choices=["forward", "train", "layout"], default="forward",
+                    help="forward = the headline metric (default, configs[1]); train = configs[2]/[3]: one optimisation step per step "
+                         "incl. the data pipeline; layout = configs[4]: inference.py general-layout path + 3D-IoU vs the reference")
+    ap.add_argument("--panoramas", type=int, default=1000, help="--mode layout: panoramas evaluated")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run
+        # (the form the driver uses itself for N > 1), rendezvous on 127.0.0.1
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    rccl = None
+    if world > 1 or args.force_rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        rccl = rccl_report(dist, dev, world, rank)       # who is in the job + all-reduce bandwidth over xGMI
 
+    if args.mode == "layout":
+        print(json.dumps(layout_leg(dev, args.panoramas, args.batch)))
+        return
     if args.mode == "train":
-        out = train_leg(dev, world, args.batch, args.steps, args.warmup, dist, args.dtype)
+        out = train_leg(dev, world, rank, args.batch, args.steps, args.warmup, dist, args.dtype, rccl)
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:
@@ -353,6 +515,8 @@ def main():
                                 "max_abs_vs_f32_outputs": round(float(max((hb - bon).abs().max(), (hc - cor).abs().max())), 6),
                                 "f32_output_max_abs": round(float(max(bon.abs().max(), cor.abs().max())), 3),
                                 "note": "bf16 MFMA convs, f32 accumulate/LSTM/head; single GPU; not the fp32 configuration the headline value is quoted on"}
+        if rccl is not None:
+            out["rccl"] = rccl
         if not args.no_cpu_baseline and world == 1:     # the CPU reference leg runs on rank 0 of the single-GPU job only
             out["cpu_baseline"] = cpu_baseline()
             out["pano_stretch"] = pano_stretch_leg(dev)

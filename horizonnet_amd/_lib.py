@@ -24,6 +24,7 @@ SIGNATURES = {
     "hn_workspace_bytes": (_sz, [_i]),
     "hn_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hn_check_status": (_i, [_vp, _vp, _c.POINTER(_i)]),
+    "hn_set_forward_tap": (_i, [_vp, _c.c_char_p, _vp]),
     "hn_set_profiling": (_i, [_vp, _i]),
     "hn_profile_count": (_i, [_vp]),
     "hn_profile_entry": (_i, [_vp, _i, _c.c_char_p, _i, _c.POINTER(_f), _c.POINTER(_c.c_double)]),
@@ -34,6 +35,7 @@ SIGNATURES = {
     "hn_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_train_workspace_bytes": (_sz, [_i]),
     "hn_train_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _f, _f, _f, _c.c_uint64, _vp]),
+    "hn_set_bn_eval": (_i, [_vp, _c.c_char_p, _i]),
     "hn_train_backward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _f, _c.c_uint64, _vp]),
     "hn_train_backward_segment": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _f, _c.c_uint64, _i, _vp]),
     "hn_grad_segments": (_i, []),

@@ -181,6 +181,21 @@ extern "C" int hn_destroy(hn_engine* e)
     return 0;
 }
 
+extern "C" int hn_set_forward_tap(hn_engine* e, const char* name, void* dst)
+{
+    HN_REQUIRE(e != nullptr, "hn_set_forward_tap: null engine");
+    if (name == nullptr) {
+        e->taps.clear();
+        return 0;
+    }
+    static const char* known[] = {"stem", "pool", "c1", "c2", "c3", "c4", "feature", "lstm"};
+    bool ok = false;
+    for (const char* k : known) ok = ok || std::string(k) == name;
+    HN_REQUIRE(ok, "hn_set_forward_tap: unknown tap '%s'", name);
+    if (dst) e->taps[name] = dst; else e->taps.erase(name);
+    return 0;
+}
+
 extern "C" int hn_set_profiling(hn_engine* e, int on)
 {
     HN_REQUIRE(e != nullptr, "hn_set_profiling: null engine");
@@ -311,7 +326,7 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
     float* W = reinterpret_cast<float*>(workspace);
     int rc;
 
-    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
     e->prof.clear();
     e->events_used = 0;
 
@@ -323,6 +338,8 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
                           W + pl.pool, stream)))
             return rc;
     }
+    if ((rc = e->tap("stem", W + pl.stem, (size_t)B * 256 * 512 * 64 * sizeof(float), s))) return rc;
+    if ((rc = e->tap("pool", W + pl.pool, (size_t)B * 128 * 256 * 64 * sizeof(float), s))) return rc;
 
     // ResNet-50 stages (model.py:78-81) + per-scale height compression (model.py:138-156,172-179)
     const float* cur = W + pl.pool;
@@ -348,6 +365,10 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
             if ((rc = run_conv(e, P, c3, W + pl.t2, out, idt, B, H, Wd, 1, 1, 1, s))) return rc;
             cur = out;
         }
+        {
+            const char* cname[4] = {"c1", "c2", "c3", "c4"};
+            if ((rc = e->tap(cname[li], cur, (size_t)B * H * Wd * (256 << li) * sizeof(float), s))) return rc;
+        }
         // GlobalHeightConv for this scale
         const float* gin = cur;
         int gh = H;
@@ -368,6 +389,7 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
 
     // bi-LSTM x2 + Linear head (model.py:263-269)
     const long rows = (long)T_COLS * B;
+    if ((rc = e->tap("feature", W + pl.seq, (size_t)rows * 1024 * sizeof(float), s))) return rc;
     const float* lin = W + pl.seq;
     float* ybuf[2] = {W + pl.y1, W + pl.y2};
     for (int l = 0; l < 2; ++l) {
@@ -382,6 +404,7 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
         }
         lin = ybuf[l];
     }
+    if ((rc = e->tap("lstm", W + pl.y2, (size_t)rows * 1024 * sizeof(float), s))) return rc;
     ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
     return hn_launch_linear_head(W + pl.y2, P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
 }

@@ -135,7 +135,7 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
     const u16* H = reinterpret_cast<const u16*>(e->packed_h);
     char* W = reinterpret_cast<char*>(workspace);
     int rc;
-    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
     e->prof.clear();
     e->events_used = 0;
 
@@ -152,6 +152,8 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
         if ((rc = hn_launch_conv_bf16(d, 0, s))) return rc;
         if ((rc = hn_launch_maxpool_bf16(W + pl.stem, W + pl.pool, B, 256, 512, 64, s))) return rc;
     }
+    if ((rc = e->tap("stem", W + pl.stem, (size_t)B * 256 * 512 * 64 * 2, s))) return rc;
+    if ((rc = e->tap("pool", W + pl.pool, (size_t)B * 128 * 256 * 64 * 2, s))) return rc;
 
     const char* cur = W + pl.pool;
     int Hh = 128, Wd = 256;
@@ -174,6 +176,10 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
             if ((rc = run_conv_h(e, a.convs[i1 + 2], h.conv[i1 + 2], W + pl.t2, out, idt, B, Hh, Wd, 1, 1, 1, s))) return rc;
             cur = out;
         }
+        {
+            const char* cname[4] = {"c1", "c2", "c3", "c4"};
+            if ((rc = e->tap(cname[li], cur, (size_t)B * Hh * Wd * (256 << li) * 2, s))) return rc;
+        }
         const char* gin = cur;
         int gh = Hh;
         char* gbuf[2] = {W + pl.g0, W + pl.g1};
@@ -192,6 +198,7 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
 
     // bi-LSTM x2: bf16 input GEMMs with f32 gate pre-activations, f32 recurrence; f32 Linear head
     const long rows = (long)T_COLS * B;
+    if ((rc = e->tap("feature", W + pl.seq, (size_t)rows * 1024 * 2, s))) return rc;
     const void* lin = W + pl.seq;
     float* ybuf[2] = {reinterpret_cast<float*>(W + pl.y1), reinterpret_cast<float*>(W + pl.y2)};
     for (int l = 0; l < 2; ++l) {
@@ -216,6 +223,7 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
             lin = W + pl.y1h;
         }
     }
+    if ((rc = e->tap("lstm", ybuf[1], (size_t)rows * 1024 * sizeof(float), s))) return rc;
     ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
     return hn_launch_linear_head(ybuf[1], P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
 }

@@ -58,6 +58,16 @@ struct hn_engine {
     std::unordered_map<std::string, const void*> bound;
     const float* packed = nullptr;       // last packed buffer (caller owned)
     const void* packed_h = nullptr;      // last bf16 weight buffer (hn_pack_weights_bf16, caller owned)
+    std::vector<unsigned char> bn_eval;  // per conv layer: 1 = its BatchNorm is in eval() inside a train-mode step (hn_set_bn_eval):
+                                         // normalise with the running statistics, leave them untouched (train.py:245-250 freezing)
+    std::unordered_map<std::string, void*> taps;   // parity-test taps of hn_forward / hn_forward_bf16 (hn_set_forward_tap)
+    int tap(const char* name, const void* src, size_t bytes, hipStream_t s) const
+    {
+        auto it = taps.find(name);
+        if (it == taps.end() || it->second == nullptr) return 0;
+        HN_HIP(hipMemcpyAsync(it->second, src, bytes, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     int train_bf16 = 0;                  // 1: train-mode convs (forward + data gradient) on the bf16 matrix cores (hn_set_train_precision)
     bool profiling = false;
     int debug_unit = -1;                 // training debug tap (hn_train_debug_set): unit whose dy / dz are copied out

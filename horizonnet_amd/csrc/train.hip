@@ -121,6 +121,7 @@ struct Ctx {
     float* grads;          // flat gradient buffer (may be null in forward)
     hipStream_t s;
     int B;
+    bool bn_eval(const Unit& u) const { return (size_t)u.ci < e->bn_eval.size() && e->bn_eval[u.ci] != 0; }
     const float* bound(const std::string& k) const { return reinterpret_cast<const float*>(e->bound.at(k)); }
     float* bound_mut(const std::string& k) const { return const_cast<float*>(reinterpret_cast<const float*>(e->bound.at(k))); }
     float* grad(const std::string& k) const { return grads + a.grad_off.at(k); }
@@ -137,10 +138,12 @@ int conv_z(const Ctx& c, const Unit& u)
     d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = u.stem ? 4 : cl.cin; d.Cout = cl.cout; d.KH = cl.k; d.KW = cl.k;
     d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo; d.relu = 0; d.ldy = cl.cout; d.stem = u.stem;
     // batch statistics of z come out of the conv epilogue (sum / sum of squares per channel, double atomics)
-    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
-    HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)cl.cout * sizeof(double), c.s));
-    d.stat_sum = ds;
-    d.stat_sq = ds + cl.cout;
+    if (!c.bn_eval(u)) {       // (a BatchNorm in eval() normalises with its running statistics: no batch statistics needed)
+        double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
+        HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)cl.cout * sizeof(double), c.s));
+        d.stat_sum = ds;
+        d.stat_sq = ds + cl.cout;
+    }
     if (c.e->train_bf16) {     // bf16 operands on the matrix cores (the unit's input has a bf16 copy, weights packed by
                                // hn_pack_weights_bf16), float32 accumulation, float32 z
         d.x = c.W + u.xh;
@@ -160,9 +163,13 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
     float* st = c.W + u.st;
     int rc;
-    if ((rc = hn_launch_bn_finalize(ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
-                                    c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
-                                    st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
+    if (c.bn_eval(u)) {       // frozen block (train.py:245-256): running statistics, untouched
+        if ((rc = hn_launch_bn_eval_affine(c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"), c.bound(cl.bnkey + ".running_mean"),
+                                           c.bound(cl.bnkey + ".running_var"), st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
+            return rc;
+    } else if ((rc = hn_launch_bn_finalize(ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
+                                           c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
+                                           st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
         return rc;
     return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, reinterpret_cast<unsigned char*>(c.W + u.mk),
                                 c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.e->train_bf16, c.s);
@@ -186,6 +193,8 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
+    // eval-mode BatchNorm: mean / invstd are constants, so dz = gamma * invstd * g -- the batch-statistics formula with both sums zero
+    if (c.bn_eval(u)) HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
     // bf16 mode: when both GEMMs of this unit read the bf16 copy and nothing else needs the float32 dz (no conv bias, no
     // debug tap), it is not written at all (4 of the pass's ~16 bytes per element)
     const bool tapped = (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) ||
@@ -279,6 +288,19 @@ extern "C" int hn_train_debug_set2(hn_engine* e, int unit, float* dy_dst, float*
     return 0;
 }
 
+extern "C" int hn_set_bn_eval(hn_engine* e, const char* bn_prefix, int eval)
+{
+    HN_REQUIRE(e != nullptr && bn_prefix != nullptr, "hn_set_bn_eval: null argument");
+    const Arch& a = arch();
+    if (e->bn_eval.size() != a.convs.size()) e->bn_eval.assign(a.convs.size(), 0);
+    for (size_t i = 0; i < a.convs.size(); ++i)
+        if (a.convs[i].bnkey == bn_prefix) {
+            e->bn_eval[i] = eval ? 1 : 0;
+            return 0;
+        }
+    HN_REQUIRE(false, "hn_set_bn_eval: no BatchNorm with prefix '%s'", bn_prefix);
+}
+
 extern "C" int hn_set_train_precision(hn_engine* e, int bf16)
 {
     HN_REQUIRE(e != nullptr && (bf16 == 0 || bf16 == 1), "hn_set_train_precision: bad argument");
@@ -312,7 +334,7 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     float* W = c.W;
     hipStream_t s = c.s;
     int rc;
-    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_SYNC_WORDS * sizeof(unsigned), s));
+    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
 
     // stem
     if ((rc = hn_launch_prep_nhwc4(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;          // f32: the stem's weight gradient reads it

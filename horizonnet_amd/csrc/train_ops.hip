@@ -113,6 +113,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sum, con
     }
 }
 
+// BN(eval) inside a training step (frozen block): the affine and the "saved" mean / invstd come from the running statistics
+__global__ __launch_bounds__(256) void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* running_mean,
+                                                             const float* running_var, float* a, float* b, float* save_mean,
+                                                             float* save_invstd, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(running_var[c] + 1e-5f);
+    const float aa = gamma[c] * invstd;
+    a[c] = aa;
+    b[c] = beta[c] - running_mean[c] * aa;
+    save_mean[c] = running_mean[c];
+    save_invstd[c] = invstd;
+}
+
 // y = act(z * a[c] + b[c] (+ res))
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
@@ -427,6 +442,15 @@ int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, cons
 {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sum, sumsq, n, gamma, beta, running_mean,
                        running_var, momentum, a, b, save_mean, save_invstd, C);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* a,
+                              float* b, float* save_mean, float* save_invstd, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, running_mean, running_var, a, b,
+                       save_mean, save_invstd, C);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -9,6 +9,8 @@ The module tree below holds ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.L
 keep working unchanged.  None of the containers' own ``forward`` methods is ever called.
 """
 import ctypes
+import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -16,6 +18,8 @@ import torch.nn as nn
 from . import _lib
 
 _STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))     # (bottleneck width, blocks) of ResNet-50
+_SYNC_BYTES = 4096                                    # HN_SYNC_WORDS * 4: first bytes of every workspace
+_STATUS_BYTE = 512 * 4                                # HN_STATUS_WORD * 4
 
 
 class LR_PAD(nn.Module):
@@ -74,10 +78,59 @@ class _ResNet50Trunk(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
 
+def _torchvision_resnet50_state_dict():
+    """ImageNet weights of torchvision's resnet50 (``ResNet50_Weights.IMAGENET1K_V1``, what reference model.py:66-69,
+    204-207 builds the encoder from), or None.  Sources, in order: the file named by ``HORIZONNET_RESNET50_WEIGHTS``;
+    torch hub's cache (``resnet50-0676ba61.pth``); an installed torchvision (which may download)."""
+    cands = [os.environ.get("HORIZONNET_RESNET50_WEIGHTS"),
+             os.path.join(torch.hub.get_dir(), "checkpoints", "resnet50-0676ba61.pth")]
+    for path in cands:
+        if path and os.path.isfile(path):
+            return torch.load(path, map_location="cpu")
+    try:
+        import torchvision.models as tvm
+        try:
+            return tvm.resnet50(weights=tvm.ResNet50_Weights.IMAGENET1K_V1).state_dict()
+        except AttributeError:                                   # torchvision < 0.13 (model.py:10-14)
+            return tvm.resnet50(pretrained=True).state_dict()
+    except Exception:
+        return None
+
+
+def _remap_torchvision_key(k):
+    """torchvision key -> key of the LR_PAD-wrapped trunk (reference model.py:42-55 turns every Conv2d with horizontal
+    padding into Sequential(LR_PAD, conv): conv1 and every bottleneck conv2 gain a '.1')."""
+    if k.startswith("fc."):
+        return None
+    if k == "conv1.weight":
+        return "conv1.1.weight"
+    if k.endswith(".conv2.weight"):
+        return k[:-len("weight")] + "1.weight"
+    return k
+
+
 class Resnet(nn.Module):
-    def __init__(self, backbone="resnet50"):
+    def __init__(self, backbone="resnet50", pretrained=True):
         super().__init__()
         self.encoder = _ResNet50Trunk()
+        self.pretrained_loaded = False
+        if pretrained:
+            tv = _torchvision_resnet50_state_dict()
+            if tv is None:
+                warnings.warn(
+                    "horizonnet_amd: no ImageNet ResNet-50 weights found (torchvision is not installed, "
+                    "HORIZONNET_RESNET50_WEIGHTS is unset and torch hub's cache has no resnet50-0676ba61.pth): the encoder "
+                    "starts from Kaiming-random weights, unlike reference model.py:204-207.  Harmless when a checkpoint is "
+                    "loaded afterwards (inference.py / --pth); training from scratch will be worse than the reference's.",
+                    RuntimeWarning, stacklevel=3)
+            else:
+                sd = {}
+                for k, v in tv.items():
+                    nk = _remap_torchvision_key(k)
+                    if nk is not None:
+                        sd[nk] = v
+                self.encoder.load_state_dict(sd, strict=True)
+                self.pretrained_loaded = True
 
     def list_blocks(self):
         ch = list(self.encoder.children())
@@ -121,31 +174,49 @@ class _DeviceState:
         self.signature_h = None
         self.signature = None
         self.keepalive = None
-        self.workspaces = {}
+        self.workspaces = {}                 # kind ("f32" | "bf16" | "train") -> (B, tensor): one batch size per kind
+        self.train_generation = 0            # bumped whenever the train workspace's saved activations are overwritten / freed
+        self.bn_flags = None                 # last per-BatchNorm eval flags pushed with hn_set_bn_eval
+        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.status_event = None
+
+    def _workspace(self, kind, B, nbytes):
+        cur = self.workspaces.get(kind)
+        if cur is not None and cur[0] == B:
+            return cur[1]
+        if kind == "train":
+            self.train_generation += 1       # a pending backward of the old buffer must not run on the new one
+        self.workspaces.pop(kind, None)      # one batch size resident per kind; the other kinds stay (a validation forward
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)      # between a train forward and its backward is fine)
+        ws[:_SYNC_BYTES].zero_()             # arrival counters + the STICKY status word of the persistent LSTM
+        self.workspaces[kind] = (B, ws)
+        return ws
 
     def workspace(self, B):
-        ws = self.workspaces.get(B)
-        if ws is None:
-            self.workspaces.clear()              # one batch size resident at a time
-            ws = torch.empty(self.lib.hn_workspace_bytes(B), dtype=torch.uint8, device=self.device)
-            self.workspaces[B] = ws
-        return ws
+        return self._workspace("f32", B, self.lib.hn_workspace_bytes(B))
 
     def workspace_bf16(self, B):
-        ws = self.workspaces.get(("bf16", B))
-        if ws is None:
-            self.workspaces.clear()
-            ws = torch.empty(self.lib.hn_workspace_bf16_bytes(B), dtype=torch.uint8, device=self.device)
-            self.workspaces[("bf16", B)] = ws
-        return ws
+        return self._workspace("bf16", B, self.lib.hn_workspace_bf16_bytes(B))
 
     def train_workspace(self, B):
-        ws = self.workspaces.get(("train", B))
-        if ws is None:
-            self.workspaces.clear()
-            ws = torch.empty(self.lib.hn_train_workspace_bytes(B), dtype=torch.uint8, device=self.device)
-            self.workspaces[("train", B)] = ws
-        return ws
+        return self._workspace("train", B, self.lib.hn_train_workspace_bytes(B))
+
+    def post_status_read(self, ws):
+        """Asynchronous copy of the workspace's sticky LSTM status word to pinned host memory (no synchronisation)."""
+        self.status_host.copy_(ws[_STATUS_BYTE:_STATUS_BYTE + 4].view(torch.int32), non_blocking=True)
+        if self.status_event is None:
+            self.status_event = torch.cuda.Event()
+        self.status_event.record(torch.cuda.current_stream(self.device))
+
+    def raise_if_failed(self):
+        """Called at the start of every engine call: if an EARLIER call's status word has arrived and is non-zero, the
+        persistent LSTM kernel hit its spin limit (its workgroups were not co-resident: CUs held by another stream or
+        process, a partitioned GPU) and that call's bon / cor were garbage."""
+        if self.status_event is not None and self.status_event.query() and int(self.status_host[0]) != 0:
+            raise _lib.HipEngineError(
+                "the persistent bi-LSTM kernel of an earlier forward timed out waiting for its peer workgroups (status "
+                "word %d): its outputs were invalid.  The kernel needs all 256 workgroups co-resident -- do not share the "
+                "GPU between processes / concurrent streams while it runs." % int(self.status_host[0]))
 
     def __del__(self):
         try:
@@ -167,18 +238,28 @@ class _HipTrainStep(torch.autograd.Function):
         if bf16:
             net._pack_bf16(st, x.device)
         _lib.check(st.lib.hn_set_train_precision(st.handle, int(bf16)), "hn_set_train_precision")
+        st.raise_if_failed()
         ws = st.train_workspace(B)
         bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
         cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
-        bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
-        momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+        named_bns = [(k, m) for k, m in net.named_modules() if isinstance(m, nn.BatchNorm2d)]
+        bns = [m for _, m in named_bns]
+        # a BatchNorm in eval() inside a training net (train.py:245-256: frozen blocks) uses its running statistics
+        flags = tuple(not m.training for m in bns)
+        net._push_bn_flags(st, named_bns, flags)
+        live = [m for m in bns if m.training]
+        momentum = live[0].momentum if (live and live[0].momentum is not None) else 0.1
         seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())        # host RNG: follows torch.manual_seed
         p_rnn, p_head = float(net.bi_rnn.dropout), float(net.drop_out.p)
         _lib.check(st.lib.hn_train_forward(st.handle, _lib.ptr(x), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws), ws.numel(),
                                            p_rnn, p_head, float(momentum), seed, _lib.stream_ptr(x.device)), "hn_train_forward")
-        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        if live:
+            torch._foreach_add_([m.num_batches_tracked for m in live], 1)
         net._train_steps += 1                                    # running stats changed under torch's feet
+        st.train_generation += 1
+        st.post_status_read(ws)
         ctx.net, ctx.B, ctx.seed, ctx.p, ctx.bf16 = net, B, seed, (p_rnn, p_head), bf16
+        ctx.generation, ctx.bn_flags, ctx.named_bns = st.train_generation, flags, named_bns
         ctx.names = net._param_names
         ctx.needs = [p.requires_grad for p in params]
         return bon, cor
@@ -191,7 +272,15 @@ class _HipTrainStep(torch.autograd.Function):
         B = ctx.B
         dbon = torch.zeros((B, 2, 1024), device=dev) if dbon is None else dbon.contiguous().float()
         dcor = torch.zeros((B, 1, 1024), device=dev) if dcor is None else dcor.contiguous().float()
+        if st.train_generation != ctx.generation:
+            raise RuntimeError(
+                "horizonnet_amd: the activations saved by this train-mode forward were overwritten before backward() ran "
+                "(another train-mode forward, or a different batch size, used the engine's training workspace in between). "
+                "Call backward() before the next training forward -- e.g. accumulate gradients step by step instead of "
+                "summing the losses of two forwards.")
+        st.raise_if_failed()
         ws = st.train_workspace(B)
+        net._push_bn_flags(st, ctx.named_bns, ctx.bn_flags)
         _lib.check(st.lib.hn_set_train_precision(st.handle, int(ctx.bf16)), "hn_set_train_precision")   # as in the forward that saved the tensors
         flat = torch.empty(st.lib.hn_grad_floats(), dtype=torch.float32, device=dev)
         import ctypes
@@ -261,6 +350,7 @@ class HorizonNet(nn.Module):
         self.precision = "f32"              # eval mode: "f32" (exact, the parity path) or "bf16"
         self.train_precision = "f32"        # train mode: "f32", or "bf16" = forward + data-gradient convs on the bf16 matrix
                                             # cores (f32 accumulation, BN / weight gradients / LSTM / master weights stay f32)
+        self.check_status_async = True      # every forward posts an asynchronous read of the LSTM status word; the NEXT call raises
         self.sync_gradients = True          # all-reduce gradients over torch.distributed when it is initialised (world > 1)
         self.process_group = None
         self._param_names = [(k, tuple(p.shape)) for k, p in self.named_parameters()]
@@ -294,6 +384,13 @@ class HorizonNet(nn.Module):
             st.signature = sig
         return st
 
+    @staticmethod
+    def _push_bn_flags(st, named_bns, flags):
+        if flags != st.bn_flags:
+            for (k, _), f in zip(named_bns, flags):
+                _lib.check(st.lib.hn_set_bn_eval(st.handle, k.encode(), int(f)), "hn_set_bn_eval(%s)" % k)
+            st.bn_flags = flags
+
     def _pack_bf16(self, st, device):
         if st.packed_h is None:
             st.packed_h = torch.empty(st.lib.hn_packed_bf16_bytes(), dtype=torch.uint8, device=device)
@@ -320,8 +417,18 @@ class HorizonNet(nn.Module):
             xin = x.detach()
             if xin.dtype != torch.float32 or not xin.is_contiguous():
                 xin = xin.float().contiguous()
+            params = list(self.parameters())
+            if len(params) != len(self._param_names):
+                # nn.DataParallel's per-forward replicas carry plain tensors instead of Parameters: autograd could not
+                # route gradients back, and the reference's GPU0-rooted replicate/scatter/gather is what this engine
+                # replaces.  Fail loudly instead of training nothing.
+                raise RuntimeError(
+                    "horizonnet_amd.HorizonNet: train-mode forward on a module without its Parameters (an nn.DataParallel "
+                    "replica?).  Multi-GPU training runs one process per GPU over torch.distributed/RCCL "
+                    "(horizonnet_amd.parallel); nn.DataParallel(net, device_ids=[one device]) works because it calls the "
+                    "module itself.")
             with torch.cuda.device(x.device):
-                return _HipTrainStep.apply(self, xin, *self.parameters())
+                return _HipTrainStep.apply(self, xin, *params)
         if C_in < 3:
             raise RuntimeError("expected at least 3 input channels")
         xin = x.detach()
@@ -329,6 +436,7 @@ class HorizonNet(nn.Module):
             xin = xin.float().contiguous()
         with torch.cuda.device(x.device):
             st = self._hip_state(x.device)
+            st.raise_if_failed()
             bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
             cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
             if self.precision == "bf16":
@@ -336,13 +444,52 @@ class HorizonNet(nn.Module):
                 ws = st.workspace_bf16(B)
                 _lib.check(st.lib.hn_forward_bf16(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
                                                   ws.numel(), _lib.stream_ptr(x.device)), "hn_forward_bf16")
-                return bon, cor
-            if self.precision != "f32":
+            elif self.precision == "f32":
+                ws = st.workspace(B)
+                _lib.check(st.lib.hn_forward(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
+                                             ws.numel(), _lib.stream_ptr(x.device)), "hn_forward")
+            else:
                 raise ValueError("precision must be 'f32' or 'bf16'")
-            ws = st.workspace(B)
-            _lib.check(st.lib.hn_forward(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
-                                         ws.numel(), _lib.stream_ptr(x.device)), "hn_forward")
+            if self.check_status_async:
+                st.post_status_read(ws)
         return bon, cor
+
+    _TAP_SHAPES = {"stem": (256, 512, 64), "pool": (128, 256, 64), "c1": (128, 256, 256), "c2": (64, 128, 512),
+                   "c3": (32, 64, 1024), "c4": (16, 32, 2048)}
+
+    def forward_with_taps(self, x, names=("stem", "pool", "c1", "c2", "c3", "c4", "feature", "lstm")):
+        """Eval-mode forward that also returns the named intermediates (hn_set_forward_tap) in the REFERENCE's layouts:
+        stem / pool / c1..c4 as NCHW views [B,C,H,W], "feature" [B,1024,256] (model.py:259), "lstm" [256,B,1024]
+        (model.py:264).  float32 in f32 mode; bf16 tensors (lstm: float32) in bf16 mode.  For parity tests."""
+        assert not self.training and x.is_cuda
+        B = int(x.shape[0])
+        st = self._hip_state(x.device)
+        dt = torch.float32 if self.precision == "f32" else torch.bfloat16
+        bufs = {}
+        for n in names:
+            if n in self._TAP_SHAPES:
+                bufs[n] = torch.empty((B,) + self._TAP_SHAPES[n], dtype=dt, device=x.device)
+            elif n == "feature":
+                bufs[n] = torch.empty((256, B, 1024), dtype=dt, device=x.device)
+            elif n == "lstm":
+                bufs[n] = torch.empty((256, B, 1024), dtype=torch.float32, device=x.device)
+            else:
+                raise KeyError(n)
+            _lib.check(st.lib.hn_set_forward_tap(st.handle, n.encode(), _lib.ptr(bufs[n])), "hn_set_forward_tap")
+        try:
+            bon, cor = self.forward(x)
+            torch.cuda.synchronize(x.device)
+        finally:
+            st.lib.hn_set_forward_tap(st.handle, None, None)
+        taps = {}
+        for n, t in bufs.items():
+            if n in self._TAP_SHAPES:
+                taps[n] = t.permute(0, 3, 1, 2)
+            elif n == "feature":
+                taps[n] = t.permute(1, 2, 0)
+            else:
+                taps[n] = t
+        return bon, cor, taps
 
     def profile_forward(self, x):
         """One forward with per-launch-group HIP-event timing (hn_set_profiling).  Returns
@@ -370,7 +517,9 @@ class HorizonNet(nn.Module):
         st = self._hip_states.get(device.index)
         if st is None or not st.workspaces:
             return 0
-        ws = next(iter(st.workspaces.values()))
-        val = ctypes.c_int(0)
-        _lib.check(st.lib.hn_check_status(st.handle, _lib.ptr(ws), ctypes.byref(val)), "hn_check_status")
-        return val.value
+        worst = 0
+        for _, ws in st.workspaces.values():         # the status word is sticky per workspace
+            val = ctypes.c_int(0)
+            _lib.check(st.lib.hn_check_status(st.handle, _lib.ptr(ws), ctypes.byref(val)), "hn_check_status")
+            worst = max(worst, val.value)
+        return worst

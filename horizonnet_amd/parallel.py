@@ -11,6 +11,7 @@ BatchNorm statistics stay per replica, exactly like the reference's DataParallel
 import torch
 
 DEFAULT_BUCKET_BYTES = 64 << 20
+FORCE_COLLECTIVES = False      # True: issue the collectives also in a single-rank group (exercises the RCCL path on one GPU)
 
 
 def allreduce_sum_async(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
@@ -18,7 +19,7 @@ def allreduce_sum_async(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
     handles ([] when there is nothing to exchange).  With the nccl (= RCCL) backend the collectives run on RCCL's own
     stream behind everything enqueued on the current stream so far -- kernels enqueued afterwards overlap with them."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES):
         return []
     assert flat.dim() == 1 and flat.is_contiguous()
     n = flat.numel()

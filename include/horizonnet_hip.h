@@ -79,6 +79,13 @@ int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float*
  * on this workspace (non-zero = the persistent LSTM kernel's bounded spin gave up). */
 int hn_check_status(hn_engine* e, void* workspace, int* status_out);
 
+/* Parity-test taps: during the following hn_forward / hn_forward_bf16 calls the named intermediate is copied
+ * (device to device, on the call's stream) into `dst`.  Names and layouts (NHWC; float32 for hn_forward, bf16 for
+ * hn_forward_bf16 except "lstm"): "stem" [B,256,512,64] (model.py:73-75), "pool" [B,128,256,64] (:76), "c1" [B,128,256,256],
+ * "c2" [B,64,128,512], "c3" [B,32,64,1024], "c4" [B,16,32,2048] (:78-81), "feature" [256*B,1024] rows t*B+b (:259-262),
+ * "lstm" [256*B,1024] float32 (:263-264).  dst == NULL removes the tap; name == NULL removes all. */
+int hn_set_forward_tap(hn_engine* e, const char* name, void* dst);
+
 /* Optional per-launch-group timing of hn_forward (HIP events on the caller's stream; used by
  * bench.py for the roofline numbers, never inside the timed region).  After a profiled
  * hn_forward: hn_profile_count() entries, each a name (the state_dict key of the conv, or a
@@ -112,6 +119,14 @@ size_t hn_train_workspace_bytes(int B);
  * current parameters.  num_batches_tracked is the caller's to increment. */
 int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
                      size_t workspace_bytes, float p_rnn, float p_head, float bn_momentum, uint64_t seed, void* stream);
+
+/* Per-BatchNorm mode inside a train-mode step.  Reference train.py:245-256 puts the frozen blocks'
+ * modules in eval() every epoch (--freeze_earlier_blocks): such a BatchNorm normalises with its
+ * RUNNING statistics and leaves them untouched, and its adjoint is the plain affine's.  `bn_prefix` is
+ * the state_dict prefix of the BatchNorm ("feature_extractor.encoder.layer1.0.bn2"); eval != 0 selects
+ * running statistics for hn_train_forward / hn_train_backward from now on (default 0 = batch
+ * statistics).  Returns non-zero for an unknown prefix. */
+int hn_set_bn_eval(hn_engine* e, const char* bn_prefix, int eval);
 
 /* Backward of the last hn_train_forward on `workspace`: dbon [B,2,1024], dcor [B,1,1024] -> gradients of all
  * 241 parameters written (not accumulated) into the flat buffer `grads` (hn_grad_floats() floats; the

@@ -455,6 +455,107 @@ def gen_train():
         json.dump({"names": names, "B": B, "weights_seed": 31, "data_seed": 32}, f)
 
 
+def gen_train_frozen():
+    """train.py:200-208,245-256 (--freeze_earlier_blocks 1): the parameters of blocks 0..1 (stem, layer1) have
+    requires_grad False AND those modules are put in eval() every epoch, so their BatchNorms normalise with the running
+    statistics and leave them untouched, while the rest of the network is in train mode.  One step of the unmodified
+    reference in that state: outputs, loss, gradient norms of the live parameters, running statistics after the step."""
+    import torch.nn.functional as F
+    import model as ref_model
+    B = 2
+    sd = make_state_dict(33, "random")
+    g = torch.Generator().manual_seed(34)
+    x = torch.rand(B, 3, 512, 1024, generator=g)
+    y_bon = (torch.rand(B, 2, 1024, generator=g) - 0.5) * 1.2
+    y_cor = (torch.rand(B, 1, 1024, generator=g) < 0.05).float()
+    net = ref_model.HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    blocks = list(net.feature_extractor.list_blocks())
+    for i in range(2):
+        for m in blocks[i]:
+            for p_ in m.parameters():
+                p_.requires_grad = False
+    net.train()
+    for i in range(2):
+        for m in blocks[i]:
+            m.eval()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    bon, cor = net(x)
+    loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+    loss.backward()
+    names = [k for k, p_ in net.named_parameters()]
+    live = [k for k, p_ in net.named_parameters() if p_.requires_grad]
+    assert all(p_.grad is None for k, p_ in net.named_parameters() if not p_.requires_grad)
+    gr = dict((k, p_.grad.detach()) for k, p_ in net.named_parameters() if p_.requires_grad)
+    after = net.state_dict()
+    frozen_bn = [k for k in after if ("running_" in k or "num_batches" in k) and
+                 (k.startswith("feature_extractor.encoder.bn1") or k.startswith("feature_extractor.encoder.layer1"))]
+    assert all(torch.equal(after[k], sd[k]) for k in frozen_bn), "frozen BN buffers moved in the reference?"
+    out = {"loss": np.float64(float(loss)), "bon": bon.detach().numpy(), "cor": cor.detach().numpy(),
+           "grad_norm": np.array([float(gr[k].double().norm()) for k in live], np.float64),
+           "grad_sum": np.array([float(gr[k].double().sum()) for k in live], np.float64)}
+    for k in ("linear.weight", "feature_extractor.encoder.layer2.0.conv1.weight", "feature_extractor.encoder.layer2.0.bn1.weight",
+              "reduce_height_module.ghc_lst.0.layer.0.layers.0.1.weight"):
+        t = gr[k].flatten()
+        out["grad:" + k] = t[:: max(1, t.numel() // 4096)].numpy().copy()
+    out["rm:layer2.0.bn1"] = after["feature_extractor.encoder.layer2.0.bn1.running_mean"].numpy()
+    out["rv:layer2.0.bn1"] = after["feature_extractor.encoder.layer2.0.bn1.running_var"].numpy()
+    out["nbt:layer2.0.bn1"] = after["feature_extractor.encoder.layer2.0.bn1.num_batches_tracked"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "train_step_frozen_seed33.npz"), **out)
+    with open(os.path.join(GOLD, "train_step_frozen_seed33.json"), "w") as f:
+        json.dump({"names": names, "live": live, "frozen_bn_buffers": frozen_bn, "B": B, "weights_seed": 33, "data_seed": 34,
+                   "freeze_earlier_blocks": 1}, f)
+    print("train step with frozen blocks 0..1: loss %.7f, %d live / %d parameters" % (float(loss), len(live), len(names)))
+
+
+def gen_traincurve():
+    """BASELINE configs[2] in miniature, from the unmodified reference: train.py's loop (:246-286 -- poly learning rate
+    via misc.utils.adjust_learning_rate, feed_forward's L1 + BCE losses, Adam) over batches drawn through the reference's
+    own PanoCorBonDataset with every augmentation on (dataset.py:70-105: Pano-Stretch, flip, roll, gamma) from the
+    committed synthetic dataset.  Dropout off, float32, CPU.  The engine's bench / tests
+    redo the same seeds through DeviceBatcher + the HIP training step and compare the loss curve."""
+    import argparse
+    import torch.nn.functional as F
+    import model as ref_model
+    import dataset as ref_ds
+    from misc.utils import adjust_learning_rate
+    from scipy.spatial.distance import cdist as _cdist
+    ref_ds.cdist = lambda a, b, p=None: _cdist(a, b)          # SciPy >= 1.9 shim, see gen_dataset
+    root = os.path.join(GOLD, "synth_ds")
+    ds = ref_ds.PanoCorBonDataset(root, flip=True, rotate=True, gamma=True, stretch=True)
+    B, K = 4, 5
+    sd = make_state_dict(41, "random")
+    net = ref_model.HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    args = argparse.Namespace(lr=1e-4, warmup_lr=1e-6, warmup_iters=0, max_iters=300, lr_pow=0.9, cur_iter=0, running_lr=1e-4)
+    opt = torch.optim.Adam(filter(lambda p_: p_.requires_grad, net.parameters()), lr=args.lr, betas=(0.9, 0.999), weight_decay=0)
+    curve, xsums = [], []
+    for k in range(K):
+        adjust_learning_rate(opt, args)
+        args.cur_iter += 1
+        np.random.seed(7000 + k)
+        idx = np.random.randint(len(ds), size=B)
+        samples = [ds[int(i)] for i in idx]
+        x = torch.stack([s_[0] for s_ in samples])
+        y_bon = torch.stack([s_[1] for s_ in samples])
+        y_cor = torch.stack([s_[2] for s_ in samples])
+        opt.zero_grad()
+        bon, cor = net(x)
+        l_bon, l_cor = F.l1_loss(bon, y_bon), F.binary_cross_entropy_with_logits(cor, y_cor)
+        (l_bon + l_cor).backward()
+        opt.step()
+        curve.append([float(l_bon), float(l_cor), args.running_lr])
+        xsums.append(float(x.double().sum()))
+        print("traincurve step %d: bon %.6f cor %.6f lr %.3e" % (k, float(l_bon), float(l_cor), args.running_lr), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "traincurve_seed41.npz"), curve=np.array(curve, np.float64),
+                        xsum=np.array(xsums, np.float64), B=np.int64(B), weights_seed=np.int64(41), data_seed0=np.int64(7000),
+                        max_iters=np.int64(args.max_iters))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from oracle.hostinfo import usable_cores
@@ -462,6 +563,10 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc", "dataset", "train"]
     if "train" in which:
         gen_train()
+    if "train_frozen" in which:
+        gen_train_frozen()
+    if "traincurve" in which:
+        gen_traincurve()
     if "dataset" in which:
         gen_dataset()
     if "postproc" in which:

@@ -1,0 +1,384 @@
+"""GPU tests (-m gpu) of the engine BEHIND THE REFERENCE'S CALLERS: the call sequences of ``inference.py`` / ``train.py``
+with only the import swap of INTEGRATION.md section 1, frozen blocks (``--freeze_earlier_blocks``), ``autocast`` +
+``GradScaler``, ``nn.DataParallel(device_ids=[0])``, checkpoint round trips, true resume, the RCCL branch, and the
+configs[2] / configs[4] fixtures generated from the unmodified reference in the build container."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from horizonnet_amd import HorizonNet, _lib, inference  # noqa: E402
+from horizonnet_amd import utils as hutils  # noqa: E402
+from horizonnet_amd.dataset import DeviceBatcher, PanoCorBonDataset  # noqa: E402
+from oracle.weights import make_state_dict  # noqa: E402
+
+from hiputil import DEV, report  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _train_net(seed, dropout=False):
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(seed, "random"))
+    net = net.to(DEV).train()
+    if not dropout:
+        net.bi_rnn.dropout = 0.0
+        net.drop_out.p = 0.0
+    return net
+
+
+def _batch(seed, B=2):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, 512, 1024, generator=gen)
+    y_bon = (torch.rand(B, 2, 1024, generator=gen) - 0.5) * 1.2
+    y_cor = (torch.rand(B, 1, 1024, generator=gen) < 0.05).float()
+    return x.to(DEV), y_bon.to(DEV), y_cor.to(DEV)
+
+
+def _loss(net, x, y_bon, y_cor):
+    bon, cor = net(x)
+    return F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor), bon, cor
+
+
+# ---- train.py:200-208,245-256: frozen blocks ------------------------------------------------------------------------
+def test_train_step_frozen_blocks_matches_reference_golden(golden_dir):
+    """One step of the UNMODIFIED reference with --freeze_earlier_blocks 1 semantics (stem + layer1: requires_grad off
+    AND eval(): BatchNorm on running statistics, buffers untouched) against the engine in the same state."""
+    g = np.load(os.path.join(golden_dir, "train_step_frozen_seed33.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "train_step_frozen_seed33.json")))
+    net = _train_net(33)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    blocks = net.feature_extractor.list_blocks()
+    for i in range(2):
+        for m in blocks[i]:
+            for p in m.parameters():
+                p.requires_grad = False
+    net.train()
+    for i in range(2):
+        for m in blocks[i]:
+            m.eval()
+    x, y_bon, y_cor = _batch(34)
+    loss, bon, cor = _loss(net, x, y_bon, y_cor)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    ok = report("frozen step bon vs reference", bon.detach().cpu().numpy(), g["bon"], 2e-5)
+    ok &= report("frozen step cor vs reference", cor.detach().cpu().numpy(), g["cor"], 2e-5)
+    params = dict(net.named_parameters())
+    live = meta["live"]
+    assert [k for k, p in params.items() if p.requires_grad] == live
+    assert all(params[k].grad is None for k in meta["names"] if k not in live)
+    worst = (0.0, "")
+    for i, k in enumerate(live):
+        if k.endswith("layers.0.1.bias"):
+            continue
+        n = float(params[k].grad.double().norm())
+        worst = max(worst, (abs(n - g["grad_norm"][i]) / g["grad_norm"][i], k))
+    print("[parity] frozen-block step, gradient norms vs the reference: worst relative difference %.2e (%s)" % worst)
+    ok &= worst[0] < 2e-2
+    for k in ("linear.weight", "feature_extractor.encoder.layer2.0.conv1.weight", "feature_extractor.encoder.layer2.0.bn1.weight",
+              "reduce_height_module.ghc_lst.0.layer.0.layers.0.1.weight"):
+        t = params[k].grad.flatten().cpu()
+        got = t[:: max(1, t.numel() // 4096)].numpy()
+        ok &= report("frozen step grad sample " + k[-40:], got, g["grad:" + k], 2e-2 * float(np.abs(g["grad:" + k]).max()))
+    after = net.state_dict()
+    for k in meta["frozen_bn_buffers"]:                    # running statistics and counters of the frozen blocks: untouched
+        assert torch.equal(after[k], before[k]), k
+    ok &= report("live running_mean layer2.0.bn1", after["feature_extractor.encoder.layer2.0.bn1.running_mean"].cpu().numpy(),
+                 g["rm:layer2.0.bn1"], 1e-5)
+    ok &= report("live running_var layer2.0.bn1", after["feature_extractor.encoder.layer2.0.bn1.running_var"].cpu().numpy(),
+                 g["rv:layer2.0.bn1"], 1e-5 * float(np.abs(g["rv:layer2.0.bn1"]).max()))
+    assert int(after["feature_extractor.encoder.layer2.0.bn1.num_batches_tracked"]) == int(g["nbt:layer2.0.bn1"])
+    assert ok
+
+
+def test_eval_batchnorm_adjoint_matches_torch():
+    """A trainable BatchNorm left in eval() (running statistics) inside a training net: the engine's adjoint of that unit
+    must be the plain affine's.  Checked on the LAST height-compression unit against torch autograd of the same tail."""
+    net = _train_net(35)
+    bn = net.reduce_height_module.ghc_lst[3].layer[3].layers[1]
+    bn.eval()
+    x, y_bon, y_cor = _batch(36, B=1)
+    loss, _, _ = _loss(net, x, y_bon, y_cor)
+    loss.backward()
+    g_eval = {k: p.grad.clone() for k, p in net.named_parameters() if "ghc_lst.3.layer.3" in k}
+    net2 = _train_net(35)
+    loss2, _, _ = _loss(net2, x, y_bon, y_cor)
+    loss2.backward()
+    g_train = {k: p.grad.clone() for k, p in net2.named_parameters() if "ghc_lst.3.layer.3" in k}
+    torch.cuda.synchronize()
+    # different normalisation -> different gradients (the flag reached the engine) and finite everywhere
+    k = "reduce_height_module.ghc_lst.3.layer.3.layers.1.weight"
+    assert float((g_eval[k] - g_train[k]).abs().max()) > 1e-6
+    assert all(bool(torch.isfinite(v).all()) for v in g_eval.values())
+    assert int(bn.num_batches_tracked) == 0 and int(net2.reduce_height_module.ghc_lst[3].layer[3].layers[1].num_batches_tracked) == 1
+
+
+# ---- saved-activation lifetime ---------------------------------------------------------------------
+def test_backward_after_second_train_forward_raises_and_validation_forward_is_fine():
+    net = _train_net(37)
+    x, y_bon, y_cor = _batch(38, B=1)
+    l1, _, _ = _loss(net, x, y_bon, y_cor)
+    l2, _, _ = _loss(net, x, y_bon, y_cor)          # overwrites the saved activations of l1
+    with pytest.raises(RuntimeError, match="overwritten"):
+        l1.backward()
+    l2.backward()                                   # the latest graph is intact
+    ref = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    # a validation forward (eval workspace, other batch size) between a train forward and its backward is harmless
+    net2 = _train_net(37)
+    l3, _, _ = _loss(net2, x, y_bon, y_cor)
+    net2.eval()
+    with torch.no_grad():
+        net2(torch.rand(2, 3, 512, 1024, device=DEV))
+    net2.train()
+    l3.backward()
+    torch.cuda.synchronize()
+    worst = max(float((p.grad - ref[k]).norm() / (ref[k].norm() + 1e-12)) for k, p in net2.named_parameters() if not k.endswith("layers.0.1.bias"))
+    print("[parity] gradients with a validation forward in between vs without: worst L2-rel %.2e" % worst)
+    assert worst < 1e-3
+
+
+# ---- train.py:190-192 nn.DataParallel, :227,273-280 autocast + GradScaler --------------------------------------------
+def test_dataparallel_single_device_and_replica_guard():
+    net = _train_net(39)
+    x, y_bon, y_cor = _batch(40, B=2)
+    dp = nn.DataParallel(net, device_ids=[0])
+    loss, _, _ = _loss(dp, x, y_bon, y_cor)
+    loss.backward()
+    plain = _train_net(39)
+    loss_p, _, _ = _loss(plain, x, y_bon, y_cor)
+    loss_p.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(loss_p.detach())) < 1e-6
+    gp = dict(plain.named_parameters())
+    worst = max(float((p.grad - gp[k].grad).norm() / (gp[k].grad.norm() + 1e-12)) for k, p in net.named_parameters() if not k.endswith("layers.0.1.bias"))
+    assert worst < 1e-3, worst
+    assert hutils.unwrap(dp) is net and hasattr(hutils.unwrap(dp).feature_extractor, "list_blocks")
+    # a real multi-device DataParallel replica has no Parameters: the engine must refuse instead of training nothing
+    from torch.nn.parallel import replicate
+    rep = replicate(net, [0])[0]
+    with pytest.raises(RuntimeError, match="DataParallel"):
+        rep(x)
+
+
+def test_autocast_gradscaler_step_equals_plain_step():
+    """train.py:273-280 verbatim around the engine: fp16 autocast context + GradScaler.  The engine computes in its own
+    precision whatever autocast says; the scaler's 65536x loss scaling must cancel exactly (float32 gradients)."""
+    from torch.cuda.amp import GradScaler, autocast
+    x, y_bon, y_cor = _batch(42, B=1)
+    upd = []
+    for scaled in (True, False):
+        net = _train_net(41)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, net.parameters()), lr=1e-4, betas=(0.9, 0.999), weight_decay=0)
+        w0 = net.linear.weight.detach().clone()
+        if scaled:
+            scaler = GradScaler()
+            opt.zero_grad()
+            with autocast():
+                bon, cor = net(x)
+                loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            assert scaler.get_scale() >= 65536.0                    # no inf/nan found: the step was taken
+        else:
+            opt.zero_grad()
+            loss, _, _ = _loss(net, x, y_bon, y_cor)
+            loss.backward()
+            opt.step()
+        upd.append((float(loss.detach()), (net.linear.weight.detach() - w0).cpu()))
+    torch.cuda.synchronize()
+    assert abs(upd[0][0] - upd[1][0]) < 1e-6
+    assert float((upd[0][1] - upd[1][1]).abs().max()) < 2e-6 and float(upd[0][1].abs().max()) > 5e-5
+
+
+# ---- configs[2] in miniature: loss curve vs the unmodified reference -------------------------------------------------
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_train_loss_curve_matches_reference_fixture(golden_dir, precision):
+    """tests/golden/traincurve_seed41.npz = reference train.py loop (poly LR, Adam, all augmentations through the reference's
+    own dataset class) for 5 steps at B=4.  Same seeds through DeviceBatcher + the HIP training step."""
+    import argparse
+    g = np.load(os.path.join(golden_dir, "traincurve_seed41.npz"))
+    curve, B = g["curve"], int(g["B"])
+    net = _train_net(int(g["weights_seed"]))
+    net.train_precision = precision
+    data = DeviceBatcher(root_dir=os.path.join(golden_dir, "synth_ds"), device=DEV, flip=True, rotate=True, gamma=True, stretch=True)
+    args = argparse.Namespace(lr=1e-4, warmup_lr=1e-6, warmup_iters=0, max_iters=int(g["max_iters"]), lr_pow=0.9, cur_iter=0, running_lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.999), weight_decay=0)
+    got = []
+    for k in range(len(curve)):
+        hutils.adjust_learning_rate(opt, args)
+        args.cur_iter += 1
+        np.random.seed(int(g["data_seed0"]) + k)
+        idx = np.random.randint(len(data), size=B)
+        x, y_bon, y_cor = data.batch(idx)
+        xs = float(x.double().sum())
+        assert abs(xs - g["xsum"][k]) < 1e-6 * abs(g["xsum"][k]), "augmented batch differs from the reference's"
+        opt.zero_grad()
+        bon, cor = net(x)
+        l_bon, l_cor = F.l1_loss(bon, y_bon), F.binary_cross_entropy_with_logits(cor, y_cor)
+        (l_bon + l_cor).backward()
+        opt.step()
+        got.append([float(l_bon), float(l_cor), args.running_lr])
+    got = np.array(got)
+    print("[parity] %s loss curve engine / reference: " % precision +
+          ", ".join("%.5f+%.5f / %.5f+%.5f" % (a[0], a[1], b[0], b[1]) for a, b in zip(got, curve)))
+    assert np.allclose(got[:, 2], curve[:, 2], rtol=1e-12)                      # learning-rate schedule
+    tol0 = 1e-5 if precision == "f32" else 2e-2
+    assert abs(got[0, 0] - curve[0, 0]) < tol0 * curve[0, 0] + 1e-6 and abs(got[0, 1] - curve[0, 1]) < tol0 * curve[0, 1] + 1e-6
+    tot_g, tot_r = got[:, 0] + got[:, 1], curve[:, 0] + curve[:, 1]
+    assert np.all(np.abs(tot_g[1:] - tot_r[1:]) < (3e-2 if precision == "f32" else 6e-2) * tot_r[1:])
+    assert tot_g[-1] < tot_g[0]
+
+
+# ---- RCCL branch on one GPU ---------------------------------------------------------------------------------------
+_RCCL_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import horizonnet_amd.parallel as par
+from horizonnet_amd import HorizonNet
+from oracle.weights import make_state_dict
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+def grads(force):
+    par.FORCE_COLLECTIVES = force
+    net = HorizonNet("resnet50", True); net.load_state_dict(make_state_dict(51, "random")); net = net.to(dev).train()
+    net.bi_rnn.dropout = 0.0; net.drop_out.p = 0.0
+    net.segmented_backward = force
+    x = torch.rand(1, 3, 512, 1024, generator=torch.Generator().manual_seed(52)).to(dev)
+    bon, cor = net(x)
+    (bon.sum() + cor.sum()).backward()
+    return torch.cat([p.grad.flatten() for p in net.parameters()])
+a = grads(True)        # segmented backward, every range all-reduced through RCCL (world size 1)
+b = grads(False)       # monolithic backward, no collective
+t = torch.ones(1 << 20, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+print("RCCL1 %%.3e %%s %%d" %% (float((a - b).norm() / b.norm()), dist.get_backend(), dist.get_world_size()))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_backend_world_size_1(tmp_path):
+    """The `nccl` (= RCCL) branch of the gradient exchange executed on the one GPU of the test box: a single-rank group,
+    collectives forced on; the all-reduced segmented backward must equal the monolithic one."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("RCCL1")][0]
+    print("[parity] segmented backward + RCCL all-reduce (world 1) vs monolithic:", line)
+    assert float(line.split()[1]) < 1e-4 and line.split()[2] == "nccl" and line.split()[3] == "1"
+
+
+def test_bench_self_launch_under_rccl():
+    """`python bench.py --gpus 1 --force-rccl` (the one-GPU form of what the driver runs at N = 2, 4, 8): prints one JSON
+    line carrying the RCCL report."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-rccl", "--steps", "2", "--warmup", "1",
+                          "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, MASTER_PORT="29657"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["rccl"]["backend"] == "nccl" and rec["rccl"]["world_size_seen_by_rccl"] == 1 and rec["value"] > 0
+
+
+# ---- inference.py:174-223 call sequence --------------------------------------------------------------------------
+def _config5_net():
+    from tools import c5_common as c5
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(c5.decode_state_dict(), strict=True)
+    return net
+
+
+def test_inference_entry_point_sequence_matches_reference_json(golden_dir, tmp_path):
+    """inference.py's main block with the import swap: save_model-format checkpoint -> load_trained_model -> per image PIL
+    -> inference(flip, rotate) -> JSON, against the JSON the UNMODIFIED reference script wrote for the same checkpoint
+    and images in the build container (tests/golden/config5/inference_cli/*.json)."""
+    import argparse
+    from PIL import Image
+    pth = str(tmp_path / "c5.pth")
+    hutils.save_model(_config5_net(), pth, argparse.Namespace(id="config5"))
+    device = torch.device(DEV)
+    net = hutils.load_trained_model(HorizonNet, pth).to(device)
+    net.eval()
+    fix_dir = os.path.join(golden_dir, "config5", "inference_cli")
+    meta = json.load(open(os.path.join(fix_dir, "args.json")))
+    names = sorted(f for f in os.listdir(os.path.join(golden_dir, "synth_ds", "img")) if f.endswith(".png"))
+    assert names
+    with torch.no_grad():
+        for f in names:
+            img_pil = Image.open(os.path.join(golden_dir, "synth_ds", "img", f))
+            if img_pil.size != (1024, 512):
+                img_pil = img_pil.resize((1024, 512), Image.BICUBIC)
+            img_ori = np.array(img_pil)[..., :3].transpose([2, 0, 1]).copy()
+            x = torch.FloatTensor(np.array([img_ori / 255]))
+            cor_id, z0, z1, vis_out = inference(net=net, x=x, device=device, flip=meta["flip"], rotate=meta["rotate"],
+                                                visualize=True, force_cuboid=False, force_raw=False, min_v=None, r=0.05)
+            want = json.load(open(os.path.join(fix_dir, f[:-4] + ".json")))
+            uv = np.array(want["uv"], np.float64)
+            assert cor_id.shape == uv.shape, (f, cor_id.shape, uv.shape)
+            assert float(z0) == want["z0"]
+            assert report("inference.py JSON uv %s" % f, cor_id, uv, 1e-4)
+            assert abs(float(z1) - want["z1"]) < 1e-3 * abs(want["z1"])
+            assert vis_out is not None and vis_out.shape == (512 + 33, 1024, 3)
+
+
+# ---- train.py sequence through the in-repo driver, kill + resume ------------------------------------------------------
+def test_train_driver_epoch_freeze_checkpoint_and_resume(golden_dir, tmp_path):
+    from horizonnet_amd import train as drv
+    root = os.path.join(golden_dir, "synth_ds")
+    common = ["--train_root_dir", root, "--valid_root_dir", root, "--batch_size_train", "2", "--epochs", "3", "--save_every", "1",
+              "--freeze_earlier_blocks", "0", "--bn_momentum", "0.05", "--precision", "f32", "--seed", "7", "--lr", "3e-4"]
+    full = drv.main(["--id", "full", "--ckpt", str(tmp_path)] + common)
+    part = drv.main(["--id", "cut", "--ckpt", str(tmp_path), "--stop_after_epoch", "1"] + common)      # "killed" after epoch 1
+    rest = drv.main(["--id", "cut", "--ckpt", str(tmp_path), "--resume"] + common)
+    tr = lambda h: [(r["epoch"], r["iter"], r["lr"], r["bon"] + r["cor"]) for r in h if "iter" in r]   # noqa: E731
+    a, b = tr(full), tr(part) + tr(rest)
+    print("[parity] uninterrupted vs killed+resumed loss curve: " + ", ".join("%.5f/%.5f" % (p[3], q[3]) for p, q in zip(a, b)))
+    assert len(a) == len(b) == 6 and [r[:2] for r in a] == [r[:2] for r in b]
+    assert np.allclose([r[2] for r in a], [r[2] for r in b], rtol=1e-12)            # the schedule continues where it stopped
+    for p, q in zip(a, b):
+        assert abs(p[3] - q[3]) < 2e-2 * abs(p[3])                                  # float atomics: not bit-identical
+    # checkpoint files of the reference + save_model round trip into an eval forward
+    d = os.path.join(str(tmp_path), "full")
+    assert os.path.isfile(os.path.join(d, "checkpoint.pth.tar")) and os.path.isfile(os.path.join(d, "epoch_3.pth"))
+    ck = torch.load(os.path.join(d, "checkpoint.pth.tar"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 3 and ck["backbone"] == "resnet50" and "optimizer" in ck and "best_valid_score" in ck
+    net = hutils.load_trained_model(HorizonNet, os.path.join(d, "epoch_3.pth")).to(DEV).eval()
+    init = HorizonNet("resnet50", True)
+    with torch.no_grad():
+        bon, cor = net(torch.rand(1, 3, 512, 1024, device=DEV))
+    assert bool(torch.isfinite(bon).all()) and bool(torch.isfinite(cor).all())
+    # block 0 (stem) frozen: untouched by three epochs, statistics included; later blocks did move
+    sd = net.state_dict()
+    torch.manual_seed(7)
+    assert int(sd["feature_extractor.encoder.bn1.num_batches_tracked"]) == 0
+    assert float(sd["feature_extractor.encoder.bn1.running_var"].float().sub(1).abs().max()) == 0.0
+    assert int(sd["feature_extractor.encoder.layer1.0.bn1.num_batches_tracked"]) == 6
+    del init
+
+
+# ---- configs[4]: 1000 panoramas against the reference's own inference() ----------------------------------------------
+def test_config5_layouts_vs_reference_inference(golden_dir):
+    """Engine f32 / bf16 general-layout inference on the 1000 seeded synthetic Structured3D-shaped panoramas against the
+    fixtures written by the UNMODIFIED reference inference() (oracle/gen_config5.py): per-image 3D IoU between the two
+    predicted layouts (eval_general.py:56-95 semantics)."""
+    from tools.c5_layout import run_layout_eval
+    res = run_layout_eval(torch.device(DEV), n=1000, batch=32)
+    print("[parity] config 5:", json.dumps({k: v for k, v in res.items() if k != "per_image"}))
+    assert res["render_crc_mismatches"] == 0
+    f32, bf16 = res["f32"], res["bf16"]
+    assert f32["signal_max_abs_vs_reference"] < 2e-5
+    assert f32["corner_count_mismatches"] <= 1 and f32["iou3d_mean"] > 0.9999       # a 1e-7 signal difference may flip one vote in 1000
+    assert bf16["iou3d_mean"] >= 0.999 and bf16["corner_count_mismatches"] <= 10

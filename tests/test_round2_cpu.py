@@ -1,0 +1,153 @@
+"""CPU tests of the round-2 host pieces: reference-format checkpoints + resume bookkeeping, the learning-rate schedule
+against values produced by the reference's own ``adjust_learning_rate``, ImageNet-weight loading into the LR_PAD-wrapped
+trunk, the config-5 checkpoint codec and fixtures, the training driver's flag surface."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from horizonnet_amd import HorizonNet
+from horizonnet_amd import utils as hutils
+from horizonnet_amd import model as hmodel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lr_schedule_matches_reference_values(golden_dir):
+    """tests/golden/traincurve_seed41.npz column 2 = args.running_lr written by the reference's misc.utils.adjust_learning_rate."""
+    g = np.load(os.path.join(golden_dir, "traincurve_seed41.npz"))
+    a = argparse.Namespace(lr=1e-4, warmup_lr=1e-6, warmup_iters=0, max_iters=int(g["max_iters"]), lr_pow=0.9, cur_iter=0, running_lr=1e-4)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    got = []
+    for _ in range(len(g["curve"])):
+        hutils.adjust_learning_rate(opt, a)
+        a.cur_iter += 1
+        got.append(opt.param_groups[0]["lr"])
+    assert np.array_equal(np.array(got), g["curve"][:, 2])
+    # warm-up branch (misc/utils.py:36-39)
+    a = argparse.Namespace(lr=1e-4, warmup_lr=1e-6, warmup_iters=10, max_iters=100, lr_pow=0.9, cur_iter=5, running_lr=0)
+    hutils.adjust_learning_rate(opt, a)
+    assert a.running_lr == pytest.approx(1e-6 + (1e-4 - 1e-6) * 0.5)
+    a.cur_iter = 100
+    hutils.adjust_learning_rate(opt, a)
+    assert a.running_lr == 0.0
+
+
+def test_save_model_format_and_resume_bookkeeping(tmp_path):
+    torch.manual_seed(3)
+    net = HorizonNet("resnet50", True)
+    args = argparse.Namespace(id="t", lr=1e-4, best_valid_score=0.5, cur_iter=12)
+    pth = str(tmp_path / "m.pth")
+    hutils.save_model(net, pth, args)
+    blob = torch.load(pth, map_location="cpu", weights_only=False)
+    assert list(blob.keys()) == ["args", "kwargs", "state_dict"] and blob["kwargs"] == {"backbone": "resnet50", "use_rnn": True}
+    back = hutils.load_trained_model(HorizonNet, pth)
+    for (k, a), (k2, b) in zip(net.state_dict().items(), back.state_dict().items()):
+        assert k == k2 and torch.equal(a, b)
+    # rolling checkpoint: optimiser state, counters and RNG streams survive
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    hutils.save_checkpoint(hutils.make_checkpoint(net, opt, 3, args), True, str(tmp_path), 3)
+    nxt_np, nxt_t = np.random.rand(), float(torch.rand(1))
+    assert os.path.isfile(tmp_path / "checkpoint.pth.tar") and os.path.isfile(tmp_path / "best_model_3.pth.tar")
+    net2 = HorizonNet("resnet50", True)
+    opt2 = torch.optim.Adam(net2.parameters(), lr=1e-4)
+    args2 = argparse.Namespace(best_valid_score=0, cur_iter=0, iters_per_epoch=4)
+    np.random.seed(99)
+    first = hutils.resume_checkpoint(str(tmp_path / "checkpoint.pth.tar"), net2, opt2, args2, torch.device("cpu"))
+    assert first == 4 and args2.cur_iter == 12 and args2.best_valid_score == 0.5
+    assert np.random.rand() == nxt_np and float(torch.rand(1)) == nxt_t
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
+    # a checkpoint written by the reference itself (no cur_iter / rng) resumes from the epoch count
+    ref_style = {"epoch": 2, "state_dict": net.state_dict(), "optimizer": opt.state_dict(), "best_valid_score": 0.25, "backbone": "resnet50"}
+    torch.save(ref_style, tmp_path / "ref.pth.tar")
+    assert hutils.resume_checkpoint(str(tmp_path / "ref.pth.tar"), net2, opt2, args2, torch.device("cpu")) == 3
+    assert args2.cur_iter == 8 and args2.best_valid_score == 0.25
+    assert hutils.unwrap(torch.nn.DataParallel(net)) is net
+
+
+def test_imagenet_weights_are_loaded_when_available(tmp_path, monkeypatch):
+    """reference model.py:66-69,204-207 builds the encoder from torchvision's IMAGENET1K_V1 weights.  A file in
+    torchvision's key layout must land in the LR_PAD-wrapped trunk (conv1 -> conv1.1, convN.conv2 -> conv2.1)."""
+    torch.manual_seed(11)
+    trunk = hmodel._ResNet50Trunk()
+    tv = {}
+    for k, v in trunk.state_dict().items():
+        tk = k.replace("conv1.1.weight", "conv1.weight") if k == "conv1.1.weight" else k.replace(".conv2.1.weight", ".conv2.weight")
+        tv[tk] = torch.randn_like(v) if v.is_floating_point() else v.clone()
+    tv["fc.weight"], tv["fc.bias"] = torch.randn(1000, 2048), torch.randn(1000)
+    path = str(tmp_path / "resnet50-0676ba61.pth")
+    torch.save(tv, path)
+    monkeypatch.setenv("HORIZONNET_RESNET50_WEIGHTS", path)
+    net = HorizonNet("resnet50", True)
+    assert net.feature_extractor.pretrained_loaded
+    sd = net.state_dict()
+    assert torch.equal(sd["feature_extractor.encoder.conv1.1.weight"], tv["conv1.weight"])
+    assert torch.equal(sd["feature_extractor.encoder.layer3.4.conv2.1.weight"], tv["layer3.4.conv2.weight"])
+    assert torch.equal(sd["feature_extractor.encoder.layer4.0.downsample.1.running_var"], tv["layer4.0.downsample.1.running_var"])
+    # without any source: loud warning, random init (documented difference)
+    monkeypatch.delenv("HORIZONNET_RESNET50_WEIGHTS")
+    monkeypatch.setattr(hmodel, "_torchvision_resnet50_state_dict", lambda: None)
+    with pytest.warns(RuntimeWarning, match="ImageNet"):
+        net = HorizonNet("resnet50", True)
+    assert not net.feature_extractor.pretrained_loaded
+
+
+def test_config5_checkpoint_codec_and_fixture(golden_dir):
+    from tools import c5_common as c5
+    w = (np.random.RandomState(0).randn(8, 16, 3, 3) * 0.05).astype(np.float32)
+    for bits in (4, 6):
+        q, s = c5.quantize_tensor(w, bits)
+        d = c5.dequantize_tensor(q, s)
+        q2, s2 = c5.quantize_tensor(d, bits)
+        assert np.array_equal(q, q2) and np.abs(np.abs(q).max(1).max() - ((1 << (bits - 1)) - 1)) == 0     # on-grid values are fixed points
+        assert np.abs(d - w).max() <= 0.5 * s.max() + 1e-9
+    sd = c5.decode_state_dict()
+    spec = json.load(open(os.path.join(golden_dir, "state_dict_spec.json")))
+    assert list(sd.keys()) == [k[0] if isinstance(k, (list, tuple)) else k for k in spec["keys"]]
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    big = sd["reduce_height_module.ghc_lst.3.layer.0.layers.0.1.weight"]
+    assert c5.bits_for(big.shape) == 4 and len(torch.unique(big[0] / big[0].abs().max() * 7).round().unique()) <= 15
+    z = np.load(os.path.join(golden_dir, "config5", "reference_layouts.npz"))
+    n = int(z["n"])
+    assert n == 1000 and z["count"].sum() == len(z["cor_id"]) and len(z["crc"]) == n
+    mix = dict(zip(*np.unique(z["count"] // 2, return_counts=True)))
+    assert mix.get(4, 0) > 300 and sum(v for k, v in mix.items() if k > 4) > 150       # general layouts, not only cuboids
+    img, _ = c5.make_room(c5.room_jobs(1, int(z["seed0"]), 3)[0])
+    assert c5.image_crc(img) == int(z["crc"][3])                                       # the renderer is deterministic
+
+
+def test_train_driver_keeps_reference_flags():
+    from horizonnet_amd import train as drv
+    flags = {a.option_strings[0] for a in drv.build_parser()._actions if a.option_strings}
+    reference_flags = {"--id", "--ckpt", "--logs", "--pth", "--backbone", "--no_rnn", "--train_root_dir", "--valid_root_dir", "--no_flip",
+                       "--no_rotate", "--no_gamma", "--no_pano_stretch", "--num_workers", "--freeze_earlier_blocks", "--batch_size_train",
+                       "--batch_size_valid", "--epochs", "--optim", "--lr", "--lr_pow", "--warmup_lr", "--warmup_epochs", "--beta1",
+                       "--weight_decay", "--bn_momentum", "--no_cuda", "--multi_gpu", "--device", "--seed", "--disp_iter", "--save_every"}
+    assert reference_flags <= flags, reference_flags - flags                             # train.py:63-135
+    a = drv.build_parser().parse_args(["--id", "x"])
+    assert (a.lr, a.lr_pow, a.epochs, a.batch_size_train, a.optim, a.seed, a.save_every) == (1e-4, 0.9, 300, 8, "Adam", 594277, 25)
+
+
+def test_frozen_block_fixture_is_consistent(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "train_step_frozen_seed33.json")))
+    net = HorizonNet("resnet50", True)
+    names = [k for k, _ in net.named_parameters()]
+    assert names == meta["names"]
+    blocks = net.feature_extractor.list_blocks()
+    for i in range(meta["freeze_earlier_blocks"] + 1):
+        for m in blocks[i]:
+            for p in m.parameters():
+                p.requires_grad = False
+    assert [k for k, p in net.named_parameters() if p.requires_grad] == meta["live"]
+    bn_names = [k for k, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(bn_names) == 69 and all(any(b.startswith(n) for n in bn_names) for b in meta["frozen_bn_buffers"])

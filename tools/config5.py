@@ -2,7 +2,7 @@
 
 There is no dataset and no trained checkpoint offline, so:
 
-1. render a synthetic Structured3D-shaped set of Manhattan rooms (oracle/synth_rooms.py) -- panoramas + label_cor;
+1. render a synthetic Structured3D-shaped set of Manhattan rooms (tools/synth_rooms.py) -- panoramas + label_cor;
 2. train HorizonNet from random init on the MI355X engine for a few hundred steps with ALL of the reference's
    augmentations (flip, rotate, gamma, Pano-Stretch) through the fused device pipeline (horizonnet_amd.dataset
    .DeviceBatcher), losses / optimiser of train.py:44-58,272-281 (float32; configs[2] asks bf16 -- not built yet);
@@ -26,28 +26,8 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from oracle import synth_rooms as sr  # noqa: E402
 from oracle.hostinfo import usable_cores  # noqa: E402
-
-ST3D_MIX = [4] * 63 + [6] * 17 + [8] * 8 + [10] * 12        # README_ST3D.md:49-56 corner-count mix
-
-
-def _make_room(args):
-    seed, n_corners = args
-    rng = np.random.RandomState(seed)
-    for _ in range(1000):                                   # bounded: ~10-20 % of notched rooms hide a corner
-        poly = sr.manhattan_polygon(rng, n_corners)
-        zc, zf = rng.uniform(1.0, 1.6), rng.uniform(1.2, 1.7)
-        cor = sr.room_corners(poly, zc, zf)
-        if np.all(np.diff(cor[::2, 0]) > 10) and cor[0, 0] + 1024 - cor[-2, 0] > 10:    # every corner visible, none merged
-            return sr.render_image(poly, zc, zf, rng), cor
-    raise RuntimeError("no fully visible room found")
-
-
-def make_rooms(n, seed0, pool):
-    jobs = [(seed0 + i, ST3D_MIX[(i * 37) % 100]) for i in range(n)]
-    res = pool.map(_make_room, jobs)
-    return np.stack([r[0] for r in res]), [r[1] for r in res]
+from tools.c5_common import make_rooms, make_room as _make_room, ST3D_MIX  # noqa: E402,F401
 
 
 def layouts(bon, cor_prob, peaks_fn):
