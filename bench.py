@@ -236,10 +236,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
     from horizonnet_amd import broadcast_module_
     from horizonnet_amd.dataset import DeviceBatcher
     from tools import c5_common as c5
-    try:
-        cores = max(1, len(os.sched_getaffinity(0)) // max(1, world))
-    except Exception:
-        cores = 4
+    cores = max(1, c5.usable_cores() // max(1, world))
     with mp.get_context("fork").Pool(cores) as pool:
         imgs, cors = c5.make_rooms(rooms, 20_000 + 1000 * rank, pool, mix=[4])
     data = DeviceBatcher(images=imgs, corners=cors, device=dev, flip=True, rotate=True, gamma=True, stretch=True)

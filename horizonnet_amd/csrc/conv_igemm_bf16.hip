@@ -360,6 +360,281 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
+// ---- 8-wave large-tile variant (inference forward; no stem / data-gradient / statistics modes) ---------------------
+// 512 threads = 2 waves per SIMD from ONE workgroup, tiles 256x256 (wave tile 128x64), 256x128 and 128x256 (64x64):
+// the 128x128 / 4-wave kernel above moves 0.5 KiB from L2 into LDS per MFMA -- 64 B/clk/CU at the full matrix rate, more
+// than the ~56 B/clk/CU the L2 delivers -- and reads 1 KiB of LDS per MFMA; the 256x256 tile halves the first (0.25 KiB)
+// and cuts the second to 0.75 KiB, with one workgroup per CU (128 KiB of LDS for the two stages) whose second wave per
+// SIMD covers the other's barrier / fragment-read gaps.  Loader, swizzle, OOB handling and k order are the 4-wave
+// kernel's (same results bit for bit: the accumulation order over k does not depend on the tile shape).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32>
+__global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
+{
+    static_assert(WAVES_M * WAVES_N == 8, "8 waves per workgroup");
+    constexpr int NW = 8;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr int AP = BM / 64, BP = BN / 64;              // loader passes: 64 rows (512 threads x 16 bytes) each
+    constexpr int A_BYTES = BM * ROWB;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid >> 3;                              // 0..63
+    const int lslot = tid & 7;
+    const int lcol = lslot ^ ((lrow >> 1) & 7);
+
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int NT = p.Cout / BN;
+    const int nt = bid % NT;
+    const int mt = bid / NT;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int hw_out = p.Ho * p.Wo;
+    const int b_first = m0 / hw_out;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w + (size_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
+
+    int a_pix0[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int m = m0 + lrow + 64 * q;
+        if (m < p.M) {
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int b = t / p.Ho;
+            a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
+            a_hi0[q] = ho * p.sh - p.ph;
+            a_wi0[q] = wo * p.sw - p.pw;
+        } else {
+            a_pix0[q] = -1;
+            a_hi0[q] = 0;
+            a_wi0[q] = 0;
+        }
+    }
+    unsigned w_off[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) w_off[q] = (unsigned)((lrow + 64 * q) * p.K + lcol * 8) * 2u;
+
+    unsigned a_off[AP];
+    auto tap_offsets = [&](int dh, int dw) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const int hi = a_hi0[q] + dh;
+            int wi = a_wi0[q] + dw;
+            wi = wi < 0 ? wi + p.Wi : wi;
+            wi = wi >= p.Wi ? wi - p.Wi : wi;
+            const bool ok = a_pix0[q] >= 0 && ((unsigned)hi < (unsigned)p.Hi);
+            const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
+            a_off[q] = ok ? (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u : OOB;
+        }
+    };
+
+    int dh = 0, dw = 0, c0 = 0;
+    tap_offsets(0, 0);
+
+    auto fetch = [&](int kc) {       // chunk kc -> LDS stage (kc & 1)
+        char* a_s = smem + (kc & 1) * STAGE_BYTES;
+        char* b_s = a_s + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < AP; ++q) dma16(rsrc_a, a_s + (q * NW + wave) * 1024, a_off[q], (unsigned)c0 * 2u);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) dma16(rsrc_w, b_s + (q * NW + wave) * 1024, w_off[q], (unsigned)kc * (unsigned)ROWB);
+        c0 += BKE;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            if (++dw == p.KW) { dw = 0; ++dh; }
+            tap_offsets(dh, dw);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31;
+    const int half = lane >> 5;
+    const int fswz = (fr >> 1) & 7;
+
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    {
+        u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto ldfrag = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN], int buf, int ks) {
+            const int koff = ((2 * ks + half) ^ fswz) * 16;
+            const char* a_s = smem + buf * STAGE_BYTES + (wm * WM + fr) * ROWB + koff;
+            const char* b_s = smem + buf * STAGE_BYTES + A_BYTES + (wn * WN + fr) * ROWB + koff;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a_s + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b_s + j * 32 * ROWB);
+        };
+        auto mma = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        };
+        ldfrag(fa0, fb0, 0, 0);
+        for (int kc = 0; kc < p.nk; ++kc) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < p.nk;
+            if (more) fetch(kc + 1);
+            ldfrag(fa1, fb1, buf, 1);
+            mma(fa0, fb0);
+            ldfrag(fa0, fb0, buf, 2);
+            mma(fa1, fb1);
+            ldfrag(fa1, fb1, buf, 3);
+            mma(fa0, fb0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc+1 has landed
+            __syncthreads();
+            if (more) ldfrag(fa0, fb0, buf ^ 1, 0);
+            mma(fa1, fb1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: per 32-row MFMA band i, every wave row writes its band into its own LDS slab ([32][BN] floats);
+    //      the 512 threads then sweep the WAVES_M slabs as whole rows: scale/shift, residual, ReLU, 16-byte stores ----
+    constexpr int CS = BN + 4;
+    constexpr int SLAB = 32 * CS;                           // floats
+    static_assert(WAVES_M * SLAB * 4 <= 2 * STAGE_BYTES, "C slabs must fit in the staging LDS");
+    constexpr int TPR = BN / 8;                             // threads per output row (8 channels each)
+    constexpr int RPP = 512 / TPR;                          // rows per sweep pass
+    constexpr int NPASS = WAVES_M * 32 / RPP;
+    static_assert(NPASS >= 1 && (WAVES_M * 32) % RPP == 0, "sweep geometry");
+    float* cs = reinterpret_cast<float*>(smem);
+    const int ccol = (tid % TPR) * 8;
+    const int crow = tid / TPR;
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
+    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol + 4);
+    const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
+    const f32x4 sf1 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol + 4);
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        u32x4 rres[NPASS];
+        if (has_res) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int sr = crow + ps * RPP;             // 0 .. WAVES_M*32-1: slab sr / 32, row sr % 32
+                const int m = m0 + (sr >> 5) * WM + i * 32 + (sr & 31);
+                const int mc = m < p.M ? m : p.M - 1;
+                rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
+            }
+        }
+        if (i > 0) __syncthreads();
+        {
+            float* c_w = cs + wm * SLAB + (4 * half) * CS + wn * WN + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c_w[((r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int sr = crow + ps * RPP;
+            const int m = m0 + (sr >> 5) * WM + i * 32 + (sr & 31);
+            const float* src = cs + (sr >> 5) * SLAB + (sr & 31) * CS + ccol;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+            v0 = v0 * sc0 + sf0;
+            v1 = v1 * sc1 + sf1;
+            if (has_res) {
+                const u32x4 rr = rres[ps];
+                v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
+                v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+            }
+            if (m < p.M) {
+                if (OUT_F32) {
+                    float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n0 + ccol;
+                    *reinterpret_cast<f32x4*>(yo) = v0;
+                    *reinterpret_cast<f32x4*>(yo + 4) = v1;
+                } else {
+                    u32x4 o;
+                    o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+                    o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + n0 + ccol) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32>
+int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
+{
+    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32>;
+    static bool attr_done[64] = {};   // per instantiation, per device
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[dev] = true;
+    }
+    const int MT = hn_cdiv(a.M, BM);
+    const int NT = a.Cout / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(512), lds, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tile choice for the inference forward: a large tile only where it still fills the 256 CUs and K is deep enough to
+// amortise its prologue / epilogue.  HN_BF16_W8 = 0 disables the 8-wave kernels, 1 = 256x256, 2 = 256x128, 3 = 128x256
+// force one (A/B runs, tests).
+template <bool OUT_F32>
+int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
+{
+    const char* env = getenv("HN_BF16_W8");              // read per call: tools/conv_sweep.py flips it between launches
+    const int force = env ? atoi(env) : -1;
+    *taken = true;
+    if (force == 0 || a.stat_sum != nullptr) { *taken = false; return 0; }
+    const long M = a.M;
+    const long t256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
+    const long t128x256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 128) * (Cout / 256) : 0;
+    const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
+    if (force == 1 && t256) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
+    if (force == 2 && t256x128) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
+    if (force == 3 && t128x256) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
+    if (force < 0 && a.nk >= 8) {
+        if (t256 >= 224) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
+        if (t128x256 >= 224) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
+        if (t256x128 >= 224) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
+    }
+    *taken = false;
+    return 0;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool OUT_F32, bool TR = false>
 int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
 {
@@ -552,7 +827,7 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;
     HN_REQUIRE(!d.res || !out_f32, "conv bf16: a residual with float32 output is only used by the data-gradient launcher");
     {
-        const double span = 128.0 / ((double)d.Ho * d.Wo) + 2.0;
+        const double span = 256.0 / ((double)d.Ho * d.Wo) + 2.0;
         HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 8 : a.xstride) * 2.0 < 2147483648.0, "conv bf16: image too large for 32-bit tile offsets");
     }
     if (d.stem) {
@@ -566,7 +841,12 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     HN_REQUIRE(d.Cout % 32 == 0, "conv bf16: Cout=%d must be a multiple of 32", d.Cout);
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BKE;
-    HN_REQUIRE(128.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
+    HN_REQUIRE(256.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
+    {
+        bool taken = false;
+        const int rc = out_f32 ? dispatch_w8<true>(a, d.Cout, s, &taken) : dispatch_w8<false>(a, d.Cout, s, &taken);
+        if (taken) return rc;
+    }
     return out_f32 ? dispatch<true>(a, d.Cout, s) : dispatch<false>(a, d.Cout, s);
 }
 

@@ -233,11 +233,11 @@ extern "C" int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_s
                                    const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
                                    int relu, int out_f32, void* stream)
 {
-    HN_REQUIRE(x && w_oihw && w_scratch && scale && shift && y, "hn_conv2d_nhwc_bf16: null pointer");
+    HN_REQUIRE(x && w_scratch && scale && shift && y, "hn_conv2d_nhwc_bf16: null pointer");
     HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = hn_launch_pack_conv_bf16(w_oihw, w_scratch, Cout, Cin, KH, KW, s))) return rc;
+    if (w_oihw && (rc = hn_launch_pack_conv_bf16(w_oihw, w_scratch, Cout, Cin, KH, KW, s))) return rc;   // NULL: w_scratch is already packed
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = reinterpret_cast<const float*>(x); d.w = reinterpret_cast<const float*>(w_scratch); d.scale = scale; d.shift = shift;

@@ -124,11 +124,78 @@ def inference(net, x, device, flip=False, rotate=[], visualize=False,
     return cor_id, z0, z1, vis_out
 
 
+class _MaskPeaks:
+    """peaks_fn over peak masks computed on the device for the whole batch (picklable: goes to the fit workers)."""
+
+    def __init__(self, masks):
+        self.masks = masks                       # {min_v: uint8 [W]}
+
+    def __call__(self, signal, r, min_v, N):
+        pk_loc = np.where(self.masks[float(min_v)] != 0)[0]
+        if N is not None:                        # inference.py:25-28: the N largest, in column order
+            order = np.argsort(-signal[pk_loc])
+            pk_loc = pk_loc[order[:N]]
+            pk_loc = pk_loc[np.argsort(pk_loc)]
+        return pk_loc, signal[pk_loc]
+
+
+def _fit_one(job):
+    y_bon, y_cor, H, W, force_cuboid, force_raw, min_v, r, masks = job
+    return layout_from_signals(y_bon, y_cor, H, W, force_cuboid, force_raw, min_v, r, _MaskPeaks(masks))
+
+
+_POOL = {"pool": None, "n": 0}
+
+
+def _usable_cores():
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.floor(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _fit_pool(workers):
+    """Process pool for the host Manhattan fit (pure numpy; the workers never touch the GPU)."""
+    import multiprocessing as mp
+    if _POOL["pool"] is None or _POOL["n"] != workers:
+        if _POOL["pool"] is not None:
+            _POOL["pool"].terminate()
+        _POOL["pool"] = mp.get_context("fork").Pool(workers)
+        _POOL["n"] = workers
+    return _POOL["pool"]
+
+
 def inference_batch(net, x, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
-                    peaks_fn=None):
-    """x [B,3,512,1024]: one engine forward for all B x augmentations, then the host fit per panorama.
-    -> list of (cor_id, z0, z1)."""
+                    peaks_fn=None, workers=None):
+    """x [B,3,512,1024]: one engine forward for all B x augmentations, ONE peak-detection launch per threshold for the
+    whole batch (hn_find_peaks), then the host Manhattan fit of the B panoramas spread over `workers` processes
+    (default: the usable host cores, inline for small batches; 0 = inline).  -> list of (cor_id, z0, z1), identical to
+    B calls of ``inference``."""
+    from .peaks import find_peaks_batch
     H, W = tuple(x.shape[2:])
+    B = int(x.shape[0])
     _, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
-    return [layout_from_signals(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn)
-            for b in range(x.shape[0])]
+    if peaks_fn is not None:                     # caller-supplied peak finder: the per-panorama path
+        return [layout_from_signals(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn) for b in range(B)]
+    mv = (0.0 if force_cuboid else 0.05) if min_v is None else float(min_v)
+    rr = int(round(W * r / 2))
+    prob = torch.from_numpy(np.ascontiguousarray(y_cor[:, 0], dtype=np.float32)).to(device)
+    masks = {mv: find_peaks_batch(prob, rr, mv)[0].cpu().numpy()}
+    if 0.0 not in masks:                         # the cuboid fallback of inference.py:121-126 re-detects with min_v = 0
+        masks[0.0] = find_peaks_batch(prob, rr, 0.0)[0].cpu().numpy()
+    jobs = [(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, {k: v[b] for k, v in masks.items()}) for b in range(B)]
+    if workers is None:
+        workers = min(_usable_cores(), 32) if B >= 8 else 0
+    if workers <= 1:
+        return [_fit_one(j) for j in jobs]
+    return _fit_pool(workers).map(_fit_one, jobs, chunksize=max(1, B // (4 * workers)))

@@ -102,7 +102,8 @@ int hn_pack_weights_bf16(hn_engine* e, void* packed_bf16, size_t bytes, void* st
 size_t hn_workspace_bf16_bytes(int B);
 int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
                     size_t workspace_bytes, void* stream);
-/* per-stage (tests): x / res / y bf16 NHWC (y f32 when out_f32), w_oihw f32, w_scratch Cout*KH*KW*Cin bf16 */
+/* per-stage (tests): x / res / y bf16 NHWC (y f32 when out_f32), w_oihw f32, w_scratch Cout*KH*KW*Cin bf16
+ * (w_oihw == NULL: w_scratch already holds the packed weights of an earlier call) */
 int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
                         const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
                         int relu, int out_f32, void* stream);

@@ -462,3 +462,28 @@ def test_inference_engine_raw_layout(golden_dir):
     with torch.no_grad():
         aug = inference(net, x, DEV, flip=True, rotate=[0.25], force_raw=True)[0]
     assert aug.shape == (2048, 2) and np.isfinite(aug).all()
+
+
+def test_inference_batch_pooled_equals_per_panorama_and_reference(golden_dir):
+    """inference_batch (one forward, one hn_find_peaks launch per threshold, Manhattan fits in worker processes) must
+    return exactly what per-panorama inference() returns -- and what the unmodified reference returned (postproc.npz) --
+    for general layouts, forced cuboids and the self-intersection -> cuboid fallback."""
+    import json
+    from horizonnet_amd.inference import inference, inference_batch
+    from oracle import synth_rooms as sr
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "postproc.json")))
+    kinds = ({"force_cuboid": False}, {"force_cuboid": True}, {"force_cuboid": False, "min_v": 0.3, "r": 0.1},
+             {"flip": True, "force_cuboid": False, "rotate": [0.25, -0.1]})
+    for kw in kinds:
+        sel = [(m["case"], k) for m in meta for k, run in enumerate(m["runs"]) if run["kw"] == kw][:40]
+        assert len(sel) >= 16, kw
+        xs = torch.stack([torch.from_numpy(np.broadcast_to(g["x_%d" % j][:, None, :], (3, 512, 1024)).copy()) for j, _ in sel])
+        for workers in (0, 4):
+            out = inference_batch(sr.SignalNet(), xs, DEV, workers=workers, **kw)
+            for (j, k), (cor_id, z0, z1) in zip(sel, out):
+                want = g["inf%d_%d" % (k, j)]
+                assert cor_id.shape == want.shape, (j, k, workers)
+                assert float(np.abs(cor_id - want).max()) < 1e-6 and abs(z1 - float(g["infz1_%d_%d" % (k, j)])) < 1e-9
+        one = inference(sr.SignalNet(), xs[:1], DEV, **kw)
+        assert np.array_equal(one[0], out[0][0]) and one[2] == out[0][2]

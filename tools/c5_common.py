@@ -24,6 +24,30 @@ VAL_SEED0 = 50_000                                           # room i of the 100
 TRAIN_SEED0 = 10_000
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask AND the cgroup quota (the MI355X box shows 256 logical CPUs
+    and grants 16)."""
+    import math
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.floor(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def bits_for(shape):
     n = 1
     for d in shape:

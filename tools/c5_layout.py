@@ -20,10 +20,7 @@ FIXTURE = os.path.join(c5.ROOT, "tests", "golden", "config5", "reference_layouts
 
 
 def _cores():
-    try:
-        return max(1, len(os.sched_getaffinity(0)))
-    except Exception:
-        return os.cpu_count() or 1
+    return c5.usable_cores()
 
 
 def load_reference():

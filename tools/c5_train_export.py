@@ -24,11 +24,7 @@ from tools import c5_common as c5  # noqa: E402
 from tools.config5 import layouts, pair_iou  # noqa: E402
 
 
-def usable_cores():
-    try:
-        return max(1, len(os.sched_getaffinity(0)))
-    except Exception:
-        return os.cpu_count() or 1
+usable_cores = c5.usable_cores
 
 
 def evaluate(net, val, gt, dev, precisions=("f32",)):
