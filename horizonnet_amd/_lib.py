@@ -24,6 +24,7 @@ SIGNATURES = {
     "hn_workspace_bytes": (_sz, [_i]),
     "hn_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hn_check_status": (_i, [_vp, _vp, _c.POINTER(_i)]),
+    "hn_set_option": (_i, [_vp, _c.c_char_p, _i]),
     "hn_set_forward_tap": (_i, [_vp, _c.c_char_p, _vp]),
     "hn_set_profiling": (_i, [_vp, _i]),
     "hn_profile_count": (_i, [_vp]),

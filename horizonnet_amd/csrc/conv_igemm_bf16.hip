@@ -626,11 +626,11 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     if (force == 1 && t256) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
     if (force == 2 && t256x128) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
     if (force == 3 && t128x256) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
-    if (force < 0 && a.nk >= 8) {
-        if (t256 >= 224) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
-        if (t128x256 >= 224) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
-        if (t256x128 >= 224) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
-    }
+    // measured on every conv shape of the B = 32 forward (tools/conv_sweep.py, profiles/r2_conv_tile_sweep.txt): the
+    // 256x256 tile wins by 10-25 % wherever it yields >= 224 workgroups (1.0-1.16 PF on the deep-K convs vs 0.8-0.96),
+    // also on the HBM-bound 1x1 convs; with 128 workgroups (layer4 3x3, ghc3.0) half the CUs idle and it loses; the
+    // 256x128 / 128x256 shapes (64x64 wave tiles) never beat the 4-wave 128x128 kernel and are kept for A/B runs only
+    if (force < 0 && t256 >= 224) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
     *taken = false;
     return 0;
 }
@@ -649,7 +649,13 @@ int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
     }
     const int MT = hn_cdiv(a.M, BM);
     const int NT = a.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(256), lds, s, a);
+    // a one-chunk GEMM (1x1 conv with 64 input channels: layer1's conv3 / downsample, HBM-bound) never touches the second
+    // LDS stage: launch with one stage (+ the epilogue's C tile) so that 4 workgroups instead of 2 share a CU and their
+    // load / compute / store phases overlap
+    constexpr size_t c_tile = (size_t)(BM / WAVES_M) * (BN + 4) * 4;
+    constexpr size_t one_stage = (size_t)(BM + BN) * ROWB;
+    const size_t lds_launch = (a.nk <= 1 && !a.stat_sum) ? (c_tile > one_stage ? c_tile : one_stage) : lds;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(256), lds_launch, s, a);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -169,16 +169,38 @@ extern "C" int hn_create(hn_engine** out, int device)
                prop.multiProcessorCount);
     hn_engine* e = new hn_engine();
     e->device = device;
+    {
+        DeviceGuard guard(device);
+        HN_REQUIRE(guard.ok, "hn_create: cannot select device %d", device);
+        HN_HIP(hipStreamCreateWithFlags(&e->branch_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) {
+            HN_HIP(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming));
+            HN_HIP(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+        }
+    }
     *out = e;
     return 0;
 }
 
 extern "C" int hn_destroy(hn_engine* e)
 {
-    if (e)
+    if (e) {
         for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+        for (int i = 0; i < 4; ++i) {
+            if (e->ev_fork[i]) (void)hipEventDestroy(e->ev_fork[i]);
+            if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+        }
+        if (e->branch_stream) (void)hipStreamDestroy(e->branch_stream);
+    }
     delete e;
     return 0;
+}
+
+extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
+{
+    HN_REQUIRE(e != nullptr && name != nullptr, "hn_set_option: null argument");
+    if (strcmp(name, "branch_stream") == 0) { e->use_branch_stream = value ? 1 : 0; return 0; }
+    HN_REQUIRE(false, "hn_set_option: unknown option '%s'", name);
 }
 
 extern "C" int hn_set_forward_tap(hn_engine* e, const char* name, void* dst)

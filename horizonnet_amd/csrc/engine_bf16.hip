@@ -37,7 +37,9 @@ size_t hn_bf16_conv_offset(int ci) { return hoff().conv[ci]; }
 namespace {
 
 struct PlanH {                     // byte offsets
-    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y1h, y2, total;
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, total;
+    size_t c[4];                   // C1..C4 (the layer outputs): own buffers, read by the next stage AND by the branch stream
+    size_t ga[4], gb[4];           // per-scale ping-pong of the height-compression chain (the four chains may overlap)
 };
 
 PlanH make_plan_h(int B)
@@ -55,8 +57,12 @@ PlanH make_plan_h(int B)
     p.t1 = take(b * 128 * 256 * 128 * 2);
     p.t2 = take(b * 128 * 256 * 64 * 2);
     p.ds = take(b * 128 * 256 * 256 * 2);
-    p.g0 = take(b * 64 * 256 * 128 * 2);
-    p.g1 = take(b * 64 * 256 * 128 * 2);
+    for (int li = 0; li < 4; ++li) {
+        const size_t hw = (size_t)(128 >> li) * (256 >> li), ch = (size_t)256 << li;
+        p.c[li] = take(b * hw * ch * 2);
+        p.ga[li] = take(b * (hw / 2) * (ch / 2) * 2);          // ghc.0 output; ghc.2 output is smaller
+        p.gb[li] = take(b * (hw / 4) * (ch / 2) * 2);          // ghc.1 output; ghc.3 output is smaller
+    }
     p.seq = take((size_t)T_COLS * b * 1024 * 2);
     p.gx = take((size_t)T_COLS * b * 4096 * 4);
     p.y1 = take((size_t)T_COLS * b * 1024 * 4);
@@ -155,6 +161,11 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
     if ((rc = e->tap("stem", W + pl.stem, (size_t)B * 256 * 512 * 64 * 2, s))) return rc;
     if ((rc = e->tap("pool", W + pl.pool, (size_t)B * 128 * 256 * 64 * 2, s))) return rc;
 
+    // The height-compression chain of scale li depends only on C_li: it is forked onto the engine's branch stream and
+    // runs beside the ResNet stages that follow (small / half-occupancy launches of the two streams fill each other's
+    // idle CUs); the caller's stream joins all four before the LSTM input GEMM.  Profiling / option off: one stream.
+    const bool fork = e->use_branch_stream && !e->profiling && e->branch_stream != nullptr;
+    hipStream_t sb = fork ? e->branch_stream : s;
     const char* cur = W + pl.pool;
     int Hh = 128, Wd = 256;
     const int nblk[4] = {3, 4, 6, 3};
@@ -162,7 +173,7 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
         for (int j = 0; j < nblk[li]; ++j) {
             const int stride = (j == 0 && li > 0) ? 2 : 1;
             const int i1 = a.block_first[li][j];
-            char* out = (cur == W + pl.p0) ? W + pl.p1 : W + pl.p0;
+            char* out = (j == nblk[li] - 1) ? W + pl.c[li] : ((cur == W + pl.p0) ? W + pl.p1 : W + pl.p0);
             if ((rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
             const char* idt = cur;
@@ -180,21 +191,28 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
             const char* cname[4] = {"c1", "c2", "c3", "c4"};
             if ((rc = e->tap(cname[li], cur, (size_t)B * Hh * Wd * (256 << li) * 2, s))) return rc;
         }
+        if (fork) {
+            HN_HIP(hipEventRecord(e->ev_fork[li], s));
+            HN_HIP(hipStreamWaitEvent(sb, e->ev_fork[li], 0));
+        }
         const char* gin = cur;
         int gh = Hh;
-        char* gbuf[2] = {W + pl.g0, W + pl.g1};
+        char* gbuf[2] = {W + pl.ga[li], W + pl.gb[li]};
         for (int k = 0; k < 4; ++k) {
             const int ig = a.ghc_first[li] + k;
             char* gout = gbuf[k & 1];
-            if ((rc = run_conv_h(e, a.convs[ig], h.conv[ig], gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s))) return rc;
+            if ((rc = run_conv_h(e, a.convs[ig], h.conv[ig], gin, gout, nullptr, B, gh, Wd, 2, 1, 1, sb))) return rc;
             gin = gout;
             gh /= 2;
         }
         {
-            ProfScope ps(e, s, "upsample_flatten." + std::to_string(li), 0.0);
-            if ((rc = hn_launch_upsample_flatten_bf16(gin, W + pl.seq, B, gh, Wd, a.convs[a.ghc_first[li] + 3].cout, 256 * li, s))) return rc;
+            ProfScope ps(e, sb, "upsample_flatten." + std::to_string(li), 0.0);
+            if ((rc = hn_launch_upsample_flatten_bf16(gin, W + pl.seq, B, gh, Wd, a.convs[a.ghc_first[li] + 3].cout, 256 * li, sb))) return rc;
         }
+        if (fork) HN_HIP(hipEventRecord(e->ev_join[li], sb));
     }
+    if (fork)
+        for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
 
     // bi-LSTM x2: bf16 input GEMMs with f32 gate pre-activations, f32 recurrence; f32 Linear head
     const long rows = (long)T_COLS * B;

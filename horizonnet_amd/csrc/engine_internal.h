@@ -68,6 +68,12 @@ struct hn_engine {
         HN_HIP(hipMemcpyAsync(it->second, src, bytes, hipMemcpyDeviceToDevice, s));
         return 0;
     }
+    // branch stream: the four height-compression chains (model.py:138-156) depend only on C1..C4 and run beside the
+    // following ResNet stages on an engine-owned second stream (fork / join with events)
+    hipStream_t branch_stream = nullptr;
+    hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    int use_branch_stream = 1;           // 0: everything on the caller's stream (hn_set_option "branch_stream")
     int train_bf16 = 0;                  // 1: train-mode convs (forward + data gradient) on the bf16 matrix cores (hn_set_train_precision)
     bool profiling = false;
     int debug_unit = -1;                 // training debug tap (hn_train_debug_set): unit whose dy / dz are copied out

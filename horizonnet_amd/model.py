@@ -346,6 +346,7 @@ class HorizonNet(nn.Module):
             self.linear.bias[1 * self.step_cols:2 * self.step_cols].fill_(-0.478)
             self.linear.bias[2 * self.step_cols:3 * self.step_cols].fill_(0.425)
         self._hip_states = {}
+        self._engine_options = {}
         self._train_steps = 0
         self.precision = "f32"              # eval mode: "f32" (exact, the parity path) or "bf16"
         self.train_precision = "f32"        # train mode: "f32", or "bf16" = forward + data-gradient convs on the bf16 matrix
@@ -365,6 +366,8 @@ class HorizonNet(nn.Module):
         st = self._hip_states.get(device.index)
         if st is None:
             st = _DeviceState(device)
+            for k, v in self._engine_options.items():
+                _lib.check(st.lib.hn_set_option(st.handle, k.encode(), int(v)), "hn_set_option(%s)" % k)
             self._hip_states[device.index] = st
         tensors = list(self._state_tensors())
         sig = tuple((t.data_ptr(), t._version) for _, t in tensors) + (self._train_steps,)
@@ -384,6 +387,13 @@ class HorizonNet(nn.Module):
             st.signature = sig
         return st
 
+    def set_engine_option(self, name, value):
+        """hn_set_option on every device state of this module (and on states created later), e.g.
+        ``set_engine_option("branch_stream", 0)`` keeps the whole bf16 forward on the caller's stream."""
+        self._engine_options[name] = int(value)
+        for st in self._hip_states.values():
+            _lib.check(st.lib.hn_set_option(st.handle, name.encode(), int(value)), "hn_set_option(%s)" % name)
+
     @staticmethod
     def _push_bn_flags(st, named_bns, flags):
         if flags != st.bn_flags:
@@ -401,7 +411,7 @@ class HorizonNet(nn.Module):
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        d["_hip_states"] = {}
+        d["_hip_states"] = {}                # (engine options are kept: they are plain ints)
         return d
 
     def forward(self, x):

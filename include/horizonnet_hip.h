@@ -79,6 +79,12 @@ int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float*
  * on this workspace (non-zero = the persistent LSTM kernel's bounded spin gave up). */
 int hn_check_status(hn_engine* e, void* workspace, int* status_out);
 
+/* Engine options.  "branch_stream" (default 1): hn_forward_bf16 runs the four height-compression chains
+ * (model.py:138-156), which depend only on C1..C4, on an engine-owned second HIP stream beside the following ResNet
+ * stages (fork / join with events: the caller's stream still orders the whole call); 0 = everything on the caller's
+ * stream.  Results are identical either way. */
+int hn_set_option(hn_engine* e, const char* name, int value);
+
 /* Parity-test taps: during the following hn_forward / hn_forward_bf16 calls the named intermediate is copied
  * (device to device, on the call's stream) into `dst`.  Names and layouts (NHWC; float32 for hn_forward, bf16 for
  * hn_forward_bf16 except "lstm"): "stem" [B,256,512,64] (model.py:73-75), "pool" [B,128,256,64] (:76), "c1" [B,128,256,256],

@@ -122,3 +122,25 @@ def test_forward_bf16_batch32_consistency():
     assert net.hip_status(DEV) == 0
     assert report("bf16 B=32 vs B=4 bon", b32.cpu().numpy(), b4.cpu().numpy()[idx], 1e-5)
     assert report("bf16 B=32 vs B=4 cor", c32.cpu().numpy(), c4.cpu().numpy()[idx], 1e-5)
+
+
+def test_forward_bf16_branch_stream_is_bit_identical():
+    """hn_forward_bf16 forks the four height-compression chains onto the engine's second stream; with the option off
+    everything runs on the caller's stream.  Same kernels, same data: the outputs must be bit-identical, also when the
+    call is issued from a non-default torch stream and repeated back to back (buffer reuse across calls)."""
+    net = _net(0, "random")
+    x = torch.rand(8, 3, 512, 1024, generator=torch.Generator().manual_seed(99)).to(DEV)
+    with torch.no_grad():
+        net.set_engine_option("branch_stream", 0)
+        b0, c0 = net(x)
+        net.set_engine_option("branch_stream", 1)
+        outs = [net(x) for _ in range(3)]
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            bs, cs_ = net(x)
+        torch.cuda.current_stream(DEV).wait_stream(side)
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    for b, c in outs + [(bs, cs_)]:
+        assert torch.equal(b, b0) and torch.equal(c, c0)

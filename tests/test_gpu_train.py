@@ -459,13 +459,13 @@ def test_bf16_train_units_locally_consistent():
         torch.cuda.synchronize()
         _lib.check(L.hn_train_debug_set(st.handle, -1, None, None), "untap")
         _lib.check(L.hn_train_debug_set2(st.handle, -1, None, None), "untap2")
-        ws = st.workspaces[("train", B)].view(torch.float32)
+        ws = st.train_workspace(B).view(torch.float32)
         grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
         out = []
         for u, shape in ((up, pshape), (uc, cshape)):
             n, C = int(np.prod(shape)), info[u][2]
             stt = ws[info[u][6]:info[u][6] + 2 * C].cpu()
-            zraw = st.workspaces[("train", B)][info[u][4] * 4:info[u][4] * 4 + 2 * n]        # bf16 mode stores z as bf16
+            zraw = st.train_workspace(B)[info[u][4] * 4:info[u][4] * 4 + 2 * n]        # bf16 mode stores z as bf16
             out.append(dict(dy=bufs[u][0].cpu().view(shape), dz=bufs[u][1].cpu().view(shape),
                             z=zraw.view(torch.bfloat16).float().cpu().view(shape), y=ws[info[u][5]:info[u][5] + n].cpu().view(shape),
                             mean=stt[:C], invstd=stt[C:], grads=grads))

@@ -62,7 +62,7 @@ for w in want:
         ref_dy = yt.grad.permute(0, 2, 3, 1).reshape(M, C)
         e_dy = (dy.cpu().view(M, C) - ref_dy).abs().max().item() / ref_dy.abs().max().item()
     # engine-side saved tensors of this unit vs the oracle's
-    ws = st.workspaces[("train", B)].view(torch.float32)
+    ws = st.train_workspace(B).view(torch.float32)
     zoff, yoff = info[u][4], info[u][5]
     ez = (ws[zoff:zoff + M * C].cpu().view(M, C) - zt.detach().permute(0, 2, 3, 1).reshape(M, C)).abs().max().item()
     ey = (ws[yoff:yoff + M * C].cpu().view(M, C) - yt.detach().permute(0, 2, 3, 1).reshape(M, C)).abs().max().item() if yt is not None else float("nan")

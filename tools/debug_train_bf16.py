@@ -34,7 +34,7 @@ for w in want:
         for p in net.parameters(): p.grad = None
         ((bon * wb).sum() + (cor * wc).sum()).backward()
         torch.cuda.synchronize()
-        ws = st.workspaces[("train", B)].view(torch.float32)
+        ws = st.train_workspace(B).view(torch.float32)
         z = ws[info[u][4]:info[u][4] + M * C].clone()
         res[prec] = (dy.clone(), dz.clone(), z, bon.detach().clone())
     a, b = res["f32"], res["bf16"]
