@@ -13,6 +13,7 @@ typedef unsigned short u16;
 struct HOff {
     std::vector<size_t> conv;      // element offsets of the packed bf16 conv weights, arch().convs order
     size_t wih[2];
+    size_t whh[2][2];              // recurrent weights [layer][direction], bf16 [2048][512] (lstm_bf16.hip)
     size_t total;                  // elements
 };
 
@@ -24,6 +25,8 @@ const HOff& hoff()
         auto take = [&](size_t n) { size_t o = off; off += (n + 127) / 128 * 128; return o; };
         for (const auto& c : arch().convs) h.conv.push_back(take(c.k == 7 ? (size_t)c.cout * 7 * 8 * 8 : (size_t)c.cout * c.k * c.k * c.cin));
         for (int l = 0; l < 2; ++l) h.wih[l] = take((size_t)4096 * 1024);
+        for (int l = 0; l < 2; ++l)
+            for (int d = 0; d < 2; ++d) h.whh[l][d] = take((size_t)2048 * 512);
         h.total = off;
         return h;
     }();
@@ -37,7 +40,7 @@ size_t hn_bf16_conv_offset(int ci) { return hoff().conv[ci]; }
 namespace {
 
 struct PlanH {                     // byte offsets
-    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, total;
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, xch, total;
     size_t c[4];                   // C1..C4 (the layer outputs): own buffers, read by the next stage AND by the branch stream
     size_t ga[4], gb[4];           // per-scale ping-pong of the height-compression chain (the four chains may overlap)
 };
@@ -68,6 +71,7 @@ PlanH make_plan_h(int B)
     p.y1 = take((size_t)T_COLS * b * 1024 * 4);
     p.y1h = take((size_t)T_COLS * b * 1024 * 2);
     p.y2 = take((size_t)T_COLS * b * 1024 * 4);
+    p.xch = take(hn_lstm_bf16_xch_bytes());
     p.total = off;
     return p;
 }
@@ -118,8 +122,11 @@ extern "C" int hn_pack_weights_bf16(hn_engine* e, void* packed_h, size_t bytes, 
         HN_REQUIRE(it != e->bound.end(), "hn_pack_weights_bf16: '%s.weight' was never bound", c.wkey.c_str());
         if ((rc = hn_launch_pack_conv_bf16(reinterpret_cast<const float*>(it->second), H + h.conv[i], c.cout, c.cin, c.k, c.k, s))) return rc;
     }
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < 2; ++l) {
         if ((rc = hn_launch_f32_to_bf16(e->packed + a.wih_off[l], H + h.wih[l], (long)4096 * 1024, s))) return rc;
+        for (int d = 0; d < 2; ++d)
+            if ((rc = hn_launch_f32_to_bf16(e->packed + a.whh_off[l][d], H + h.whh[l][d], (long)2048 * 512, s))) return rc;
+    }
     e->packed_h = packed_h;
     return 0;
 }
@@ -232,18 +239,32 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
         }
         {
             ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".recurrence", 2.0 * rows * 512.0 * 2048 * 2);
-            if ((rc = hn_launch_lstm_layer(reinterpret_cast<float*>(W + pl.gx), P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l], T_COLS, B,
-                                           W + pl.sync, s)))
+            if (e->bf16_lstm) {      // recurrent matmul on the bf16 matrix cores, 8-workgroup groups, granule hand-off (lstm_bf16.hip)
+                if ((rc = hn_launch_lstm_layer_bf16(reinterpret_cast<float*>(W + pl.gx), H + h.whh[l][0], H + h.whh[l][1], ybuf[l],
+                                                    l == 0 ? W + pl.y1h : nullptr, T_COLS, B, W + pl.xch, W + pl.sync, s)))
+                    return rc;
+            } else if ((rc = hn_launch_lstm_layer(reinterpret_cast<float*>(W + pl.gx), P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l],
+                                                  T_COLS, B, W + pl.sync, s)))
                 return rc;
         }
         if (l == 0) {
-            if ((rc = hn_launch_f32_to_bf16(ybuf[0], W + pl.y1h, rows * 1024, s))) return rc;
+            if (!e->bf16_lstm && (rc = hn_launch_f32_to_bf16(ybuf[0], W + pl.y1h, rows * 1024, s))) return rc;
             lin = W + pl.y1h;
         }
     }
     if ((rc = e->tap("lstm", ybuf[1], (size_t)rows * 1024 * sizeof(float), s))) return rc;
     ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
     return hn_launch_linear_head(ybuf[1], P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
+}
+
+extern "C" size_t hn_lstm_bf16_exchange_bytes(void) { return hn_lstm_bf16_xch_bytes(); }
+
+// per-stage entry (tests): one bf16-recurrence bi-LSTM layer, see lstm_bf16.hip
+extern "C" int hn_lstm_layer_bf16(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, void* y_bf16, int T, int B,
+                                  void* exchange, void* sync_ws, void* stream)
+{
+    HN_REQUIRE(gx && whh_fwd_bf16 && whh_rev_bf16 && y && exchange && sync_ws, "hn_lstm_layer_bf16: null pointer");
+    return hn_launch_lstm_layer_bf16(gx, whh_fwd_bf16, whh_rev_bf16, y, y_bf16, T, B, exchange, sync_ws, (hipStream_t)stream);
 }
 
 // per-stage entry point for the parity tests: x / w / res / y are bf16 device buffers (y f32 when out_f32)

@@ -1,0 +1,190 @@
+// Persistent bidirectional LSTM layer for the bf16 inference mode (hidden 512, gates i,f,g,o): the recurrent matmul on the
+// bf16 matrix cores with a bf16 h_{t-1} hand-off, organised so that the per-step exchange is SMALL.
+//
+// Replaces the recurrent half of `nn.LSTM` (reference model.py:222-227,263-264) in hn_forward_bf16; the input projection
+// gx = x @ W_ih^T + b is one bf16 GEMM launch before it.  The float32 kernel (lstm.hip) spreads one direction over 128
+// workgroups, so every step is a 128-party hand-off of 64 KB (4.1 us per step, 2.1 ms per forward = 20 % of the bf16
+// forward).  Here the work is partitioned by BATCH first:
+//
+//   * 32 groups of 8 workgroups (one per CU, 256 CUs): group = (direction, pair of panoramas).  The 8 members split the
+//     512 hidden units (64 each = 256 gate rows); each member keeps its W_hh slice (256 x 512 bf16 = 256 KB) in REGISTERS for
+//     the whole sequence as B fragments of v_mfma_f32_16x16x32_bf16 (wave w: 16 units x 4 gates = 64 fragments = 256 VGPRs).
+//     The weights are replicated across the 16 groups of a direction -- registers are what an idle-by-construction
+//     latency-bound kernel has plenty of.
+//   * per step a member needs h_{t-1} of ITS TWO panoramas only: 2 x 512 bf16 = 2 KB, published by the 8 members as 512
+//     eight-byte {tag, value} granules (cdna guide G16 form R2: the data is the flag -- one write-through store per
+//     granule, no counter, no fence, no drain on the critical path; tag = step + 1, two slots by step parity).  One wave
+//     sweeps the 512 granules (8 coalesced 8-byte sc1 loads per lane) until every tag matches, spreads h into LDS, and all
+//     four waves run 64 MFMAs each (A = h rows, 2 of the 16 MFMA rows live).
+//   * gates, cell state (registers of the 16 lanes that own the live accumulator rows) and the float32 layer output y are
+//     float32; h is rounded to bf16 only where it re-enters the matrix cores (recurrence, next layer's input GEMM).
+//
+// Placement independent (any workgroup -> CU / XCD map is correct), every spin is bounded and reports through the sticky
+// status word of the sync scratch instead of hanging.
+#include "hn_common.h"
+
+namespace {
+
+constexpr int LH = 512;                       // hidden size
+constexpr int GRP = 8;                        // workgroups per group
+constexpr int UPC = LH / GRP;                 // 64 hidden units per workgroup
+constexpr int BPG = 2;                        // panoramas per group
+constexpr int NGRP = 32;                      // 2 directions x 16 panorama pairs
+constexpr unsigned SPIN_LIMIT_H = 1u << 22;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ unsigned bf16_rn(float x)
+{
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(0.f));
+    return r & 0xffffu;
+}
+
+__global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __restrict__ gx, const u16* __restrict__ whh_f,
+                                                              const u16* __restrict__ whh_r, float* __restrict__ y,
+                                                              u16* __restrict__ y_h, u64* xch, int T, int B, int b0, int bc,
+                                                              unsigned* sync)
+{
+    __shared__ __attribute__((aligned(16))) u16 hs[2][BPG][LH];      // h_{t-1} of the group's two panoramas, by step parity
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // blockIdx b runs on XCD b % 8 (observed, speed only): keep a group's 8 members on one XCD
+    const int bid = blockIdx.x;
+    const int grp = (bid & 7) | ((bid >> 6) << 3);     // 0..31
+    const int mem = (bid >> 3) & 7;                    // 0..7
+    const int dir = grp & 1;
+    const int pair = grp >> 1;                         // 0..15
+    const int bfirst = pair * BPG;
+    if (bfirst >= bc) return;                          // the whole group leaves together
+    const int nvalid = (bc - bfirst) < BPG ? (bc - bfirst) : BPG;
+    const u16* whh = dir ? whh_r : whh_f;
+    const int col = lane & 15;                         // unit within the wave's 16 / MFMA column
+    const int kb = lane >> 4;                          // 8-wide k block within a 32-deep MFMA
+    const int u0 = mem * UPC + wave * 16;              // first hidden unit of this wave
+    u64* slots = xch + (size_t)grp * LH;               // [parity][NGRP][LH] granules
+
+    // ---- W_hh fragments: B[k][n], n = unit col of gate g -> row g*512 + u0 + col; lane holds k = ks*32 + kb*8 .. +8 ----
+    u32x4 wf[4][16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const u16* wr = whh + (size_t)(g * LH + u0 + col) * LH + kb * 8;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) wf[g][ks] = *reinterpret_cast<const u32x4*>(wr + ks * 32);
+    }
+
+    // accumulator rows: lane l, register r -> MFMA row (l >> 4) * 4 + r; the live rows 0 / 1 (the two panoramas) sit in
+    // registers 0 / 1 of lanes 0..15 -- those 16 lanes are the gate lanes of the wave (unit u0 + col)
+    const bool gate_lane = lane < 16;
+    float c_state[BPG] = {0.f, 0.f};
+    bool failed = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+
+        float gxv[BPG][4];
+        if (gate_lane) {
+#pragma unroll
+            for (int r = 0; r < BPG; ++r) {
+                const int bb = b0 + bfirst + (r < nvalid ? r : 0);
+                const float* gp = gx + ((size_t)t * B + bb) * 4096 + dir * 2048 + u0 + col;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gxv[r][g] = gp[g * LH];
+            }
+        }
+
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            const int par = step & 1;
+            if (wave == 0) {
+                // sweep the group's 512 granules of step-1 (tag == step) until all have landed, then spread h into LDS
+                const u64* src = slots + (size_t)((step - 1) & 1) * NGRP * LH;
+                unsigned v[8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const u64 x = __hip_atomic_load(src + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[k] = (unsigned)x;
+                        ok = ok && (unsigned)(x >> 32) == (unsigned)step;
+                    }
+                    if (__all(ok) || failed) break;
+                    if (++spins > SPIN_LIMIT_H) {
+                        __hip_atomic_store(sync + HN_STATUS_WORD, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        failed = true;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    hs[par][0][k * 64 + lane] = (u16)(v[k] & 0xffffu);
+                    hs[par][1][k * 64 + lane] = (u16)(v[k] >> 16);
+                }
+            }
+            __syncthreads();
+            // A fragments: row = lane % 16 -> panorama (rows >= 2 are dead: they read row 0), k = ks*32 + kb*8 .. +8
+            const u16* hrow = &hs[par][col < BPG ? col : 0][kb * 8];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(hrow + ks * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wf[g][ks]),
+                                                                     acc[g], 0, 0, 0);
+            }
+        }
+
+        if (gate_lane) {
+            unsigned packed = 0;
+#pragma unroll
+            for (int r = 0; r < BPG; ++r) {
+                const float ig = sigm(gxv[r][0] + acc[0][r]);
+                const float fg = sigm(gxv[r][1] + acc[1][r]);
+                const float gg = tanhf(gxv[r][2] + acc[2][r]);
+                const float og = sigm(gxv[r][3] + acc[3][r]);
+                c_state[r] = fg * c_state[r] + ig * gg;
+                const float h = og * tanhf(c_state[r]);
+                if (r < nvalid) {
+                    const size_t o = ((size_t)t * B + b0 + bfirst + r) * 1024 + dir * LH + u0 + col;
+                    y[o] = h;
+                    if (y_h) y_h[o] = (u16)bf16_rn(h);
+                    packed |= bf16_rn(h) << (16 * r);
+                }
+            }
+            // publish: ONE write-through 8-byte store per unit, tag = step + 1 (never 0)
+            u64* dst = slots + (size_t)(step & 1) * NGRP * LH + u0 + col;
+            __hip_atomic_store(dst, ((u64)(unsigned)(step + 1) << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+size_t hn_lstm_bf16_xch_bytes(void) { return (size_t)2 * NGRP * LH * sizeof(u64); }
+
+// gx: [T*B][4096] float32 gate pre-activations (both directions); whh_*: bf16 [2048][512]; y: float32 [T*B][1024];
+// y_h: optional bf16 copy of y (the next layer's GEMM operand); xch: hn_lstm_bf16_xch_bytes() of scratch
+int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B, void* xch,
+                              void* sync_ws, hipStream_t s)
+{
+    HN_REQUIRE(T >= 1 && B >= 1 && T < 0x7fffffff, "lstm bf16: bad T/B");
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int bc = (B - b0) < 32 ? (B - b0) : 32;
+        HN_HIP(hipMemsetAsync(xch, 0, hn_lstm_bf16_xch_bytes(), s));       // every tag back to 0 before every launch
+        hipLaunchKernelGGL(lstm_layer_bf16_kernel, dim3(NGRP * GRP), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
+                           reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), reinterpret_cast<u64*>(xch), T, B, b0,
+                           bc, reinterpret_cast<unsigned*>(sync_ws));
+        HN_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -82,7 +82,9 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
 /* Engine options.  "branch_stream" (default 1): hn_forward_bf16 runs the four height-compression chains
  * (model.py:138-156), which depend only on C1..C4, on an engine-owned second HIP stream beside the following ResNet
  * stages (fork / join with events: the caller's stream still orders the whole call); 0 = everything on the caller's
- * stream.  Results are identical either way. */
+ * stream.  Results are identical either way.
+ * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores
+ * (float32 accumulation, gates, cell state and outputs); 0 = the float32 recurrence kernel of hn_forward. */
 int hn_set_option(hn_engine* e, const char* name, int value);
 
 /* Parity-test taps: during the following hn_forward / hn_forward_bf16 calls the named intermediate is copied
@@ -113,6 +115,14 @@ int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, f
 int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
                         const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
                         int relu, int out_f32, void* stream);
+
+/* per-stage (tests): one bi-LSTM layer with the bf16 recurrence of hn_forward_bf16 (reference model.py:222-227,263-264).
+ * gx [T*B][4096] float32 gate pre-activations (fwd gates | rev gates), whh_*_bf16 [2048][512] bf16, y [T*B][1024] float32,
+ * y_bf16 optional bf16 copy of y, exchange: hn_lstm_bf16_exchange_bytes() of scratch, sync_ws: 4096 zeroed bytes (status
+ * word at uint32 index 512). */
+size_t hn_lstm_bf16_exchange_bytes(void);
+int hn_lstm_layer_bf16(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, void* y_bf16, int T, int B,
+                       void* exchange, void* sync_ws, void* stream);
 
 /* ---- training step: autograd of net(x) at reference train.py:44-58,272-281 (float32) ---------- */
 

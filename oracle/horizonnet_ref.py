@@ -186,11 +186,13 @@ def forward_train(x, sd, momentum=0.1, bf16_convs=False):
         _TRAIN["bf16_convs"] = False
 
 
-def forward_bf16_emulated(x, sd):
+def forward_bf16_emulated(x, sd, bf16_lstm=True):
     """What the engine's bf16 mode computes, restated on the CPU: every tensor the engine stores as bf16 (normalised
     input, conv weights, conv outputs after the folded-BN / residual / ReLU epilogue, the sequence matrix, the LSTM
     layer-0 output fed to layer 1) is rounded to bf16; products are exact and accumulation is f32; BatchNorm is the
-    f32 per-channel scale/shift fold; the LSTM recurrence, its gate pre-activations and the head are f32.
+    f32 per-channel scale/shift fold; the gate pre-activations, gates, cell state and the head are f32.  bf16_lstm (the
+    engine's default, lstm_bf16.hip): h_{t-1} and W_hh enter the recurrent matmul rounded to bf16 (f32 accumulation);
+    False = the float32 recurrence (engine option "bf16_lstm" = 0).
     This is NOT the reference's arithmetic (that is forward()); it exists to check the bf16 kernels tightly."""
     def fold(k_conv, k_bn):
         s_ = sd[k_bn + ".weight"] / torch.sqrt(sd[k_bn + ".running_var"] + BN_EPS)
@@ -244,13 +246,15 @@ def forward_bf16_emulated(x, sd):
             for suf in ("", "_reverse"):
                 wih = _r16(sd["bi_rnn.weight_ih_l%d%s" % (layer, suf)])
                 whh = sd["bi_rnn.weight_hh_l%d%s" % (layer, suf)]
+                if bf16_lstm:
+                    whh = _r16(whh)
                 bias = sd["bi_rnn.bias_ih_l%d%s" % (layer, suf)] + sd["bi_rnn.bias_hh_l%d%s" % (layer, suf)]
                 gx = xin @ wih.t() + bias
                 h = xin.new_zeros(B, 512)
                 c = xin.new_zeros(B, 512)
                 ys = [None] * 256
                 for t in (range(256) if suf == "" else range(255, -1, -1)):
-                    g4 = gx[t] + h @ whh.t()
+                    g4 = gx[t] + (_r16(h) if bf16_lstm else h) @ whh.t()
                     i_, f_, gg, o_ = g4.chunk(4, dim=1)
                     c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
                     h = torch.sigmoid(o_) * torch.tanh(c)

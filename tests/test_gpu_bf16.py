@@ -104,11 +104,67 @@ def test_forward_bf16_vs_emulation_and_reference(golden_dir):
                  3e-2 * float(np.abs(g["feature"]).max()))
     ok &= report("bf16 tap lstm vs reference f32", taps["lstm"][::8].cpu().numpy(), g["lstm"], 3e-2 * float(np.abs(g["lstm"]).max()))
     assert ok
+    # engine option "bf16_lstm" = 0: the float32 recurrence kernel inside the bf16 forward, against its own emulation
+    net.set_engine_option("bf16_lstm", 0)
+    fbon, fcor = horizonnet_ref.forward_bf16_emulated(x, sd, bf16_lstm=False)
+    with torch.no_grad():
+        bon0, cor0 = net(x.to(DEV))
+    ok = report("bf16 forward (f32 recurrence) vs CPU emulation: bon", bon0.cpu().numpy(), fbon.numpy(), 5e-4)
+    ok &= report("bf16 forward (f32 recurrence) vs CPU emulation: cor", cor0.cpu().numpy(), fcor.numpy(), 5e-4)
+    ok &= report("bf16 recurrence vs f32 recurrence (same bf16 convs): bon", bon.cpu().numpy(), bon0.cpu().numpy(), 1e-3)
+    assert ok
+    net.set_engine_option("bf16_lstm", 1)
     # f32 mode of the same module is untouched by the bf16 buffers
     net.precision = "f32"
     with torch.no_grad():
         b32, c32 = net(x.to(DEV))
     assert report("f32 mode after bf16 mode", b32.cpu().numpy(), g["bon"], 1e-3)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 31, 32, 37])
+def test_lstm_layer_bf16_batch_sizes(B):
+    """The bf16 recurrence kernel (8-workgroup groups, 2 panoramas per group, granule hand-off) at ragged batch sizes:
+    odd B (a group with one live panorama), B < 32 (idle groups leave at once), B > 32 (second chunk launch), run twice on
+    the same buffers (stale tags of the previous launch must not be taken for fresh ones).  Checked against a float64
+    recurrence on the bf16-rounded operands."""
+    import ctypes
+    from hiputil import P, lib, sp
+    L = lib()
+    T = 256
+    gen = torch.Generator().manual_seed(100 + B)
+    gx = (torch.rand(T * B, 4096, generator=gen) - 0.5) * 2.0
+    whh = [(torch.rand(2048, 512, generator=gen) - 0.5) * 0.12 for _ in range(2)]
+    whh_h = [w.to(torch.bfloat16) for w in whh]
+    # reference: h re-enters the matmul rounded to bf16, everything else float64
+    want = torch.zeros(T, B, 1024, dtype=torch.float64)
+    g3 = gx.view(T, B, 4096).double()
+    for d in range(2):
+        w = whh_h[d].double()
+        h = torch.zeros(B, 512, dtype=torch.float64)
+        c = torch.zeros(B, 512, dtype=torch.float64)
+        for stp in range(T):
+            t = T - 1 - stp if d else stp
+            pre = g3[t, :, d * 2048:(d + 1) * 2048] + h.float().to(torch.bfloat16).double() @ w.t()
+            i_, f_, gg, o_ = pre.chunk(4, dim=1)
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
+            h = torch.sigmoid(o_) * torch.tanh(c)
+            want[t, :, d * 512:(d + 1) * 512] = h
+    gxd = gx.to(DEV)
+    wd = [w.to(DEV).contiguous() for w in whh_h]
+    y = torch.full((T * B, 1024), float("nan"), device=DEV)
+    yh = torch.zeros((T * B, 1024), dtype=torch.bfloat16, device=DEV)
+    xch = torch.empty(L.hn_lstm_bf16_exchange_bytes(), dtype=torch.uint8, device=DEV)
+    sync = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    for rep in range(2):
+        _lib.check(L.hn_lstm_layer_bf16(P(gxd), P(wd[0]), P(wd[1]), P(y), P(yh), T, B, P(xch), P(sync), sp()), "hn_lstm_layer_bf16")
+        torch.cuda.synchronize()
+        assert int(sync.view(torch.int32)[512]) == 0, "bf16 LSTM kernel reported a spin time-out"
+        # a 1-ulp bf16 rounding flip of h (2^-9 relative) moves later steps by ~1e-4: the bound is the feedback's granularity
+        assert report("bf16 LSTM layer B=%d (run %d) vs float64 recurrence" % (B, rep), y.view(T, B, 1024).cpu().numpy(), want.numpy(), 2e-3)
+        assert torch.equal(yh, y.to(torch.bfloat16))
+        if rep == 0:
+            first = y.clone()
+    assert torch.equal(first, y)          # deterministic, independent of what the previous launch left in the exchange buffer
 
 
 def test_forward_bf16_batch32_consistency():
