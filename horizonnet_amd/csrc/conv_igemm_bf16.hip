@@ -360,6 +360,229 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
+// ---- bottleneck block 0 tail in ONE launch: y = relu(bn3(conv3(t2)) + bn_d(downsample(x)))  (model.py:78-81) -------------
+// Both convolutions are 1x1 GEMMs into the same output tile.  Run separately the downsample branch writes its
+// [M][Cout] result to HBM and conv3 reads it back as the residual -- for layer1 that is 2 x 537 MB of the block's
+// 2.4 GB at B = 32, all of it on the HBM roof.  Here the tile keeps TWO accumulator sets: K chunks 0..nk1-1 come from t2
+// (dense rows) into acc1, chunks nk1.. from x (strided pixels of the block input) into acc2; the epilogue applies each
+// branch's own folded-BN scale/shift, rounds the downsample branch to bf16 exactly where the two-launch form stores it,
+// adds, ReLUs, stores.  Bit-identical to conv3(res = downsample(x)) by construction (same k order, same rounding points).
+struct DualArgsH {
+    const u16* a1;      // t2 [M][K1]
+    const u16* w1;      // conv3 weights [Cout][K1]
+    const float* scale1;
+    const float* shift1;
+    const u16* a2;      // block input x [B][Hi2][Wi2][K2]
+    const u16* w2;      // downsample weights [Cout][K2]
+    const float* scale2;
+    const float* shift2;
+    u16* y;             // [M][Cout]
+    int M, Cout, K1, K2, nk1, nk2;
+    int Ho, Wo, Hi2, Wi2, s2;       // output grid; input grid and stride of the downsample conv
+    int xcd_swizzle;
+};
+
+__global__ __launch_bounds__(256, 2) void conv1x1_dual_bf16_kernel(DualArgsH p)
+{
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, AP = 4, BP = 4;
+    constexpr int A_BYTES = BM * ROWB;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 3;
+    const int lslot = tid & 7;
+    const int lcol = lslot ^ ((lrow >> 1) & 7);
+
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int NT = p.Cout / BN;
+    const int nt = bid % NT;
+    const int mt = bid / NT;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int hw_out = p.Ho * p.Wo;
+    const int b_first = m0 / hw_out;
+    const __amdgpu_buffer_rsrc_t rsrc_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.a1 + (size_t)m0 * p.K1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u16*>(p.a2 + (size_t)b_first * p.Hi2 * p.Wi2 * p.K2), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w1 + (size_t)n0 * p.K1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w2 + (size_t)n0 * p.K2), 0, 0x7fffffff, 0x00020000);
+
+    unsigned a1_off[AP], a2_off[AP], w1_off[BP], w2_off[BP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int m = m0 + lrow + 32 * q;
+        if (m < p.M) {
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int b = t / p.Ho;
+            a1_off[q] = (unsigned)((lrow + 32 * q) * p.K1 + lcol * 8) * 2u;
+            const unsigned pix = (unsigned)((b - b_first) * p.Hi2 * p.Wi2 + ho * p.s2 * p.Wi2 + wo * p.s2);
+            a2_off[q] = (pix * (unsigned)p.K2 + (unsigned)lcol * 8u) * 2u;
+        } else {
+            a1_off[q] = OOB;
+            a2_off[q] = OOB;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+        w1_off[q] = (unsigned)((lrow + 32 * q) * p.K1 + lcol * 8) * 2u;
+        w2_off[q] = (unsigned)((lrow + 32 * q) * p.K2 + lcol * 8) * 2u;
+    }
+
+    const int nk = p.nk1 + p.nk2;
+    // chunk kc -> LDS stage (kc & 1).  Two loaders with their own descriptors / offsets (a runtime choice between the two
+    // inside one loader makes hipcc spill both sets to scratch and select through memory)
+    auto fetch1 = [&](int kc) __attribute__((always_inline)) {
+        char* a_s = smem + (kc & 1) * STAGE_BYTES;
+        char* b_s = a_s + A_BYTES;
+        const unsigned so = (unsigned)kc * (unsigned)ROWB;
+#pragma unroll
+        for (int q = 0; q < AP; ++q) dma16(rsrc_a1, a_s + (q * 4 + wave) * 1024, a1_off[q], so);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) dma16(rsrc_w1, b_s + (q * 4 + wave) * 1024, w1_off[q], so);
+    };
+    auto fetch2 = [&](int kc) __attribute__((always_inline)) {      // kc counts over both branches; its chunk of x / W_d is kc - nk1
+        char* a_s = smem + (kc & 1) * STAGE_BYTES;
+        char* b_s = a_s + A_BYTES;
+        const unsigned so = (unsigned)(kc - p.nk1) * (unsigned)ROWB;
+#pragma unroll
+        for (int q = 0; q < AP; ++q) dma16(rsrc_a2, a_s + (q * 4 + wave) * 1024, a2_off[q], so);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) dma16(rsrc_w2, b_s + (q * 4 + wave) * 1024, w2_off[q], so);
+    };
+
+    f32x16 acc1[TM][TN], acc2[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+
+    const int fr = lane & 31;
+    const int half = lane >> 5;
+    const int fswz = (fr >> 1) & 7;
+
+    fetch1(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto ldfrag = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN], int buf, int ks) __attribute__((always_inline)) {
+            const int koff = ((2 * ks + half) ^ fswz) * 16;
+            const char* a_s = smem + buf * STAGE_BYTES + (wm * WM + fr) * ROWB + koff;
+            const char* b_s = smem + buf * STAGE_BYTES + A_BYTES + (wn * WN + fr) * ROWB + koff;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a_s + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b_s + j * 32 * ROWB);
+        };
+        auto mma = [&](f32x16 (&acc)[TM][TN], const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        };
+        ldfrag(fa0, fb0, 0, 0);
+        // one chunk sequence, two accumulator sets; every (accumulator, prefetch source) pair is its own instantiation of the
+        // loop body: static register indices, static descriptors
+        auto body = [&](auto& acc, int kc, auto prefetch) __attribute__((always_inline)) {
+            const int buf = kc & 1;
+            prefetch();
+            ldfrag(fa1, fb1, buf, 1);
+            mma(acc, fa0, fb0);
+            ldfrag(fa0, fb0, buf, 2);
+            mma(acc, fa1, fb1);
+            ldfrag(fa1, fb1, buf, 3);
+            mma(acc, fa0, fb0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kc + 1 < nk) ldfrag(fa0, fb0, buf ^ 1, 0);
+            mma(acc, fa1, fb1);
+        };
+        for (int kc = 0; kc + 1 < p.nk1; ++kc) body(acc1, kc, [&]() __attribute__((always_inline)) { fetch1(kc + 1); });
+        body(acc1, p.nk1 - 1, [&]() __attribute__((always_inline)) { fetch2(p.nk1); });          // nk2 >= 1
+        for (int kc = p.nk1; kc + 1 < nk; ++kc) body(acc2, kc, [&]() __attribute__((always_inline)) { fetch2(kc + 1); });
+        body(acc2, nk - 1, [&]() __attribute__((always_inline)) {});
+        __syncthreads();
+    }
+
+    // ---- epilogue: per wave row h, acc1 and acc2 pass through the LDS C tile one after the other ----
+    constexpr int CS = BN + 4;
+    constexpr int EROWS = WM;
+    constexpr int TPR = BN / 8;          // 16
+    constexpr int RPP = 256 / TPR;       // 16 rows per pass
+    constexpr int NPS = EROWS / RPP;     // 4
+    float* cs = reinterpret_cast<float*>(smem);
+    const int ccol = (tid % TPR) * 8;
+    const int crow = tid / TPR;
+    const f32x4 s1a = *reinterpret_cast<const f32x4*>(p.scale1 + n0 + ccol), s1b = *reinterpret_cast<const f32x4*>(p.scale1 + n0 + ccol + 4);
+    const f32x4 t1a = *reinterpret_cast<const f32x4*>(p.shift1 + n0 + ccol), t1b = *reinterpret_cast<const f32x4*>(p.shift1 + n0 + ccol + 4);
+    const f32x4 s2a = *reinterpret_cast<const f32x4*>(p.scale2 + n0 + ccol), s2b = *reinterpret_cast<const f32x4*>(p.scale2 + n0 + ccol + 4);
+    const f32x4 t2a = *reinterpret_cast<const f32x4*>(p.shift2 + n0 + ccol), t2b = *reinterpret_cast<const f32x4*>(p.shift2 + n0 + ccol + 4);
+    auto to_lds = [&](const f32x16 (&acc)[TM][TN]) __attribute__((always_inline)) {
+        float* c_w = cs + (4 * half) * CS + wn * WN + fr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c_w[(i * 32 + (r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 d0[NPS], d1[NPS];
+        if (h > 0) __syncthreads();
+        if (wm == h) to_lds(acc2);
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {        // downsample branch: bn_d, then the bf16 rounding of its stored form
+            const float* src = cs + (crow + ps * RPP) * CS + ccol;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s2a + t2a;
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * s2b + t2b;
+            const unsigned q0 = pack_bf16(v0[0], v0[1]), q1 = pack_bf16(v0[2], v0[3]), q2 = pack_bf16(v1[0], v1[1]), q3 = pack_bf16(v1[2], v1[3]);
+            d0[ps] = f32x4{bf16_lo(q0), bf16_hi(q0), bf16_lo(q1), bf16_hi(q1)};
+            d1[ps] = f32x4{bf16_lo(q2), bf16_hi(q2), bf16_lo(q3), bf16_hi(q3)};
+        }
+        __syncthreads();
+        if (wm == h) to_lds(acc1);
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int row = crow + ps * RPP;
+            const int m = m0 + h * EROWS + row;
+            const float* src = cs + row * CS + ccol;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s1a + t1a + d0[ps];
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * s1b + t1b + d1[ps];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+            if (m < p.M) {
+                u32x4 o;
+                o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+                o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+                *reinterpret_cast<u32x4*>(p.y + (size_t)m * p.Cout + n0 + ccol) = o;
+            }
+        }
+    }
+}
+
 // ---- 8-wave large-tile variant (inference forward; no stem / data-gradient / statistics modes) ---------------------
 // 512 threads = 2 waves per SIMD from ONE workgroup, tiles 256x256 (wave tile 128x64), 256x128 and 128x256 (64x64):
 // the 128x128 / 4-wave kernel above moves 0.5 KiB from L2 into LDS per MFMA -- 64 B/clk/CU at the full matrix rate, more
@@ -946,6 +1169,40 @@ int hn_launch_upsample_flatten_bf16(const void* in, void* seq, int B, int hq, in
     HN_REQUIRE(Wq > 0 && 256 % Wq == 0 && col0 + cq * hq <= 1024, "upsample bf16: bad geometry");
     hipLaunchKernelGGL(upsample_flatten_bf16_kernel, dim3(256, B), dim3(256), 0, s, reinterpret_cast<const u16*>(in),
                        reinterpret_cast<u16*>(seq), B, hq, Wq, cq, col0, 256 / Wq);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = relu(bn3(conv3(t2)) + bn_d(downsample(x))) in one launch (conv1x1_dual_bf16_kernel).  t2: bf16 [B][Ho][Wo][K1];
+// x: bf16 [B][Hi2][Wi2][K2], sampled at stride s2; w1 / w2 packed bf16 [Cout][K]; y bf16 [B][Ho][Wo][Cout].
+int hn_launch_conv1x1_dual_bf16(const void* t2, const void* w1, const float* scale1, const float* shift1, const void* x, const void* w2,
+                                const float* scale2, const float* shift2, void* y, int B, int Ho, int Wo, int K1, int Hi2, int Wi2,
+                                int K2, int s2, int Cout, hipStream_t s)
+{
+    static const char* env = getenv("HN_XCD_SWIZZLE");
+    HN_REQUIRE(K1 % BKE == 0 && K2 % BKE == 0 && Cout % 128 == 0, "dual 1x1 conv: K1=%d K2=%d Cout=%d", K1, K2, Cout);
+    HN_REQUIRE((Ho - 1) * s2 < Hi2 && (Wo - 1) * s2 < Wi2, "dual 1x1 conv: stride %d does not map the %dx%d grid into %dx%d", s2, Ho, Wo, Hi2, Wi2);
+    DualArgsH a;
+    a.a1 = reinterpret_cast<const u16*>(t2); a.w1 = reinterpret_cast<const u16*>(w1); a.scale1 = scale1; a.shift1 = shift1;
+    a.a2 = reinterpret_cast<const u16*>(x); a.w2 = reinterpret_cast<const u16*>(w2); a.scale2 = scale2; a.shift2 = shift2;
+    a.y = reinterpret_cast<u16*>(y);
+    a.M = B * Ho * Wo; a.Cout = Cout; a.K1 = K1; a.K2 = K2; a.nk1 = K1 / BKE; a.nk2 = K2 / BKE;
+    a.Ho = Ho; a.Wo = Wo; a.Hi2 = Hi2; a.Wi2 = Wi2; a.s2 = s2;
+    a.xcd_swizzle = env ? atoi(env) : 1;
+    {
+        const double span = 128.0 / ((double)Ho * Wo) + 2.0;
+        HN_REQUIRE(span * Hi2 * Wi2 * (double)K2 * 2.0 < 2147483648.0 && 128.0 * (K1 > K2 ? K1 : K2) * 2.0 < 2147483648.0,
+                   "dual 1x1 conv: tile offsets exceed 32 bits");
+    }
+    const size_t lds = 2 * (size_t)(128 + 128) * ROWB;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_dual_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(conv1x1_dual_bf16_kernel, dim3((unsigned)(hn_cdiv(a.M, 128) * (Cout / 128))), dim3(256), lds, s, a);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -201,6 +201,7 @@ extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
     HN_REQUIRE(e != nullptr && name != nullptr, "hn_set_option: null argument");
     if (strcmp(name, "branch_stream") == 0) { e->use_branch_stream = value ? 1 : 0; return 0; }
     if (strcmp(name, "bf16_lstm") == 0) { e->bf16_lstm = value ? 1 : 0; return 0; }
+    if (strcmp(name, "fuse_downsample") == 0) { e->fuse_downsample = value ? 1 : 0; return 0; }
     HN_REQUIRE(false, "hn_set_option: unknown option '%s'", name);
 }
 

@@ -184,14 +184,28 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
             if ((rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
             const char* idt = cur;
-            if (j == 0) {
+            // block 0 of the HBM-bound stages (layer1, layer2): downsample + conv3 + add + ReLU in ONE launch -- the
+            // downsample output never goes to HBM (conv1x1_dual_bf16_kernel; bit-identical to the two-launch form)
+            const bool dual = j == 0 && li < 2 && e->fuse_downsample;
+            if (j == 0 && !dual) {
                 const int id = a.block_down[li];
                 if ((rc = run_conv_h(e, a.convs[id], h.conv[id], cur, W + pl.ds, nullptr, B, Hh, Wd, stride, stride, 0, s))) return rc;
                 idt = W + pl.ds;
             }
+            const int Hin = Hh, Win = Wd;
             Hh /= stride;
             Wd /= stride;
-            if ((rc = run_conv_h(e, a.convs[i1 + 2], h.conv[i1 + 2], W + pl.t2, out, idt, B, Hh, Wd, 1, 1, 1, s))) return rc;
+            if (dual) {
+                const int id = a.block_down[li];
+                const ConvLayer& c3 = a.convs[i1 + 2];
+                const ConvLayer& cd = a.convs[id];
+                ProfScope ps(e, s, c3.wkey + "+downsample", 2.0 * B * Hh * Wd * (double)c3.cout * (c3.cin + cd.cin));
+                if ((rc = hn_launch_conv1x1_dual_bf16(W + pl.t2, H + h.conv[i1 + 2], P + c3.scale_off, P + c3.shift_off, cur, H + h.conv[id],
+                                                      P + cd.scale_off, P + cd.shift_off, out, B, Hh, Wd, c3.cin, Hin, Win, cd.cin, stride,
+                                                      c3.cout, s)))
+                    return rc;
+            } else if ((rc = run_conv_h(e, a.convs[i1 + 2], h.conv[i1 + 2], W + pl.t2, out, idt, B, Hh, Wd, 1, 1, 1, s)))
+                return rc;
             cur = out;
         }
         {

@@ -73,6 +73,7 @@ struct hn_engine {
     hipStream_t branch_stream = nullptr;
     hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    int fuse_downsample = 1;             // hn_forward_bf16: layer1 / layer2 block 0: downsample + conv3 in one launch
     int bf16_lstm = 1;                   // hn_forward_bf16: 1 = bf16 recurrence kernel (lstm_bf16.hip), 0 = the float32 one (lstm.hip)
     int use_branch_stream = 1;           // 0: everything on the caller's stream (hn_set_option "branch_stream")
     int train_bf16 = 0;                  // 1: train-mode convs (forward + data gradient) on the bf16 matrix cores (hn_set_train_precision)

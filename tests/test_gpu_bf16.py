@@ -190,6 +190,10 @@ def test_forward_bf16_branch_stream_is_bit_identical():
         net.set_engine_option("branch_stream", 0)
         b0, c0 = net(x)
         net.set_engine_option("branch_stream", 1)
+        net.set_engine_option("fuse_downsample", 0)          # two-launch form of the block-0 tails
+        bu, cu = net(x)
+        assert torch.equal(bu, b0) and torch.equal(cu, c0)   # the fused dual-GEMM launch is bit-identical
+        net.set_engine_option("fuse_downsample", 1)
         outs = [net(x) for _ in range(3)]
         side = torch.cuda.Stream(DEV)
         side.wait_stream(torch.cuda.current_stream(DEV))
