@@ -445,13 +445,13 @@ def main():
         fam = {}
         for name, ms, fl in entries:
             if "ghc_lst" in name:
-                key = "height_compress_convs(conv_igemm_f32)"
+                key = "height_compress_convs(conv_igemm)"
             elif "encoder.layer" in name:
-                key = "resnet_stage_convs(conv_igemm_f32)"
+                key = "resnet_stage_convs(conv_igemm)"
             elif name.startswith("stem"):
-                key = "stem(prep+conv_igemm_f32+maxpool)"
+                key = "stem(prep+conv_igemm+maxpool)"
             elif "input_gemm" in name:
-                key = "lstm_input_gemm(conv_igemm_f32)"
+                key = "lstm_input_gemm(conv_igemm)"
             elif "recurrence" in name:
                 key = "lstm_recurrence(persistent)"
             else:
@@ -464,11 +464,17 @@ def main():
                          "share": round(v[0] / prof_total, 3)} for k, v in fam.items()}
         igemm_ms = sum(v[0] for k, v in fam.items() if "conv_igemm" in k)
         igemm_fl = sum(v[1] for k, v in fam.items() if "conv_igemm" in k)
-        traffic = None                                   # HBM-side bytes per forward from the committed PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r1_v1_pmc_traffic.json")
+        traffic, traffic_note = None, None               # HBM-side bytes per forward from the committed PMC passes of THIS round's kernels
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_forward.json")
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        if B == 32 and args.dtype == "f32" and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("total_bytes")
+        if B == 32 and os.path.exists(tpath):
+            rec = json.load(open(tpath))["precisions"][args.dtype]
+            traffic = rec["total_bytes"]
+            traffic_note = ("bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes, profiles/r2_pmc_forward.json "
+                            "(tools/profile_forward.sh); Infinity-Cache hits included; algorithmic minimum %.1f GB -> counter / algorithmic = %.2f; "
+                            "matrix pipe busy %s %% of the conv kernels' cycles" % (
+                                rec["fetch_bytes"] / 1e9, rec["write_bytes"] / 1e9, rec["algorithmic_min_bytes"] / 1e9, rec["counter_over_algorithmic"],
+                                "/".join(str(v["mfma_busy_pct"]) for k, v in rec["by_kernel_family"].items() if k.startswith("conv") and "mfma_busy_pct" in v)))
         out = {
             "metric": "panoramas/s (512x1024 fwd)",
             "value": round(value, 2),
@@ -486,13 +492,14 @@ def main():
                                    % ("fp32" if args.dtype == "f32" else "bf16 MFMA convs (f32 accumulate, f32 LSTM/head) -- NOT the fp32 config"),
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d (independent replicas, no data-path collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": "hn_forward (all launches of one forward; conv_igemm_f32 family = %.0f%% of device time)" % (100.0 * igemm_ms / prof_total),
+            "roofline": {"bound": "mfma", "kernel": "%s (all launches of one forward; implicit-GEMM conv family = %.0f%% of device time)" % (
+                             "hn_forward" if args.dtype == "f32" else "hn_forward_bf16", 100.0 * igemm_ms / prof_total),
                          "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / peak, 4), "traffic": traffic,
-                         "traffic_note": "bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate --pmc passes, profiles/r1_v1_pmc_traffic.json; Infinity-Cache hits included; algorithmic minimum 31.7 GB",
+                         "traffic_note": traffic_note,
                          "algorithmic_flop_per_launch": FWD_FLOP_PER_PANO * B,
                          "launch_ms_hip_events": round(ms_per_fwd, 3),
-                         "conv_igemm_f32": {"ms": round(igemm_ms, 3), "tflops": round(igemm_fl / (igemm_ms * 1e-3) / 1e12, 2),
+                         "conv_igemm": {"ms": round(igemm_ms, 3), "tflops": round(igemm_fl / (igemm_ms * 1e-3) / 1e12, 2),
                                             "frac": round(igemm_fl / (igemm_ms * 1e-3) / 1e12 / peak, 4)},
                          "breakdown": breakdown},
         }

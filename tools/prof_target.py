@@ -1,0 +1,24 @@
+"""Profiling target for rocprofv3 (MEASUREMENT TOOL): N identical B=32 forwards of the seeded network in one precision.
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d gpurun_out/pmc_x -- python tools/prof_target.py bf16
+Every forward launches the same kernels, so per-forward figures are the per-kernel totals / N (weight packing runs once
+and has its own kernel names)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from bench import seeded_net  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+dev = torch.device("cuda:0")
+net = seeded_net(0).to(dev).eval()
+net.precision = prec
+x = torch.rand(B, 3, 512, 1024, generator=torch.Generator().manual_seed(1000)).to(dev)
+with torch.no_grad():
+    for _ in range(N):
+        bon, cor = net(x)
+torch.cuda.synchronize()
+assert net.hip_status(dev) == 0
+print("PROF_TARGET precision=%s B=%d forwards=%d" % (prec, B, N))
