@@ -85,7 +85,7 @@ int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq,
 int hn_launch_dropout(const float* in, float* out, long n, float p, unsigned long long seed, hipStream_t s);
 int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, const float* y, float* dy, float* dlin, float* dw,
                        float* db, int T, int B, hipStream_t s);
-int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, const float* dh_rec, float* dc_rec, float* dgx, int T, int B, int step,
+int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, float* dh_rec, float* dc_rec, float* dgx, int T, int B, int step,
                              hipStream_t s);
 int hn_launch_linear_head(const float* y, const float* w, const float* bias, float* bon, float* cor, int T, int B,
                           hipStream_t s);

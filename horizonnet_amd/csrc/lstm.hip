@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // whhT_f / whhT_r: the recurrent weights transposed to [512][2048]
 int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whhT_f, const float* whhT_r, float* dh, int B, hipStream_t s)
 {
-    HN_HIP(hipMemsetAsync(dh, 0, (size_t)B * 1024 * sizeof(float), s));      // partial tiles are accumulated with atomics
+    // dh must be zero on entry (partial tiles are accumulated with atomics): the caller zeroes it once per layer and
+    // lstm_bwd_gates_kernel re-zeroes every element as it consumes it -- no memset per step
     hipLaunchKernelGGL(lstm_bwd_dh_kernel, dim3(256, (B + 31) / 32), dim3(256), 0, s, dg_f, dg_r, whhT_f, whhT_r, dh, B);
     HN_LAUNCH_CHECK();
     return 0;

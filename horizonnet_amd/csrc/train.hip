@@ -19,6 +19,7 @@ struct Unit {
     int stem;
     size_t x, z, y, st, mk;        // float offsets: input, pre-BN, post-activation, [mean|invstd|a|b], ReLU bit mask (1 byte per 4 outputs)
     size_t xh, yh;                 // float offsets of the bf16 copies of the input / of y (train_precision bf16)
+    size_t sf, sb;                 // this unit's slots in the statistics arena (doubles): forward [sum | sumsq], backward [S1 | S2 | dbias]
     long M;
 };
 
@@ -27,6 +28,7 @@ struct TrainPlan {
     int blk[4][6], dsu[4], ghc[4];         // unit indices
     size_t xn8, poolh, dzh[2];             // bf16: NHWC8 normalised image, max-pool output, two dz staging buffers
     size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
+    size_t stat_fwd_doubles, stat_bwd_first, stat_bwd_doubles, stat_lstm;   // layout of the statistics arena at `dstat` (doubles)
     size_t gmax;
 };
 
@@ -42,6 +44,7 @@ TrainPlan make_train_plan(int B)
     p.sync = take(HN_SYNC_WORDS);
     p.xn = take(b * IMG_H * IMG_W * 4);
     p.xn8 = take(b * IMG_H * IMG_W * 4);          // 8 bf16 per pixel
+    size_t stat_f = 0, stat_b = 0;
     auto add_unit = [&](int ci, size_t x, size_t xh, int Hi, int Wi, int sh, int sw, int relu, int stem) {
         const ConvLayer& c = a.convs[ci];
         Unit u;
@@ -56,6 +59,8 @@ TrainPlan make_train_plan(int B)
         u.st = take(4 * (size_t)c.cout);
         u.mk = take(((size_t)u.M * c.cout / 4 + 3) / 4);
         u.yh = take((size_t)u.M * c.cout / 2);
+        u.sf = stat_f; stat_f += 2 * (size_t)c.cout;
+        u.sb = stat_b; stat_b += 3 * (size_t)c.cout;
         p.units.push_back(u);
         return (int)p.units.size() - 1;
     };
@@ -107,7 +112,13 @@ TrainPlan make_train_plan(int B)
     p.dcrec = take(b * 1024);
     p.wsA = take((size_t)1024 * 18432 + 64);      // largest packed weight (ghc3.0) / wgrad scratch
     p.wsB = take((size_t)1024 * 18432 + 64);
-    p.dstat = take(4 * 4096 * 2);                 // 4 x 4096 doubles
+    // statistics arena (doubles): every unit has its own forward and backward slots, so ONE memset per forward and ONE
+    // per backward pass replace the two or three per unit (~160 tiny launches per step)
+    p.stat_fwd_doubles = stat_f;
+    p.stat_bwd_first = stat_f;
+    p.stat_bwd_doubles = stat_b;
+    p.stat_lstm = stat_f + stat_b;                // 4096 doubles for the LSTM bias gradients
+    p.dstat = take((stat_f + stat_b + 4096) * 2);
     p.total = off;
     return p;
 }
@@ -139,8 +150,7 @@ int conv_z(const Ctx& c, const Unit& u)
     d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo; d.relu = 0; d.ldy = cl.cout; d.stem = u.stem;
     // batch statistics of z come out of the conv epilogue (sum / sum of squares per channel, double atomics)
     if (!c.bn_eval(u)) {       // (a BatchNorm in eval() normalises with its running statistics: no batch statistics needed)
-        double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
-        HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)cl.cout * sizeof(double), c.s));
+        double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + u.sf;       // zeroed once at the start of hn_train_forward
         d.stat_sum = ds;
         d.stat_sq = ds + cl.cout;
     }
@@ -160,7 +170,7 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
 {
     const ConvLayer& cl = c.a.convs[u.ci];
     const int C = cl.cout;
-    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
+    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + u.sf;
     float* st = c.W + u.st;
     int rc;
     if (c.bn_eval(u)) {       // frozen block (train.py:245-256): running statistics, untouched
@@ -184,12 +194,11 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     void* dz_h = (c.e->train_bf16 && dzh_slot >= 0 && c.a.convs[u.ci].cout % 64 == 0) ? c.W + c.pl.dzh[dzh_slot] : nullptr;
     const ConvLayer& cl = c.a.convs[u.ci];
     const int C = cl.cout;
-    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat);
+    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + u.sb;    // zeroed once per backward pass
     const float* st = c.W + u.st;
     // ymask != null: the unit ends in a ReLU; the adjoint reads the bit mask its affine_act pass stored (1/16 of y's bytes)
     const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
-    HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
     if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
@@ -212,8 +221,7 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
         if (c.e->debug_dz2) HN_HIP(hipMemcpyAsync(c.e->debug_dz2, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     }
     if (cl.has_bias) {
-        double* db = ds + 2 * 4096;
-        HN_HIP(hipMemsetAsync(db, 0, (size_t)C * sizeof(double), c.s));
+        double* db = ds + 2 * C;
         if ((rc = hn_launch_col_stats(dz, db, nullptr, u.M, C, C, c.s))) return rc;
         if ((rc = hn_launch_d2f(db, c.grad(cl.wkey + ".bias"), C, c.s))) return rc;
     }
@@ -335,6 +343,7 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     hipStream_t s = c.s;
     int rc;
     HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
+    HN_HIP(hipMemsetAsync(W + pl.dstat, 0, pl.stat_fwd_doubles * sizeof(double), s));   // every unit's batch-statistics slot
 
     // stem
     if ((rc = hn_launch_prep_nhwc4(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;          // f32: the stem's weight gradient reads it
@@ -419,7 +428,9 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     float* G1 = W + pl.G[1];
     float* G2 = W + pl.G[2];
     float* G3 = W + pl.G[3];
-    double* ds = reinterpret_cast<double*>(W + pl.dstat);
+    double* ds = reinterpret_cast<double*>(W + pl.dstat) + pl.stat_lstm;      // LSTM bias-gradient sums (zeroed where used)
+    if (seg_lo == 0)      // the pass starts: every unit's [S1 | S2 | dbias] slot in one go
+        HN_HIP(hipMemsetAsync(reinterpret_cast<double*>(W + pl.dstat) + pl.stat_bwd_first, 0, pl.stat_bwd_doubles * sizeof(double), s));
 
     // ---- head: Linear + dropout ----
     if (LIVE && (rc = hn_launch_head_bwd(dbon, dcor, c.bound("linear.weight"), W + pl.y2d, G0, W + pl.dlin, c.grad("linear.weight"),

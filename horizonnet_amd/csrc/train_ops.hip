@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
 //   saved[t][b][dir][5][512] = (i, f, g, o, c) post-activation;  c_prev = c of the previous step of that direction (0 at its first step)
 //   dh = dy[t][b][dir*512+u] + dh_rec[b][dir*512+u];  standard LSTM adjoint -> dgx[t][b][dir*2048 + gate*512 + u], dc_rec updated in place
 __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __restrict__ saved, const float* __restrict__ dy,
-                                                             const float* __restrict__ dh_rec, float* __restrict__ dc_rec,
+                                                             float* __restrict__ dh_rec, float* __restrict__ dc_rec,
                                                              float* __restrict__ dgx, int T, int B, int step)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over B * 2 * 512
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __rest
     float cprev = 0.f;
     if (tprev >= 0 && tprev < T) cprev = saved[((((size_t)tprev * B + b) * 2 + dir) * 5 + 4) * 512 + u];
     const float dh = dy[((size_t)t * B + b) * 1024 + dir * 512 + u] + dh_rec[(size_t)b * 1024 + dir * 512 + u];
+    dh_rec[(size_t)b * 1024 + dir * 512 + u] = 0.f;    // consumed: the next launch (lstm_bwd_dh) accumulates this step's into it with atomics
     const float tc = tanhf(c);
     const float dc = dc_rec[(size_t)b * 1024 + dir * 512 + u] + dh * og * (1.f - tc * tc);
     float* g = dgx + ((size_t)t * B + b) * 4096 + dir * 2048 + u;
@@ -529,7 +530,7 @@ int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, con
     return 0;
 }
 
-int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, const float* dh_rec, float* dc_rec, float* dgx, int T, int B, int step,
+int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, float* dh_rec, float* dc_rec, float* dgx, int T, int B, int step,
                              hipStream_t s)
 {
     hipLaunchKernelGGL(lstm_bwd_gates_kernel, dim3((B * 1024 + 255) / 256), dim3(256), 0, s, saved, dy, dh_rec, dc_rec, dgx, T, B, step);
