@@ -391,6 +391,201 @@ int env_flag(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+// ---- bottleneck block 0 tail in ONE launch (float32): y = relu(bn3(conv3(t2)) + bn_d(downsample(x)))  (model.py:78-81) ----
+// Same idea as conv1x1_dual_bf16_kernel (conv_igemm_bf16.hip): two accumulator sets in one 128x128 tile, K chunks
+// 0..nk1-1 from t2 (dense rows), nk1.. from the strided pixels of the block input; the epilogue forms the downsample
+// branch's value exactly as the two-launch form stores it (acc2 * scale_d + shift_d, float32) and adds it where that
+// form adds the residual -- bit-identical, and the downsample output (2 x 1.07 GB in layer1 at B = 32) never goes to HBM.
+struct DualArgs {
+    const float* a1; const float* w1; const float* scale1; const float* shift1;
+    const float* a2; const float* w2; const float* scale2; const float* shift2;
+    float* y;
+    int M, Cout, K1, K2, nk1, nk2;
+    int Ho, Wo, Hi2, Wi2, s2;
+    int xcd_swizzle;
+};
+
+__global__ __launch_bounds__(256, 2) void conv1x1_dual_f32_kernel(DualArgs p)
+{
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, TM = 2, TN = 2, AP = 4, BP = 4;
+    constexpr int A_TILE = BM * BK;
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 3;
+    const int lslot = tid & 7;
+    const int lcol = lslot ^ ((lrow >> 1) & 7);
+
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int NT = p.Cout / BN;
+    const int nt = bid % NT;
+    const int mt = bid / NT;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int b_first = m0 / (p.Ho * p.Wo);
+    const __amdgpu_buffer_rsrc_t rsrc_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a1 + (size_t)m0 * p.K1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.a2 + (size_t)b_first * p.Hi2 * p.Wi2 * p.K2), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w1 + (size_t)n0 * p.K1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2 + (size_t)n0 * p.K2), 0, 0x7fffffff, 0x00020000);
+
+    unsigned a1_off[AP], a2_off[AP], w1_off[BP], w2_off[BP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int m = m0 + lrow + 32 * q;
+        if (m < p.M) {
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int b = t / p.Ho;
+            a1_off[q] = (unsigned)((lrow + 32 * q) * p.K1 + lcol * 4) * 4u;
+            const unsigned pix = (unsigned)((b - b_first) * p.Hi2 * p.Wi2 + ho * p.s2 * p.Wi2 + wo * p.s2);
+            a2_off[q] = (pix * (unsigned)p.K2 + (unsigned)lcol * 4u) * 4u;
+        } else {
+            a1_off[q] = OOB;
+            a2_off[q] = OOB;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+        w1_off[q] = (unsigned)((lrow + 32 * q) * p.K1 + lcol * 4) * 4u;
+        w2_off[q] = (unsigned)((lrow + 32 * q) * p.K2 + lcol * 4) * 4u;
+    }
+
+    const int nk = p.nk1 + p.nk2;
+    auto fetch1 = [&](int kc) __attribute__((always_inline)) {
+        float* a_s = smem + (kc & 1) * STAGE;
+        float* b_s = a_s + A_TILE;
+        const unsigned so = (unsigned)kc * (BK * 4u);
+#pragma unroll
+        for (int q = 0; q < AP; ++q) buf_load16_to_lds(rsrc_a1, a_s + (q * 4 + wave) * 256, a1_off[q], so);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) buf_load16_to_lds(rsrc_w1, b_s + (q * 4 + wave) * 256, w1_off[q], so);
+    };
+    auto fetch2 = [&](int kc) __attribute__((always_inline)) {
+        float* a_s = smem + (kc & 1) * STAGE;
+        float* b_s = a_s + A_TILE;
+        const unsigned so = (unsigned)(kc - p.nk1) * (BK * 4u);
+#pragma unroll
+        for (int q = 0; q < AP; ++q) buf_load16_to_lds(rsrc_a2, a_s + (q * 4 + wave) * 256, a2_off[q], so);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) buf_load16_to_lds(rsrc_w2, b_s + (q * 4 + wave) * 256, w2_off[q], so);
+    };
+
+    f32x16 acc1[TM][TN], acc2[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+
+    const int fr = lane & 31;
+    const int fswz = (fr >> 1) & 7;
+
+    fetch1(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto ldfrag = [&](f32x4 (&fa)[TM], f32x4 (&fb)[TN], int buf, int kk) __attribute__((always_inline)) {
+            const int koff = ((2 * kk + (lane >> 5)) ^ fswz) * 4;
+            const float* a_s = smem + buf * STAGE + (wm * WM + fr) * BK + koff;
+            const float* b_s = smem + buf * STAGE + A_TILE + (wn * WN + fr) * BK + koff;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * BK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b_s + j * 32 * BK);
+        };
+        auto mma = [&](auto& acc, const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
+        };
+        ldfrag(fa0, fb0, 0, 0);
+        auto body = [&](auto& acc, int kc, auto prefetch) __attribute__((always_inline)) {
+            const int buf = kc & 1;
+            prefetch();
+            ldfrag(fa1, fb1, buf, 1);
+            mma(acc, fa0, fb0);
+            ldfrag(fa0, fb0, buf, 2);
+            mma(acc, fa1, fb1);
+            ldfrag(fa1, fb1, buf, 3);
+            mma(acc, fa0, fb0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kc + 1 < nk) ldfrag(fa0, fb0, buf ^ 1, 0);
+            mma(acc, fa1, fb1);
+        };
+        for (int kc = 0; kc + 1 < p.nk1; ++kc) body(acc1, kc, [&]() __attribute__((always_inline)) { fetch1(kc + 1); });
+        body(acc1, p.nk1 - 1, [&]() __attribute__((always_inline)) { fetch2(p.nk1); });
+        for (int kc = p.nk1; kc + 1 < nk; ++kc) body(acc2, kc, [&]() __attribute__((always_inline)) { fetch2(kc + 1); });
+        body(acc2, nk - 1, [&]() __attribute__((always_inline)) {});
+        __syncthreads();
+    }
+
+    constexpr int CS = BN + 4;
+    constexpr int EROWS = WM;
+    constexpr int TPR = BN / 4;          // 32 threads per row (4 floats each)
+    constexpr int RPP = 256 / TPR;       // 8 rows per sweep
+    constexpr int NPS = EROWS / RPP;     // 8
+    float* cs = smem;
+    const int ccol = (tid % TPR) * 4;
+    const int crow = tid / TPR;
+    const int half = lane >> 5;
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale1 + n0 + ccol), t1 = *reinterpret_cast<const f32x4*>(p.shift1 + n0 + ccol);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(p.scale2 + n0 + ccol), t2 = *reinterpret_cast<const f32x4*>(p.shift2 + n0 + ccol);
+    auto to_lds = [&](const f32x16 (&acc)[TM][TN]) __attribute__((always_inline)) {
+        float* c_w = cs + (4 * half) * CS + wn * WN + fr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c_w[(i * 32 + (r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 d[NPS];
+        if (h > 0) __syncthreads();
+        if (wm == h) to_lds(acc2);
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps)          // the downsample branch's stored value: acc * scale_d + shift_d
+            d[ps] = *reinterpret_cast<const f32x4*>(cs + (crow + ps * RPP) * CS + ccol) * s2 + t2;
+        __syncthreads();
+        if (wm == h) to_lds(acc1);
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int row = crow + ps * RPP;
+            const int m = m0 + h * EROWS + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(cs + row * CS + ccol) * s1 + t1;
+            v += d[ps];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + ccol) = v;
+        }
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, bool DMA, bool TR>
 int launch_cfg_d(const ConvArgs& a, hipStream_t s);
 
@@ -555,4 +750,35 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     a.nk = a.K / BK;
     HN_REQUIRE(128.0 * a.K * 4.0 < 2147483648.0, "conv: K too large for 32-bit weight-tile offsets");
     return dispatch_tiles<false>(a, d.Cout, force_tile, s);
+}
+
+// y = relu(bn3(conv3(t2)) + bn_d(downsample(x))) in one float32 launch (conv1x1_dual_f32_kernel); packed weights [Cout][K]
+int hn_launch_conv1x1_dual_f32(const float* t2, const float* w1, const float* scale1, const float* shift1, const float* x, const float* w2,
+                               const float* scale2, const float* shift2, float* y, int B, int Ho, int Wo, int K1, int Hi2, int Wi2, int K2,
+                               int s2, int Cout, hipStream_t s)
+{
+    static const char* env = getenv("HN_XCD_SWIZZLE");
+    HN_REQUIRE(K1 % BK == 0 && K2 % BK == 0 && Cout % 128 == 0, "dual 1x1 conv f32: K1=%d K2=%d Cout=%d", K1, K2, Cout);
+    HN_REQUIRE((Ho - 1) * s2 < Hi2 && (Wo - 1) * s2 < Wi2, "dual 1x1 conv f32: stride %d does not map the %dx%d grid into %dx%d", s2, Ho, Wo, Hi2, Wi2);
+    DualArgs a;
+    a.a1 = t2; a.w1 = w1; a.scale1 = scale1; a.shift1 = shift1; a.a2 = x; a.w2 = w2; a.scale2 = scale2; a.shift2 = shift2; a.y = y;
+    a.M = B * Ho * Wo; a.Cout = Cout; a.K1 = K1; a.K2 = K2; a.nk1 = K1 / BK; a.nk2 = K2 / BK;
+    a.Ho = Ho; a.Wo = Wo; a.Hi2 = Hi2; a.Wi2 = Wi2; a.s2 = s2;
+    a.xcd_swizzle = env ? atoi(env) : 1;
+    {
+        const double span = 128.0 / ((double)Ho * Wo) + 2.0;
+        HN_REQUIRE(span * Hi2 * Wi2 * (double)K2 * 4.0 < 2147483648.0 && 128.0 * (K1 > K2 ? K1 : K2) * 4.0 < 2147483648.0,
+                   "dual 1x1 conv f32: tile offsets exceed 32 bits");
+    }
+    const size_t lds = 2 * (size_t)(128 + 128) * BK * sizeof(float);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_dual_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(conv1x1_dual_f32_kernel, dim3((unsigned)(hn_cdiv(a.M, 128) * (Cout / 128))), dim3(256), lds, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
 }

@@ -379,14 +379,26 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
             if ((rc = run_conv(e, P, c1, cur, W + pl.t1, nullptr, B, H, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv(e, P, c2, W + pl.t1, W + pl.t2, nullptr, B, H, Wd, stride, stride, 1, s))) return rc;
             const float* idt = cur;
-            if (j == 0) {
+            // block 0: downsample + conv3 + add + ReLU as ONE dual-accumulator launch (conv1x1_dual_f32_kernel): the
+            // downsample output never goes to HBM; bit-identical to the two-launch form (option "fuse_downsample")
+            const bool dual = j == 0 && e->fuse_downsample;
+            if (j == 0 && !dual) {
                 const ConvLayer& cd = a.convs[a.block_down[li]];
                 if ((rc = run_conv(e, P, cd, cur, W + pl.ds, nullptr, B, H, Wd, stride, stride, 0, s))) return rc;
                 idt = W + pl.ds;
             }
+            const int Hin = H, Win = Wd;
             H /= stride;
             Wd /= stride;
-            if ((rc = run_conv(e, P, c3, W + pl.t2, out, idt, B, H, Wd, 1, 1, 1, s))) return rc;
+            if (dual) {
+                const ConvLayer& cd = a.convs[a.block_down[li]];
+                ProfScope ps(e, s, c3.wkey + "+downsample", 2.0 * B * H * Wd * (double)c3.cout * (c3.cin + cd.cin));
+                if ((rc = hn_launch_conv1x1_dual_f32(W + pl.t2, P + c3.w_off, P + c3.scale_off, P + c3.shift_off, cur, P + cd.w_off,
+                                                     P + cd.scale_off, P + cd.shift_off, out, B, H, Wd, c3.cin, Hin, Win, cd.cin, stride,
+                                                     c3.cout, s)))
+                    return rc;
+            } else if ((rc = run_conv(e, P, c3, W + pl.t2, out, idt, B, H, Wd, 1, 1, 1, s)))
+                return rc;
             cur = out;
         }
         {

@@ -85,8 +85,9 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * stream.  Results are identical either way.
  * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores
  * (float32 accumulation, gates, cell state and outputs); 0 = the float32 recurrence kernel of hn_forward.
- * "fuse_downsample" (default 1): hn_forward_bf16 computes block 0 of layer1 / layer2 as ONE launch for
- * relu(bn3(conv3(t2)) + bn_d(downsample(x))) (model.py:78-81) instead of two; bit-identical results. */
+ * "fuse_downsample" (default 1): block 0 of a ResNet stage ends in ONE launch for
+ * relu(bn3(conv3(t2)) + bn_d(downsample(x))) (model.py:78-81) instead of two (hn_forward: all four stages;
+ * hn_forward_bf16: layer1 / layer2); bit-identical results. */
 int hn_set_option(hn_engine* e, const char* name, int value);
 
 /* Parity-test taps: during the following hn_forward / hn_forward_bf16 calls the named intermediate is copied

@@ -301,6 +301,21 @@ def test_forward_full_batch32_consistency(golden_dir):
     assert ok
 
 
+def test_forward_f32_fused_downsample_is_bit_identical():
+    """hn_forward ends block 0 of every ResNet stage in one dual-accumulator launch (conv1x1_dual_f32_kernel); with the
+    engine option off it runs downsample and conv3 (+ residual) separately.  Same k order, same rounding points."""
+    net = _net(0, "random")
+    x = torch.rand(5, 3, 512, 1024, generator=torch.Generator().manual_seed(98)).to(DEV)
+    with torch.no_grad():
+        b1, c1 = net(x)
+        net.set_engine_option("fuse_downsample", 0)
+        b0, c0 = net(x)
+        net.set_engine_option("fuse_downsample", 1)
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert torch.equal(b0, b1) and torch.equal(c0, c1)
+
+
 def test_forward_batch_not_multiple_of_32():
     # B = 40: two LSTM chunks (32 + 8), ragged M tiles everywhere; every panorama must equal its B=4 result
     net = _net(2, "random")
