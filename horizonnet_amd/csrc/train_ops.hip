@@ -395,6 +395,43 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __rest
     dc_rec[(size_t)b * 1024 + dir * 512 + u] = dc * fg;
 }
 
+// Adam over ALL parameter tensors in one launch (train.py:216-225 / :279 `optimizer.step()`): thread i owns 4 consecutive
+// elements of the engine's flat gradient buffer, finds the tensor they belong to in the (sorted) offset table and
+// updates that tensor's parameter storage in place.  Same arithmetic as torch.optim.Adam (no amsgrad): L2 weight
+// decay folded into the gradient, bias-corrected step size, denom = sqrt(v) / sqrt(1 - b2^t) + eps.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* const* __restrict__ params, const long long* __restrict__ offsets,
+                                                        const unsigned char* __restrict__ active, int n_tensors,
+                                                        const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                        long long total, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                        float bc2_sqrt, float inv_grad_scale)
+{
+    const float step_size = lr / bc1;
+    for (long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < total; i4 += (long long)gridDim.x * blockDim.x * 4) {
+        int lo = 0, hi = n_tensors - 1;                  // last tensor whose first element is <= i4
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offsets[mid] <= i4) lo = mid; else hi = mid - 1;
+        }
+        int t = lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = i4 + k;
+            if (i >= total) break;
+            while (i >= offsets[t + 1]) ++t;            // offsets[n_tensors] = total
+            if (!active[t]) continue;
+            float* p = params[t] + (i - offsets[t]);
+            float gi = g[i] * inv_grad_scale;
+            const float pi = *p;
+            gi += wd * pi;
+            const float mi = b1 * m[i] + (1.f - b1) * gi;
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            *p = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+    }
+}
+
 inline unsigned grid_for(long total, long cap = 256L * 16)
 {
     long g = (total + 255) / 256;
@@ -534,6 +571,23 @@ int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, float* dh_rec,
                              hipStream_t s)
 {
     hipLaunchKernelGGL(lstm_bwd_gates_kernel, dim3((B * 1024 + 255) / 256), dim3(256), 0, s, saved, dy, dh_rec, dc_rec, dgx, T, B, step);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// One Adam step for every parameter tensor (see adam_flat_kernel).  params / offsets / active are DEVICE arrays
+// (n_tensors pointers, n_tensors + 1 element offsets into the flat buffers, n_tensors flags); grads / m / v are flat
+// float32 buffers of `total` elements in the layout of hn_grad_offset().
+extern "C" int hn_adam_step(float* const* params, const long long* offsets, const unsigned char* active, int n_tensors, const float* grads,
+                            float* m, float* v, long long total, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            int step, float grad_scale, void* stream)
+{
+    HN_REQUIRE(params && offsets && active && grads && m && v, "hn_adam_step: null pointer");
+    HN_REQUIRE(n_tensors >= 1 && total >= 1 && step >= 1 && grad_scale > 0.f, "hn_adam_step: bad sizes / step");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for((total + 3) / 4, 256L * 32)), dim3(256), 0, (hipStream_t)stream, params, offsets, active,
+                       n_tensors, grads, m, v, total, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), 1.f / grad_scale);
     HN_LAUNCH_CHECK();
     return 0;
 }

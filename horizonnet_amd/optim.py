@@ -1,0 +1,115 @@
+"""``FusedAdam``: Adam over all 241 parameter tensors of ``HorizonNet`` in ONE kernel launch (``hn_adam_step``).
+
+Replaces ``torch.optim.Adam(net.parameters(), …)`` at reference ``train.py:216-225`` / ``optimizer.step()`` at
+``:279``: same arithmetic (no amsgrad; L2 ``weight_decay`` folded into the gradient; bias-corrected step), same
+``param_groups[0]['lr']`` knob for ``adjust_learning_rate`` (``misc/utils.py:35-46``), ``state_dict`` /
+``load_state_dict`` for checkpoints.  It works on the engine's FLAT gradient buffer: after ``loss.backward()`` every
+``p.grad`` is a view into one 326 MB tensor laid out by ``hn_grad_offset``; the kernel reads that buffer, keeps the two
+moments as flat buffers of the same layout, and writes the parameters in place -- one launch instead of one
+multi-tensor pass per dtype/shape bucket, no per-step Python loop over 241 tensors.  Frozen parameters
+(``requires_grad = False``, ``--freeze_earlier_blocks``) are skipped.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    def __init__(self, net, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.net = net.module if hasattr(net, "module") else net
+        self.lib = _lib.load()
+        self.named = list(self.net.named_parameters())
+        dev = self.named[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedAdam works on the MI355X engine's device tensors: move the module to the GPU first")
+        self.device = dev
+        self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": float(weight_decay),
+                              "params": [p for _, p in self.named]}]
+        self.total = int(self.lib.hn_grad_floats())
+        offs, order = [], []
+        for k, p in self.named:
+            o = int(self.lib.hn_grad_offset(k.encode()))
+            if o < 0 or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("FusedAdam: parameter %s is not a contiguous float32 tensor of the engine's layout" % k)
+            offs.append(o)
+            order.append((o, k, p))
+        order.sort(key=lambda r: r[0])
+        self.order = order
+        self.offsets = torch.tensor([r[0] for r in order] + [self.total], dtype=torch.int64, device=dev)
+        for (o, k, p), nxt in zip(order, [r[0] for r in order[1:]] + [self.total]):
+            assert nxt - o == p.numel(), "flat layout does not tile the parameters (%s)" % k
+        self.m = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self._ptr_sig = None
+        self._ptrs = None
+        self._active = None
+
+    def zero_grad(self, set_to_none=True):
+        for _, p in self.named:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def _tables(self):
+        sig = tuple((p.data_ptr(), p.requires_grad) for _, _, p in self.order)
+        if sig != self._ptr_sig:
+            self._ptrs = torch.tensor([p.data_ptr() for _, _, p in self.order], dtype=torch.int64, device=self.device)
+            self._active = torch.tensor([1 if p.requires_grad else 0 for _, _, p in self.order], dtype=torch.uint8, device=self.device)
+            self._ptr_sig = sig
+        return self._ptrs, self._active
+
+    def _flat_grads(self):
+        """Device address of a flat gradient buffer in the engine's layout.  After loss.backward() on the engine every
+        p.grad is normally a VIEW into the one buffer hn_train_backward filled (autograd adopts the views it is handed);
+        if some gradient is not (accumulated over several backward passes, replaced by the caller) the gradients are
+        gathered into an internal flat buffer with one multi-tensor copy."""
+        base, views_ok = None, True
+        live = [(o, k, p) for o, k, p in self.order if p.requires_grad]
+        for o, k, p in live:
+            if p.grad is None:
+                raise RuntimeError("FusedAdam.step(): parameter %s has no gradient (call loss.backward() first)" % k)
+            b = p.grad.data_ptr() - 4 * o
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or (base is not None and b != base):
+                views_ok = False
+                break
+            base = b
+        if not live:
+            return None
+        if views_ok:
+            self.used_views = True
+            return base
+        self.used_views = False
+        if getattr(self, "_gather", None) is None:
+            self._gather = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        torch._foreach_copy_([self._gather[o:o + p.numel()].view(p.shape) for o, k, p in live], [p.grad.float() for o, k, p in live])
+        return self._gather.data_ptr()
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        base = self._flat_grads()
+        if base is None:
+            return
+        ptrs, active = self._tables()
+        self.step_count += 1
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.hn_adam_step(_lib.ptr(ptrs), _lib.ptr(self.offsets), _lib.ptr(active), len(self.order),
+                                             ctypes.c_void_p(base), _lib.ptr(self.m), _lib.ptr(self.v), self.total, g["lr"], g["betas"][0],
+                                             g["betas"][1], g["eps"], g["weight_decay"], self.step_count, float(grad_scale),
+                                             _lib.stream_ptr(self.device)), "hn_adam_step")
+        self.net._train_steps += 1           # parameters changed behind torch's version counters: the engine re-packs
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m, "v": self.v,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"].to(self.device))
+        self.v.copy_(sd["v"].to(self.device))
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
