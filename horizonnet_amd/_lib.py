@@ -45,7 +45,7 @@ SIGNATURES = {
     "hn_grad_segment_range": (_i, [_i, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "hn_set_train_precision": (_i, [_vp, _i]),
     "hn_grad_floats": (_sz, []),
-    "hn_adam_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _c.c_longlong, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "hn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _c.c_longlong, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "hn_train_debug_unit": (_i, [_i, _i, _c.POINTER(_i64)]),
     "hn_train_debug_set": (_i, [_vp, _i, _vp, _vp]),
     "hn_train_debug_set2": (_i, [_vp, _i, _vp, _vp]),

@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __rest
 // updates that tensor's parameter storage in place.  Same arithmetic as torch.optim.Adam (no amsgrad): L2 weight
 // decay folded into the gradient, bias-corrected step size, denom = sqrt(v) / sqrt(1 - b2^t) + eps.
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* const* __restrict__ params, const long long* __restrict__ offsets,
-                                                        const unsigned char* __restrict__ active, int n_tensors,
+                                                        const long long* __restrict__ ends, const unsigned char* __restrict__ active,
+                                                        int n_tensors,
                                                         const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                         long long total, float lr, float b1, float b2, float eps, float wd, float bc1,
                                                         float bc2_sqrt, float inv_grad_scale)
@@ -417,8 +418,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* const* __restrict
         for (int k = 0; k < 4; ++k) {
             const long long i = i4 + k;
             if (i >= total) break;
-            while (i >= offsets[t + 1]) ++t;            // offsets[n_tensors] = total
-            if (!active[t]) continue;
+            while (t + 1 < n_tensors && i >= offsets[t + 1]) ++t;
+            if (i >= ends[t] || !active[t]) continue;   // alignment gap between two tensors of the flat layout / frozen tensor
             float* p = params[t] + (i - offsets[t]);
             float gi = g[i] * inv_grad_scale;
             const float pi = *p;
@@ -575,18 +576,19 @@ int hn_launch_lstm_bwd_gates(const float* saved, const float* dy, float* dh_rec,
     return 0;
 }
 
-// One Adam step for every parameter tensor (see adam_flat_kernel).  params / offsets / active are DEVICE arrays
-// (n_tensors pointers, n_tensors + 1 element offsets into the flat buffers, n_tensors flags); grads / m / v are flat
-// float32 buffers of `total` elements in the layout of hn_grad_offset().
-extern "C" int hn_adam_step(float* const* params, const long long* offsets, const unsigned char* active, int n_tensors, const float* grads,
+// One Adam step for every parameter tensor (see adam_flat_kernel).  params / offsets / ends / active are DEVICE arrays
+// (n_tensors pointers, first / one-past-last element of every tensor inside the flat buffers in ascending order, flags);
+// grads / m / v are flat float32 buffers of `total` elements in the layout of hn_grad_offset().
+extern "C" int hn_adam_step(float* const* params, const long long* offsets, const long long* ends, const unsigned char* active, int n_tensors,
+                            const float* grads,
                             float* m, float* v, long long total, float lr, float beta1, float beta2, float eps, float weight_decay,
                             int step, float grad_scale, void* stream)
 {
-    HN_REQUIRE(params && offsets && active && grads && m && v, "hn_adam_step: null pointer");
+    HN_REQUIRE(params && offsets && ends && active && grads && m && v, "hn_adam_step: null pointer");
     HN_REQUIRE(n_tensors >= 1 && total >= 1 && step >= 1 && grad_scale > 0.f, "hn_adam_step: bad sizes / step");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for((total + 3) / 4, 256L * 32)), dim3(256), 0, (hipStream_t)stream, params, offsets, active,
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for((total + 3) / 4, 256L * 32)), dim3(256), 0, (hipStream_t)stream, params, offsets, ends, active,
                        n_tensors, grads, m, v, total, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), 1.f / grad_scale);
     HN_LAUNCH_CHECK();
     return 0;

@@ -37,9 +37,10 @@ class FusedAdam:
             order.append((o, k, p))
         order.sort(key=lambda r: r[0])
         self.order = order
-        self.offsets = torch.tensor([r[0] for r in order] + [self.total], dtype=torch.int64, device=dev)
+        self.offsets = torch.tensor([r[0] for r in order], dtype=torch.int64, device=dev)
+        self.ends = torch.tensor([r[0] + r[2].numel() for r in order], dtype=torch.int64, device=dev)
         for (o, k, p), nxt in zip(order, [r[0] for r in order[1:]] + [self.total]):
-            assert nxt - o == p.numel(), "flat layout does not tile the parameters (%s)" % k
+            assert o + p.numel() <= nxt, "flat layout overlaps at %s" % k           # (alignment gaps between tensors are fine)
         self.m = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.step_count = 0
@@ -97,7 +98,7 @@ class FusedAdam:
         ptrs, active = self._tables()
         self.step_count += 1
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.hn_adam_step(_lib.ptr(ptrs), _lib.ptr(self.offsets), _lib.ptr(active), len(self.order),
+            _lib.check(self.lib.hn_adam_step(_lib.ptr(ptrs), _lib.ptr(self.offsets), _lib.ptr(self.ends), _lib.ptr(active), len(self.order),
                                              ctypes.c_void_p(base), _lib.ptr(self.m), _lib.ptr(self.v), self.total, g["lr"], g["betas"][0],
                                              g["betas"][1], g["eps"], g["weight_decay"], self.step_count, float(grad_scale),
                                              _lib.stream_ptr(self.device)), "hn_adam_step")

@@ -176,12 +176,14 @@ int hn_grad_segments(void);
 int hn_grad_segment_range(int segment, int64_t* first, int64_t* count);
 
 /* One Adam step (torch.optim.Adam arithmetic, no amsgrad; train.py:216-225,279) for ALL parameter tensors in one launch.
- * params: DEVICE array of n_tensors float32 pointers (the parameter storages, updated in place); offsets: DEVICE array of
- * n_tensors + 1 element offsets of the tensors inside the flat buffers (hn_grad_offset() layout, last = total); active:
+ * params: DEVICE array of n_tensors float32 pointers (the parameter storages, updated in place); offsets / ends: DEVICE
+ * arrays of the first / one-past-last element of every tensor inside the flat buffers (hn_grad_offset() layout, ascending;
+ * the layout may leave alignment gaps between tensors); active:
  * DEVICE array of n_tensors flags (0 = frozen, skipped); grads: the flat gradient buffer of hn_train_backward; m, v: flat
  * first / second moments (total floats each, caller-owned state); step: 1-based step count; grad_scale: the loss scale
  * the gradients carry (1 if none). */
-int hn_adam_step(float* const* params, const long long* offsets, const unsigned char* active, int n_tensors, const float* grads,
+int hn_adam_step(float* const* params, const long long* offsets, const long long* ends, const unsigned char* active, int n_tensors,
+                 const float* grads,
                  float* m, float* v, long long total, float lr, float beta1, float beta2, float eps, float weight_decay,
                  int step, float grad_scale, void* stream);
 
