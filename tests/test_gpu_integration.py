@@ -387,17 +387,51 @@ def test_config5_layouts_vs_reference_inference(golden_dir):
 
 
 # ---- train.py:216-225,279: the optimiser ----------------------------------------------------------------------------
-def test_fused_adam_equals_torch_adam():
-    """horizonnet_amd.optim.FusedAdam (one hn_adam_step launch over the flat gradient buffer) against torch.optim.Adam on
-    the same gradients for 3 steps, with weight decay, a changing learning rate and a frozen block."""
+def test_adam_kernel_equals_torch_adam_on_synthetic_tensors():
+    """hn_adam_step on a synthetic flat layout (4 tensors, alignment gaps, one frozen) against torch.optim.Adam: weight
+    decay, changing learning rate, gradients spanning 1e-9 .. 1e-2."""
+    from hiputil import P, lib, sp
+    L = lib()
+    torch.manual_seed(0)
+    sizes, offs, total = [1000, 12, 4096, 7], [0, 1024, 1088, 5248], 5312
+    ps = [(torch.randn(n, device=DEV) * 0.05) for n in sizes]
+    frozen0 = ps[1].clone()
+    pt = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam([pt[0], pt[2], pt[3]], lr=1e-3, weight_decay=1e-2)
+    m, v = torch.zeros(total, device=DEV), torch.zeros(total, device=DEV)
+    ptrs = torch.tensor([p.data_ptr() for p in ps], dtype=torch.int64, device=DEV)
+    o = torch.tensor(offs, dtype=torch.int64, device=DEV)
+    e = torch.tensor([a + b for a, b in zip(offs, sizes)], dtype=torch.int64, device=DEV)
+    act = torch.tensor([1, 0, 1, 1], dtype=torch.uint8, device=DEV)
+    for step in range(1, 4):
+        lr = 1e-3 * (1 - 0.2 * (step - 1))
+        flat = torch.full((total,), float("nan"), device=DEV)           # gaps hold NaN: they must never be read into a parameter
+        for p, of, n in zip(pt, offs, sizes):
+            g = torch.randn(n, device=DEV) * 10 ** float(torch.randint(-9, -2, (1,)))
+            p.grad = g.clone()
+            flat[of:of + n] = g
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        opt.step()
+        _lib.check(L.hn_adam_step(P(ptrs), P(o), P(e), P(act), 4, P(flat), P(m), P(v), total, lr, 0.9, 0.999, 1e-8, 1e-2, step, 1.0, sp()), "hn_adam_step")
+    torch.cuda.synchronize()
+    worst = max(float((a - b).abs().max() / a.abs().max()) for a, b in zip([pt[0], pt[2], pt[3]], [ps[0], ps[2], ps[3]]))
+    print("[parity] hn_adam_step vs torch.optim.Adam (synthetic layout, 3 steps): worst relative difference %.2e" % worst)
+    assert worst < 5e-7 and torch.equal(ps[1], frozen0)
+
+
+def test_fused_adam_drives_the_engine_like_torch_adam():
+    """horizonnet_amd.optim.FusedAdam on the real module: the gradients it reads are the engine's flat buffer behind the
+    p.grad views; three steps against torch.optim.Adam fed the same gradients (weight_decay 0: with decay, elements
+    whose g + wd * p cancels make Adam's normalised update chaotic at the 1-ulp level in BOTH implementations)."""
     from horizonnet_amd.optim import FusedAdam
     x, y_bon, y_cor = _batch(61, B=1)
     nets = [_train_net(60), _train_net(60)]
     for net in nets:
         for p in net.feature_extractor.encoder.conv1.parameters():
             p.requires_grad = False
-    opt_t = torch.optim.Adam([p for p in nets[0].parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
-    opt_f = FusedAdam(nets[1], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    opt_t = torch.optim.Adam([p for p in nets[0].parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    opt_f = FusedAdam(nets[1], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
     for step in range(3):
         lr = 1e-3 * (1.0 - 0.2 * step)
         loss, _, _ = _loss(nets[0], x, y_bon, y_cor)
@@ -407,8 +441,6 @@ def test_fused_adam_equals_torch_adam():
         for g_ in opt_t.param_groups:
             g_["lr"] = lr
         opt_t.step()
-        # same gradients into the fused optimiser: run net 1's own step (its weights equal net 0's up to the previous
-        # steps' 1-ulp differences), then overwrite its flat gradient views with net 0's gradients
         loss1, _, _ = _loss(nets[1], x, y_bon, y_cor)
         opt_f.zero_grad()
         loss1.backward()
@@ -417,21 +449,17 @@ def test_fused_adam_equals_torch_adam():
                 p.grad.copy_(g_)
         opt_f.param_groups[0]["lr"] = lr
         opt_f.step()
+        assert opt_f.used_views                      # autograd adopted the engine's views: no gather copy
     torch.cuda.synchronize()
-    worst = 0.0
-    for (k, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        d = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
-        worst = max(worst, d)
-    print("[parity] FusedAdam vs torch.optim.Adam after 3 steps: worst relative parameter difference %.2e" % worst)
-    assert worst < 2e-6
+    worst = max(float((a - b).abs().max()) for a, b in zip(nets[0].parameters(), nets[1].parameters()))
+    print("[parity] FusedAdam vs torch.optim.Adam on the module after 3 steps: worst absolute parameter difference %.2e (lr 1e-3)" % worst)
+    assert worst < 2e-6                               # 0.2 % of one step
     w0 = make_state_dict(60, "random")["feature_extractor.encoder.conv1.1.weight"]
     assert torch.equal(nets[1].feature_extractor.encoder.conv1[1].weight.detach().cpu(), w0)      # frozen tensor untouched
     sd = opt_f.state_dict()
     opt_g = FusedAdam(nets[1], lr=1e-3)
     opt_g.load_state_dict(sd)
     assert opt_g.step_count == 3 and torch.equal(opt_g.m, opt_f.m)
-    # the engine sees the new weights (re-pack triggered by step()): an eval forward after the fused step is finite and
-    # differs from before
     nets[1].eval()
     with torch.no_grad():
         b1, _ = nets[1](x)
