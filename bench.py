@@ -243,7 +243,8 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
     net = seeded_net(0).to(dev).train()
     net.train_precision = dtype          # bf16: the three conv GEMMs on the bf16 matrix cores, rest f32
     broadcast_module_(net)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), fused=True)
+    from horizonnet_amd.optim import FusedAdam
+    opt = FusedAdam(net, lr=1e-4, betas=(0.9, 0.999))     # one hn_adam_step launch over the flat gradient buffer (train.py:216-225,279)
     rng = np.random.RandomState(2000 + rank)
     total_iters = max(1, warmup + steps)
     state = {"it": 0, "host_s": 0.0}

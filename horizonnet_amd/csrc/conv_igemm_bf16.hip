@@ -11,7 +11,10 @@
 //   * v_mfma_f32_32x32x16_bf16: one 16-byte fragment (8 consecutive k) per lane per operand feeds ONE
 //     MFMA (lanes 0-31 carry k = 16s..16s+7, lanes 32-63 k = 16s+8..16s+15);
 //   * the epilogue converts with v_cvt_pk_bf16_f32 (round to nearest even) and stores 16 bytes per lane.
-// The 7x7 stem reads an NHWC8 bf16 image (3 real channels), 8 taps x 8 channels per 128-byte chunk.
+// The 7x7 stem reads an NHWC4 bf16 image (3 real channels + 0; 8 bytes per pixel).  One 128-byte K chunk holds TWO filter
+// rows: 2 x (8 pixels x 4 channels), the 8-pixel window starting at the even pixel 2*wo - 4 (tap 0 and channel 3 carry
+// zero weights) so every 16-byte DMA piece is an aligned pixel pair; 7 filter rows -> 4 chunks, K = 256 (the NHWC8 /
+// one-row-per-chunk form of round 1 spent K = 448 on the same 147 real products).
 #include "hn_common.h"
 
 #include <stdlib.h>
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
 
     const int hw_out = TR ? p.cHo * p.cWo : p.Ho * p.Wo;
     const int b_first = m0 / hw_out;
-    const size_t img_elems = (size_t)p.Hi * p.Wi * (STEM ? 8 : p.xstride);
+    const size_t img_elems = (size_t)p.Hi * p.Wi * (STEM ? 4 : p.xstride);
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w =
@@ -147,14 +150,21 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                 wi = tw >> p.sw_log2;
                 ok = ok && th >= 0 && hi < p.Hi;
             } else {
-                hi = a_hi0[q] + dh;
-                wi = a_wi0[q] + (STEM ? lcol : dw);
+                if (STEM) {      // dh = chunk index: piece lcol -> filter row 2*dh + (lcol >> 2), pixel pair (lcol & 3) of the window
+                    const int frow = 2 * dh + (lcol >> 2);
+                    hi = a_hi0[q] + frow;
+                    wi = a_wi0[q] - 1 + 2 * (lcol & 3);             // a_wi0 = 2*wo - 3: the window starts at the even pixel 2*wo - 4
+                    ok = ok && frow < 7;
+                } else {
+                    hi = a_hi0[q] + dh;
+                    wi = a_wi0[q] + dw;
+                }
                 wi = wi < 0 ? wi + p.Wi : wi;
                 wi = wi >= p.Wi ? wi - p.Wi : wi;
                 ok = ok && ((unsigned)hi < (unsigned)p.Hi);
             }
             const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
-            const unsigned off = STEM ? pix * 16u : (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u;
+            const unsigned off = STEM ? pix * 8u : (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u;
             a_off[q] = ok ? off : OOB;
         }
     };
@@ -912,21 +922,24 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     }
 }
 
-// (x[:, :3] - mean) / std, NCHW f32 -> NHWC8 bf16 (channels 3..7 = 0)   (reference model.py:248-252)
-__global__ __launch_bounds__(256) void prep_nhwc8_bf16_kernel(const float* __restrict__ x, u16* __restrict__ out, long npix, long total,
+// (x[:, :3] - mean) / std, NCHW f32 -> NHWC4 bf16 (channel 3 = 0; 8 bytes per pixel)   (reference model.py:248-252)
+__global__ __launch_bounds__(256) void prep_nhwc4_bf16_kernel(const float* __restrict__ x, u16* __restrict__ out, long npix, long total,
                                                               int C_in)
 {
     const float mean[3] = {0.485f, 0.456f, 0.406f};
     const float stdv[3] = {0.229f, 0.224f, 0.225f};
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // 2 pixels (16 bytes out) per thread
+    for (long i2 = (long)blockIdx.x * blockDim.x + threadIdx.x; i2 * 2 < total; i2 += (long)gridDim.x * blockDim.x) {
+        const long i = i2 * 2;
         const long b = i / npix;
-        const long pix = i - b * npix;
+        const long pix = i - b * npix;                       // npix is even: the pair never straddles two images
         const float* src = x + b * C_in * npix + pix;
-        const float v0 = (src[0] - mean[0]) / stdv[0];
-        const float v1 = (src[npix] - mean[1]) / stdv[1];
-        const float v2 = (src[2 * npix] - mean[2]) / stdv[2];
-        u32x4 o = {pack_bf16(v0, v1), pack_bf16(v2, 0.f), 0u, 0u};
-        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+        const float2 c0 = *reinterpret_cast<const float2*>(src);
+        const float2 c1 = *reinterpret_cast<const float2*>(src + npix);
+        const float2 c2 = *reinterpret_cast<const float2*>(src + 2 * npix);
+        u32x4 o = {pack_bf16((c0.x - mean[0]) / stdv[0], (c1.x - mean[1]) / stdv[1]), pack_bf16((c2.x - mean[2]) / stdv[2], 0.f),
+                   pack_bf16((c0.y - mean[0]) / stdv[0], (c1.y - mean[1]) / stdv[1]), pack_bf16((c2.y - mean[2]) / stdv[2], 0.f)};
+        *reinterpret_cast<u32x4*>(out + i * 4) = o;
     }
 }
 
@@ -1009,6 +1022,21 @@ __global__ __launch_bounds__(256) void pack_conv_bf16_kernel(const float* __rest
     }
 }
 
+// 7x7 stem: OIHW f32 [64][3][7][7] -> packed bf16 [64][4 chunks][2 filter rows][8 taps][4 channels] (tap t <-> dw = t - 1)
+__global__ __launch_bounds__(256) void pack_stem_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout)
+{
+    const long total = (long)Cout * 256;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 3);
+        const int t = (int)((i >> 2) & 7);
+        const int dh = (int)((i >> 5) & 7);                  // chunk * 2 + row-in-chunk
+        const int o = (int)(i >> 8);
+        float v = 0.f;
+        if (ch < 3 && t >= 1 && dh < 7) v = w[(((long)o * 3 + ch) * 7 + dh) * 7 + (t - 1)];
+        out[i] = (u16)(pack_bf16(v, 0.f) & 0xffffu);
+    }
+}
+
 // OIHW f32 -> per-class data-gradient packing [Cin][ndh][ndw][Cout] in bf16 (only the taps that reach the class)
 __global__ __launch_bounds__(256) void pack_dgrad_class_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout, int Cin,
                                                                     int KH, int KW, int dh0, int dh1, int dh2, int ndh, int dw0, int dw1,
@@ -1057,13 +1085,13 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     HN_REQUIRE(!d.res || !out_f32, "conv bf16: a residual with float32 output is only used by the data-gradient launcher");
     {
         const double span = 256.0 / ((double)d.Ho * d.Wo) + 2.0;
-        HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 8 : a.xstride) * 2.0 < 2147483648.0, "conv bf16: image too large for 32-bit tile offsets");
+        HN_REQUIRE(span * d.Hi * d.Wi * (double)(d.stem ? 4 : a.xstride) * 2.0 < 2147483648.0, "conv bf16: image too large for 32-bit tile offsets");
     }
     if (d.stem) {
         HN_REQUIRE(d.KH == 7 && d.KW == 7 && d.Cout == 64, "stem conv bf16: expects 7x7, Cout=64");
-        HN_REQUIRE(d.Ho * d.Wo >= 128, "stem conv bf16: image >= one tile");
-        a.K = 7 * BKE;
-        a.nk = 7;
+        HN_REQUIRE(d.Ho * d.Wo >= 128 && d.Wi % 2 == 0, "stem conv bf16: image >= one tile, even width");
+        a.K = 4 * BKE;
+        a.nk = 4;
         return out_f32 ? launch_cfg_h<128, 64, 2, 2, true, true>(a, s) : launch_cfg_h<128, 64, 2, 2, true, false>(a, s);
     }
     HN_REQUIRE(d.Cin % BKE == 0, "conv bf16: Cin=%d must be a multiple of %d", d.Cin, BKE);
@@ -1129,10 +1157,14 @@ int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* 
 
 int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s)
 {
-    const bool stem = KH == 7;
-    const int KWp = stem ? 8 : KW, Cp = stem ? 8 : Cin;
-    const long total = (long)Cout * KH * KWp * Cp;
-    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, reinterpret_cast<u16*>(out), Cout, Cin, KH, KW, KWp, Cp);
+    if (KH == 7) {          // the stem: its own K layout (see the header)
+        HN_REQUIRE(KW == 7 && Cin == 3, "pack bf16: the 7x7 form is the 3-channel stem only");
+        hipLaunchKernelGGL(pack_stem_bf16_kernel, dim3(grid_for((long)Cout * 256)), dim3(256), 0, s, w, reinterpret_cast<u16*>(out), Cout);
+        HN_LAUNCH_CHECK();
+        return 0;
+    }
+    const long total = (long)Cout * KH * KW * Cin;
+    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, reinterpret_cast<u16*>(out), Cout, Cin, KH, KW, KW, Cin);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -1145,10 +1177,11 @@ int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s)
     return 0;
 }
 
-int hn_launch_prep_nhwc8_bf16(const float* x, void* out, int B, int C_in, int H, int W, hipStream_t s)
+int hn_launch_prep_nhwc4_bf16(const float* x, void* out, int B, int C_in, int H, int W, hipStream_t s)
 {
     const long npix = (long)H * W, total = npix * B;
-    hipLaunchKernelGGL(prep_nhwc8_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, reinterpret_cast<u16*>(out), npix, total, C_in);
+    HN_REQUIRE(npix % 2 == 0 && W % 2 == 0, "prep bf16: even image width required");
+    hipLaunchKernelGGL(prep_nhwc4_bf16_kernel, dim3(grid_for(total / 2)), dim3(256), 0, s, x, reinterpret_cast<u16*>(out), npix, total, C_in);
     HN_LAUNCH_CHECK();
     return 0;
 }

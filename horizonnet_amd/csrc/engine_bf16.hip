@@ -152,10 +152,10 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
     e->prof.clear();
     e->events_used = 0;
 
-    {   // stem: normalise -> NHWC8 bf16, 7x7/2 conv + BN + ReLU, max-pool
+    {   // stem: normalise -> NHWC4 bf16, 7x7/2 conv + BN + ReLU, max-pool
         const ConvLayer& c = a.convs[a.stem];
         ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
-        if ((rc = hn_launch_prep_nhwc8_bf16(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
+        if ((rc = hn_launch_prep_nhwc4_bf16(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
         ConvDesc d;
         memset(&d, 0, sizeof(d));
         d.x = reinterpret_cast<const float*>(W + pl.xn); d.w = reinterpret_cast<const float*>(H + h.conv[a.stem]);

@@ -26,7 +26,7 @@ struct Unit {
 struct TrainPlan {
     std::vector<Unit> units;
     int blk[4][6], dsu[4], ghc[4];         // unit indices
-    size_t xn8, poolh, dzh[2];             // bf16: NHWC8 normalised image, max-pool output, two dz staging buffers
+    size_t xn8, poolh, dzh[2];             // bf16: NHWC4 normalised image, max-pool output, two dz staging buffers
     size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
     size_t stat_fwd_doubles, stat_bwd_first, stat_bwd_doubles, stat_lstm;   // layout of the statistics arena at `dstat` (doubles)
     size_t gmax;
@@ -349,7 +349,7 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     if ((rc = hn_launch_prep_nhwc4(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;          // f32: the stem's weight gradient reads it
     if (e->train_bf16) {
         HN_REQUIRE(e->packed_h != nullptr, "hn_train_forward: train_precision bf16 needs hn_pack_weights_bf16");
-        if ((rc = hn_launch_prep_nhwc8_bf16(x, W + pl.xn8, B, C_in, IMG_H, IMG_W, s))) return rc;
+        if ((rc = hn_launch_prep_nhwc4_bf16(x, W + pl.xn8, B, C_in, IMG_H, IMG_W, s))) return rc;
     }
     {
         const Unit& u = pl.units[0];

@@ -164,7 +164,8 @@ def main(argv=None):
     if args.optim == "SGD":
         optimizer = torch.optim.SGD(live, lr=args.lr, momentum=args.beta1, weight_decay=args.weight_decay)
     elif args.optim == "Adam":
-        optimizer = torch.optim.Adam(live, lr=args.lr, betas=(args.beta1, 0.999), weight_decay=args.weight_decay, fused=True)
+        from .optim import FusedAdam           # torch.optim.Adam's arithmetic, one launch over the engine's flat gradient buffer
+        optimizer = FusedAdam(net, lr=args.lr, betas=(args.beta1, 0.999), weight_decay=args.weight_decay)
     else:
         raise NotImplementedError()
 

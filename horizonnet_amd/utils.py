@@ -70,7 +70,7 @@ def resume_checkpoint(path, net, optimizer, args, device):
     blob = torch.load(path, map_location="cpu", weights_only=False)
     unwrap(net).load_state_dict(blob["state_dict"])
     optimizer.load_state_dict(blob["optimizer"])
-    for state in optimizer.state.values():
+    for state in getattr(optimizer, "state", {}).values():            # torch optimisers; FusedAdam moves its own buffers
         for k, v in state.items():
             if torch.is_tensor(v) and v.is_floating_point() and v.dim() > 0:
                 state[k] = v.to(device)
