@@ -43,6 +43,7 @@ struct ConvArgsH {
     int M, K, nk, relu, ldy;
     int xstride;
     int xcd_swizzle;
+    int ksplit;          // > 1: split-K -- blockIdx.y = K slice, float32 partial tiles to y + slice * M * ldy (forward, OUT_F32 only)
     double* stat_sum;    // optional per-channel sum / sum of squares of the stored rows (train-mode BatchNorm statistics)
     double* stat_sq;
     // data-gradient mode (template TR), see conv_igemm_f32.hip: one launch = one stride-parity class of dX pixels
@@ -169,8 +170,21 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
         }
     };
 
+    // K range of this workgroup: everything, or slice blockIdx.y of a split-K launch (deep-K convs with few output tiles:
+    // the tails of the height-compression chains).  Slices are contiguous chunk ranges in the usual k order.
+    int kb = 0, ke = p.nk;
     int dh = 0, dw = 0, c0 = 0;
-    tap_offsets(0, 0);
+    if (!STEM && !TR && p.ksplit > 1) {
+        const int sl = blockIdx.y;
+        kb = (int)((long)p.nk * sl / p.ksplit);
+        ke = (int)((long)p.nk * (sl + 1) / p.ksplit);
+        const int cpt = p.Cin / BKE;                     // chunks per filter tap
+        const int tap = kb / cpt;
+        c0 = (kb - tap * cpt) * BKE;
+        dh = tap / p.KW;
+        dw = tap - dh * p.KW;
+    }
+    tap_offsets(dh, dw);
 
     auto fetch = [&](int kc) {       // chunk kc -> LDS stage (kc & 1)
         char* a_s = smem + (kc & 1) * STAGE_BYTES;
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     const int fswz = (fr >> 1) & 7;
 
     if (!TR || p.nk > 0) {      // a parity class no tap reaches (1x1 stride 2) has K = 0: dX = add there
-        fetch(0);
+        fetch(kb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -229,10 +243,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                                         acc[i][j], 0, 0, 0);
         };
-        if (!TR || p.nk > 0) ldfrag(fa0, fb0, 0, 0);
-        for (int kc = 0; kc < p.nk; ++kc) {
+        if (!TR || p.nk > 0) ldfrag(fa0, fb0, kb & 1, 0);
+        for (int kc = kb; kc < ke; ++kc) {
             const int buf = kc & 1;
-            const bool more = kc + 1 < p.nk;
+            const bool more = kc + 1 < ke;
             if (more) fetch(kc + 1);
             ldfrag(fa1, fb1, buf, 1);
             mma(fa0, fb0);
@@ -311,8 +325,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                 const int m = m0 + h * EROWS + row;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + row * CS + ccol);
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + row * CS + ccol + 4);
-                v0 = v0 * sc0 + sf0;
-                v1 = v1 * sc1 + sf1;
+                if (p.ksplit <= 1) {          // (split-K partial tiles stay raw: the reduce kernel applies scale / shift once)
+                    v0 = v0 * sc0 + sf0;
+                    v1 = v1 * sc1 + sf1;
+                }
                 if (HAS_RES) {
                     if (OUT_F32) {
                         v0 += rres_lo[h * NPS + ps];
@@ -333,7 +349,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                         st2a += v0 * v0; st2b += v1 * v1;
                     }
                     if (OUT_F32) {
-                        float* yo = reinterpret_cast<float*>(p.y) + out_pix(m) * p.ldy + n0 + ccol;
+                        float* yo = reinterpret_cast<float*>(p.y) + (p.ksplit > 1 ? (size_t)blockIdx.y * p.M * p.ldy : (size_t)0) +
+                                    out_pix(m) * p.ldy + n0 + ccol;
                         *reinterpret_cast<f32x4*>(yo) = v0;
                         *reinterpret_cast<f32x4*>(yo + 4) = v1;
                     } else {
@@ -888,7 +905,7 @@ int launch_cfg_h(const ConvArgsH& a, hipStream_t s)
     constexpr size_t c_tile = (size_t)(BM / WAVES_M) * (BN + 4) * 4;
     constexpr size_t one_stage = (size_t)(BM + BN) * ROWB;
     const size_t lds_launch = (a.nk <= 1 && !a.stat_sum) ? (c_tile > one_stage ? c_tile : one_stage) : lds;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(256), lds_launch, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT), (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(256), lds_launch, s, a);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -1055,6 +1072,30 @@ __global__ __launch_bounds__(256) void pack_dgrad_class_bf16_kernel(const float*
     }
 }
 
+// split-K tail: out[m][n] = act(scale[n] * sum_s partial[s][m][n] + shift[n]) -> bf16, slices summed in index order
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ part, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, u16* __restrict__ out, long MN8, int N8,
+                                                                 long slice_elems, int S, int relu)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN8; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N8) * 8;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int sl = 0; sl < S; ++sl) {
+            const float* q = part + sl * slice_elems + i * 8;
+            a0 += *reinterpret_cast<const f32x4*>(q);
+            a1 += *reinterpret_cast<const f32x4*>(q + 4);
+        }
+        a0 = a0 * *reinterpret_cast<const f32x4*>(scale + n) + *reinterpret_cast<const f32x4*>(shift + n);
+        a1 = a1 * *reinterpret_cast<const f32x4*>(scale + n + 4) + *reinterpret_cast<const f32x4*>(shift + n + 4);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] = fmaxf(a0[k], 0.f); a1[k] = fmaxf(a1[k], 0.f); }
+        }
+        u32x4 o = {pack_bf16(a0[0], a0[1]), pack_bf16(a0[2], a0[3]), pack_bf16(a1[0], a1[1]), pack_bf16(a1[2], a1[3])};
+        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+    }
+}
+
 inline unsigned grid_for(long total, long cap = 256L * 16)
 {
     long g = (total + 255) / 256;
@@ -1080,6 +1121,7 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.relu = d.relu;
     a.ldy = d.ldy ? d.ldy : d.Cout;
     a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq;
+    a.ksplit = 1;
     a.sh_log2 = a.sw_log2 = a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
     for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;
     HN_REQUIRE(!d.res || !out_f32, "conv bf16: a residual with float32 output is only used by the data-gradient launcher");
@@ -1099,6 +1141,31 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BKE;
     HN_REQUIRE(256.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
+    // Split-K for deep-K convs with few output tiles (tails of the height-compression chains: ghc3.2 has 64 tiles of 128x128
+    // with K = 9216, ghc3.3 16 tiles).  The slice count depends on the layer's shape at the nominal batch of 32 ONLY, never on
+    // the actual M, so the summation order -- and with it every output bit -- is the same for any batch size.
+    if (!out_f32 && !d.res && !d.stat_sum && d.splitk_ws && d.Cout % 128 == 0 && d.B > 0) {
+        static const char* sk_env = getenv("HN_BF16_SPLITK");
+        const long per_image = (long)d.Ho * d.Wo;
+        const long t32 = (long)hn_cdiv(32 * per_image, 128) * (d.Cout / 128);
+        int S = t32 >= 192 ? 1 : (int)(256 / t32);
+        if (S > 8) S = 8;
+        while (S > 1 && a.nk / S < 8) --S;
+        if (sk_env && atoi(sk_env) == 0) S = 1;
+        if (S > 1 && (size_t)S * a.M * d.Cout <= d.splitk_ws_floats) {
+            ConvArgsH b = a;
+            b.ksplit = S;
+            b.y = d.splitk_ws;
+            b.relu = 0;
+            b.ldy = d.Cout;
+            if (int rc = launch_cfg_h<128, 128, 2, 2, false, true, false>(b, s)) return rc;
+            const long MN8 = (long)a.M * d.Cout / 8;
+            hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid_for(MN8)), dim3(256), 0, s, d.splitk_ws, d.scale, d.shift,
+                               reinterpret_cast<u16*>(d.y), MN8, d.Cout / 8, (long)a.M * d.Cout, S, d.relu);
+            HN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     {
         bool taken = false;
         const int rc = out_f32 ? dispatch_w8<true>(a, d.Cout, s, &taken) : dispatch_w8<false>(a, d.Cout, s, &taken);

@@ -39,8 +39,10 @@ size_t hn_bf16_conv_offset(int ci) { return hoff().conv[ci]; }
 
 namespace {
 
+constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 8 * 128 * 256;   // up to 8 slices of the largest split layer (ghc2.2: 256 x 256 per panorama)
+
 struct PlanH {                     // byte offsets
-    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, xch, total;
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, xch, sk, total;
     size_t c[4];                   // C1..C4 (the layer outputs): own buffers, read by the next stage AND by the branch stream
     size_t ga[4], gb[4];           // per-scale ping-pong of the height-compression chain (the four chains may overlap)
 };
@@ -72,12 +74,13 @@ PlanH make_plan_h(int B)
     p.y1h = take((size_t)T_COLS * b * 1024 * 2);
     p.y2 = take((size_t)T_COLS * b * 1024 * 4);
     p.xch = take(hn_lstm_bf16_xch_bytes());
+    p.sk = take(SPLITK_WS_FLOATS_PER_PANO * b * 4);      // split-K partial tiles (branch stream only: one user at a time)
     p.total = off;
     return p;
 }
 
 int run_conv_h(hn_engine* e, const ConvLayer& c, size_t woff, const void* x, void* y, const void* res, int B, int Hi, int Wi, int sh,
-               int sw, int relu, hipStream_t s)
+               int sw, int relu, hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_floats = 0)
 {
     const float* P = e->packed;
     ConvDesc d;
@@ -90,6 +93,7 @@ int run_conv_h(hn_engine* e, const ConvLayer& c, size_t woff, const void* x, voi
     d.Ho = (Hi + 2 * d.ph - c.k) / sh + 1;
     d.Wo = (Wi + 2 * d.pw - c.k) / sw + 1;
     d.relu = relu; d.ldy = c.cout;
+    d.splitk_ws = splitk_ws; d.splitk_ws_floats = splitk_ws_floats;
     ProfScope ps(e, s, c.wkey, 2.0 * B * d.Ho * d.Wo * (double)c.cout * c.cin * c.k * c.k);
     return hn_launch_conv_bf16(d, 0, s);
 }
@@ -222,7 +226,9 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
         for (int k = 0; k < 4; ++k) {
             const int ig = a.ghc_first[li] + k;
             char* gout = gbuf[k & 1];
-            if ((rc = run_conv_h(e, a.convs[ig], h.conv[ig], gin, gout, nullptr, B, gh, Wd, 2, 1, 1, sb))) return rc;
+            if ((rc = run_conv_h(e, a.convs[ig], h.conv[ig], gin, gout, nullptr, B, gh, Wd, 2, 1, 1, sb, reinterpret_cast<float*>(W + pl.sk),
+                                 SPLITK_WS_FLOATS_PER_PANO * (size_t)B)))
+                return rc;
             gin = gout;
             gh /= 2;
         }

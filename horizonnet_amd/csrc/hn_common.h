@@ -52,6 +52,8 @@ struct ConvDesc {
     int xstride;         // floats between input pixels (0 = Cin)
     double* stat_sum;    // optional [Cout]: += column sums of the stored output (train-mode BatchNorm statistics, fused in the epilogue)
     double* stat_sq;     // optional [Cout]: += column sums of squares
+    float* splitk_ws;    // optional scratch for split-K partial tiles (bf16 forward; see hn_launch_conv_bf16)
+    size_t splitk_ws_floats;
     int transposed;      // 1 = data-gradient mode: x = dY [B][Hi][Wi][Cin(=Cout of the fwd conv)], y = dX [B][Ho][Wo][Cout(=Cin fwd)],
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };

@@ -204,3 +204,32 @@ def test_forward_bf16_branch_stream_is_bit_identical():
     assert net.hip_status(DEV) == 0
     for b, c in outs + [(bs, cs_)]:
         assert torch.equal(b, b0) and torch.equal(c, c0)
+
+
+def test_forward_bf16_split_k_matches_unsplit(monkeypatch):
+    """The deep-K / few-tile tails of the height-compression chains run split-K (float32 partial tiles + an ordered
+    reduce).  Against the unsplit kernels (HN_BF16_SPLITK=0 is read once per process, so the comparison runs in a child
+    process) the outputs may differ only by float32 summation order."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from horizonnet_amd import HorizonNet
+from oracle.weights import make_state_dict
+net = HorizonNet("resnet50", True); net.load_state_dict(make_state_dict(0, "random")); net = net.to("cuda:0").eval(); net.precision = "bf16"
+x = torch.rand(3, 3, 512, 1024, generator=torch.Generator().manual_seed(97)).to("cuda:0")
+with torch.no_grad():
+    b, c = net(x)
+torch.save((b.cpu(), c.cpu()), sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = []
+    for flag in ("1", "0"):
+        f = tempfile.mktemp(suffix=".pt")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, HN_BF16_SPLITK=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+        os.remove(f)
+    assert report("bf16 split-K vs unsplit: bon", outs[0][0].numpy(), outs[1][0].numpy(), 2e-4)
+    assert report("bf16 split-K vs unsplit: cor", outs[0][1].numpy(), outs[1][1].numpy(), 2e-4)
