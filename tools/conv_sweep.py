@@ -79,10 +79,14 @@ def run(shape, variant, iters=10):
 def main():
     print("# bf16 conv tile sweep, B=%d; columns: 4-wave kernels | 256x256 | 256x128 | 128x256  (ms, TF/s)" % B)
     tot = {0: 0.0, "best": 0.0, "auto": 0.0}
+    only = [t for t in os.environ.get("SWEEP_ONLY", "").split(",") if t]
+    variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "0,1,2,3,-1").split(",")]
     for shp in SHAPES:
         name, Hi, Wi, cin, cout, k, sh, sw, res = shp
+        if only and not any(t in name for t in only):
+            continue
         row, best, ref = [], None, None
-        for v in (0, 1, 2, 3, -1):
+        for v in variants:
             legal = v in (0, -1) or (v == 1 and cout % 256 == 0) or (v == 2 and cout % 128 == 0) or (v == 3 and cout % 256 == 0)
             if not legal:
                 row.append("      -      ")
@@ -91,9 +95,9 @@ def main():
             if v == 0:
                 ref = y.float().clone()
                 tot[0] += ms
-            elif v > 0:
+            elif v > 0 and ref is not None:
                 err = float((y.float() - ref).abs().max())
-                assert err == 0.0, (name, v, err)             # same k order -> bit-identical to the 4-wave kernel
+                assert err == 0.0 or os.environ.get("HN_W8_ABL", "0") != "0", (name, v, err)   # same k order -> bit-identical to the 4-wave kernel
             if v == -1:
                 tot["auto"] += ms
             elif best is None or ms < best[0]:
