@@ -56,6 +56,7 @@ struct ConvArgs {
     int ca, cb, cHo, cWo;
     int tdh[3], tdw[3], ntdh, ntdw;
     int xcd_swizzle;     // 1: remap blockIdx so each XCD (own L2) works on a contiguous run of tiles
+    int ksplit;          // > 1: split-K -- blockIdx.y = K slice, raw float32 partial tiles to y + slice * M * ldy (forward only)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -182,8 +183,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     };
 
     f32x4 ra[AP], rb[BP];
+    // K range of this workgroup: everything, or slice blockIdx.y of a split-K launch (deep-K convs with few output tiles)
+    int kb = 0, ke = p.nk;
     int dh = 0, dw = 0, c0 = 0;      // filter-tap cursor of the chunk being fetched
-    tap_offsets(0, 0);
+    if (!STEM && !TR && p.ksplit > 1) {
+        const int sl = blockIdx.y;
+        kb = (int)((long)p.nk * sl / p.ksplit);
+        ke = (int)((long)p.nk * (sl + 1) / p.ksplit);
+        const int cpt = p.Cin / BK;
+        const int tap = kb / cpt;
+        c0 = (kb - tap * cpt) * BK;
+        dh = tap / p.KW;
+        dw = tap - dh * p.KW;
+    }
+    tap_offsets(dh, dw);
 
     auto fetch = [&](int kc) {
         if (DMA) {
@@ -243,8 +256,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
     const int fswz = (fr >> 1) & 7;  // DMA layout: slot permutation of this lane's fragment rows (same for every 32-row tile)
 
     if (!TR || p.nk > 0) {      // a parity class no tap reaches (1x1 stride 2) has K = 0: dX = add there
-    fetch(0);
-    stage(0);
+    fetch(kb);
+    stage(kb & 1);
     __syncthreads();
     }
 
@@ -272,10 +285,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
         };
-        if (!TR || p.nk > 0) ldfrag(fa0, fb0, 0, 0);
-        for (int kc = 0; kc < p.nk; ++kc) {
+        if (!TR || p.nk > 0) ldfrag(fa0, fb0, kb & 1, 0);
+        for (int kc = kb; kc < ke; ++kc) {
             const int buf = kc & 1;
-            const bool more = kc + 1 < p.nk;
+            const bool more = kc + 1 < ke;
             if (more) fetch(kc + 1);
             ldfrag(fa1, fb1, buf, 1);
             mma(fa0, fb0);
@@ -346,14 +359,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
                 const int row = crow + ps * RPP;
                 const int m = m0 + h * EROWS + row;
                 f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + ccol);
-                v = v * sc + sf;
+                if (p.ksplit <= 1) v = v * sc + sf;      // (split-K partial tiles stay raw: the reduce kernel applies scale / shift once)
                 if (HAS_RES) v += rres[h * NPS + ps];
                 if (p.relu) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 }
                 if (m < p.M) {
-                    *reinterpret_cast<f32x4*>(p.y + out_pix(m) * p.ldy + n0 + ccol) = v;
+                    *reinterpret_cast<f32x4*>(p.y + (p.ksplit > 1 ? (size_t)blockIdx.y * p.M * p.ldy : (size_t)0) + out_pix(m) * p.ldy + n0 + ccol) = v;
                     if (p.stat_sum) {            // wave-uniform: inference launches skip the statistics arithmetic
                         st1 += v;
                         st2 += v * v;
@@ -612,9 +625,27 @@ int launch_cfg_d(const ConvArgs& a, hipStream_t s)
     }
     const int MT = hn_cdiv(a.M, BM);
     const int NT = a.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT), (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(256), lds, s, a);
     HN_LAUNCH_CHECK();
     return 0;
+}
+
+// split-K tail: out[m][n] = act(scale[n] * sum_s partial[s][m][n] + shift[n]), slices summed in index order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const float* __restrict__ part, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float* __restrict__ out, long MN4, int N4,
+                                                                long slice_elems, int S, int relu)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN4; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N4) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < S; ++sl) a += *reinterpret_cast<const f32x4*>(part + sl * slice_elems + i * 4);
+        a = a * *reinterpret_cast<const f32x4*>(scale + n) + *reinterpret_cast<const f32x4*>(shift + n);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = a;
+    }
 }
 
 // OIHW -> per-class data-gradient packing [Cin][ndh][ndw][Cout] (only the taps that reach the class)
@@ -727,6 +758,7 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
     a.xstride = d.xstride ? d.xstride : d.Cin;
     a.sh_log2 = a.sw_log2 = 0; a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
+    a.ksplit = 1;
     HN_REQUIRE(!d.transposed, "conv: data gradients go through hn_launch_conv_dgrad");
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;
@@ -749,6 +781,32 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BK;
     HN_REQUIRE(128.0 * a.K * 4.0 < 2147483648.0, "conv: K too large for 32-bit weight-tile offsets");
+    // Deterministic split-K for the deep-K / tiny-M tails of the height-compression chains (ghc3.3: 16 tiles of 64x128
+    // at the nominal batch, K = 4608).  The slice count depends on the layer's shape at the nominal batch of 32 only, never
+    // on the actual M: the summation order -- and every output bit -- is the same for any batch size.
+    if (!d.res && !d.stat_sum && d.splitk_ws && d.Cout % 128 == 0 && !force_tile) {
+        static const int sk_on = env_flag("HN_F32_SPLITK", 1);
+        const long t32 = (long)hn_cdiv(32L * d.Ho * d.Wo, 64) * (d.Cout / 128);
+        int S = t32 >= 192 ? 1 : (int)(256 / t32);
+        if (S > 8) S = 8;
+        while (S > 1 && a.nk / S < 16) --S;
+        if (!sk_on) S = 1;
+        if (S > 1 && (size_t)S * a.M * d.Cout <= d.splitk_ws_floats) {
+            ConvArgs b = a;
+            b.ksplit = S;
+            b.y = d.splitk_ws;
+            b.relu = 0;
+            b.ldy = d.Cout;
+            if (int rc = launch_cfg<64, 128, 2, 2, false>(b, s)) return rc;
+            const long MN4 = (long)a.M * d.Cout / 4;
+            long g = (MN4 + 255) / 256;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((unsigned)g), dim3(256), 0, s, d.splitk_ws, d.scale, d.shift, d.y, MN4, d.Cout / 4,
+                               (long)a.M * d.Cout, S, d.relu);
+            HN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     return dispatch_tiles<false>(a, d.Cout, force_tile, s);
 }
 

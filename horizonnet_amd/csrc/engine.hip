@@ -124,8 +124,10 @@ const Arch& arch()
 namespace {
 // ---- workspace plan ----------------------------------------------------------------------------
 struct Plan {
-    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y2, total;   // float offsets
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y2, sk, total;   // float offsets
 };
+
+constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 8 * 128 * 256;   // up to 8 slices of the largest split layer per panorama
 
 Plan make_plan(int B)
 {
@@ -148,6 +150,7 @@ Plan make_plan(int B)
     p.gx = take((size_t)T_COLS * b * 4096);
     p.y1 = take((size_t)T_COLS * b * 1024);
     p.y2 = take((size_t)T_COLS * b * 1024);
+    p.sk = take(SPLITK_WS_FLOATS_PER_PANO * b);      // split-K partial tiles (conv_igemm_f32.hip)
     p.total = off;
     return p;
 }
@@ -305,7 +308,7 @@ extern "C" int hn_pack_weights(hn_engine* e, void* packed, size_t packed_bytes, 
 namespace {
 
 int run_conv(hn_engine* e, const float* P, const ConvLayer& c, const float* x, float* y, const float* res, int B, int Hi,
-             int Wi, int sh, int sw, int relu, hipStream_t s)
+             int Wi, int sh, int sw, int relu, hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_floats = 0)
 {
     ConvDesc d;
     memset(&d, 0, sizeof(d));
@@ -315,6 +318,7 @@ int run_conv(hn_engine* e, const float* P, const ConvLayer& c, const float* x, f
     d.Ho = (Hi + 2 * d.ph - c.k) / sh + 1;
     d.Wo = (Wi + 2 * d.pw - c.k) / sw + 1;
     d.relu = relu; d.ldy = c.cout; d.stem = 0;
+    d.splitk_ws = splitk_ws; d.splitk_ws_floats = splitk_ws_floats;
     ProfScope ps(e, s, c.wkey, 2.0 * B * d.Ho * d.Wo * (double)c.cout * c.cin * c.k * c.k);
     return hn_launch_conv(d, s);
 }
@@ -412,7 +416,7 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
         for (int k = 0; k < 4; ++k) {
             const ConvLayer& gc = a.convs[a.ghc_first[li] + k];
             float* gout = gbuf[k & 1];
-            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s))) return rc;
+            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s, W + pl.sk, SPLITK_WS_FLOATS_PER_PANO * (size_t)B))) return rc;
             gin = gout;
             gh /= 2;
         }
