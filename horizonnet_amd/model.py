@@ -173,6 +173,7 @@ class _DeviceState:
         self.packed_h = None               # bf16 conv / input-GEMM weights, allocated on first bf16 forward
         self.signature_h = None
         self.signature = None
+        self.ptr_signature = None
         self.keepalive = None
         self.workspaces = {}                 # kind ("f32" | "bf16" | "train") -> (B, tensor): one batch size per kind
         self.train_generation = 0            # bumped whenever the train workspace's saved activations are overwritten / freed
@@ -370,20 +371,25 @@ class HorizonNet(nn.Module):
                 _lib.check(st.lib.hn_set_option(st.handle, k.encode(), int(v)), "hn_set_option(%s)" % k)
             self._hip_states[device.index] = st
         tensors = list(self._state_tensors())
-        sig = tuple((t.data_ptr(), t._version) for _, t in tensors) + (self._train_steps,)
+        ptr_sig = tuple(t.data_ptr() for _, t in tensors)
+        sig = tuple(t._version for _, t in tensors) + (self._train_steps,) + ptr_sig
         if sig != st.signature:
-            keep = []
-            for k, t in tensors:
-                if t.device != device:
-                    raise RuntimeError("parameter %s lives on %s but the input is on %s" % (k, t.device, device))
-                d = t.detach()
-                if d.dtype != torch.float32 or not d.is_contiguous():
-                    d = d.float().contiguous()
-                keep.append(d)
-                _lib.check(st.lib.hn_bind_tensor(st.handle, k.encode(), _lib.ptr(d), d.numel()), "hn_bind_tensor(%s)" % k)
+            if ptr_sig != st.ptr_signature:          # storages moved (first call, .to(), load_state_dict into new tensors): re-bind
+                keep = []
+                for k, t in tensors:
+                    if t.device != device:
+                        raise RuntimeError("parameter %s lives on %s but the input is on %s" % (k, t.device, device))
+                    d = t.detach()
+                    if d.dtype != torch.float32 or not d.is_contiguous():
+                        d = d.float().contiguous()
+                    keep.append(d)
+                    _lib.check(st.lib.hn_bind_tensor(st.handle, k.encode(), _lib.ptr(d), d.numel()), "hn_bind_tensor(%s)" % k)
+                st.keepalive = keep
+                # (a converted copy is a snapshot: remember the ORIGINAL pointers only when every tensor was bound in place)
+                st.ptr_signature = ptr_sig if all(a.data_ptr() == b.data_ptr() for a, (_, b) in zip(keep, tensors)) else None
+            # values changed (optimiser step, in-place edits): the 379 bindings stand, only the packed copies are rebuilt
             _lib.check(st.lib.hn_pack_weights(st.handle, _lib.ptr(st.packed), st.packed.numel(),
                                               _lib.stream_ptr(device)), "hn_pack_weights")
-            st.keepalive = keep
             st.signature = sig
         return st
 

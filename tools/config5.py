@@ -1,11 +1,12 @@
-"""BASELINE configs[2] + configs[4] in one GPU job (MEASUREMENT TOOL -- test infrastructure, may use oracle/).
+"""BASELINE configs[2] + configs[4] in one GPU job (ROUND-1 MEASUREMENT TOOL -- test infrastructure, may use oracle/;
+the round-2 forms are `bench.py --mode train` / `--mode layout`, which compare with the UNMODIFIED reference's outputs).
 
 There is no dataset and no trained checkpoint offline, so:
 
 1. render a synthetic Structured3D-shaped set of Manhattan rooms (tools/synth_rooms.py) -- panoramas + label_cor;
 2. train HorizonNet from random init on the MI355X engine for a few hundred steps with ALL of the reference's
    augmentations (flip, rotate, gamma, Pano-Stretch) through the fused device pipeline (horizonnet_amd.dataset
-   .DeviceBatcher), losses / optimiser of train.py:44-58,272-281 (float32; configs[2] asks bf16 -- not built yet);
+   .DeviceBatcher), losses / optimiser of train.py:44-58,272-281 (float32, or --train-precision bf16 = the bf16 matrix-core step);
 3. run the general-layout inference path (inference.py:65-141 = horizonnet_amd.inference) on held-out panoramas with
    (a) the engine in float32, (b) the engine in bf16, (c) the CPU float32 oracle of the reference forward, and report
    the per-image 3D IoU (eval_general.py:56-95 = horizonnet_amd.evaluation) between the predicted layouts -- the
