@@ -47,6 +47,7 @@ SIGNATURES = {
     "hn_grad_floats": (_sz, []),
     "hn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _c.c_longlong, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "hn_train_debug_unit": (_i, [_i, _i, _c.POINTER(_i64)]),
+    "hn_train_debug_unit_yh": (_i64, [_i, _i]),
     "hn_train_debug_set": (_i, [_vp, _i, _vp, _vp]),
     "hn_train_debug_set2": (_i, [_vp, _i, _vp, _vp]),
     "hn_grad_offset": (_i64, [_c.c_char_p]),

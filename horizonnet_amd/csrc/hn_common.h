@@ -76,7 +76,7 @@ int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, cons
 int hn_launch_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* a,
                               float* b, float* save_mean, float* save_invstd, int C, hipStream_t s);
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
-                         long M, int C, int relu, int z_bf16, hipStream_t s);
+                         long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s);
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
                            int C, int z_bf16, hipStream_t s);

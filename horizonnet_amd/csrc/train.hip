@@ -19,6 +19,7 @@ struct Unit {
     int stem;
     size_t x, z, y, st, mk;        // float offsets: input, pre-BN, post-activation, [mean|invstd|a|b], ReLU bit mask (1 byte per 4 outputs)
     size_t xh, yh;                 // float offsets of the bf16 copies of the input / of y (train_precision bf16)
+    int keep_y32;                  // bf16 mode: 1 = a float32 consumer of y exists (max-pool, up-sampling, an f32 weight-gradient fallback)
     size_t sf, sb;                 // this unit's slots in the statistics arena (doubles): forward [sum | sumsq], backward [S1 | S2 | dbias]
     long M;
 };
@@ -48,7 +49,7 @@ TrainPlan make_train_plan(int B)
     auto add_unit = [&](int ci, size_t x, size_t xh, int Hi, int Wi, int sh, int sw, int relu, int stem) {
         const ConvLayer& c = a.convs[ci];
         Unit u;
-        u.ci = ci; u.Hi = Hi; u.Wi = Wi; u.sh = sh; u.sw = sw; u.relu = relu; u.stem = stem;
+        u.ci = ci; u.Hi = Hi; u.Wi = Wi; u.sh = sh; u.sw = sw; u.relu = relu; u.stem = stem; u.keep_y32 = stem;
         u.Ho = (Hi + 2 * (c.k / 2) - c.k) / sh + 1;
         u.Wo = (Wi + 2 * (c.k / 2) - c.k) / sw + 1;
         u.M = (long)B * u.Ho * u.Wo;
@@ -88,6 +89,10 @@ TrainPlan make_train_plan(int B)
         for (int k = 0; k < 4; ++k) {
             const int u = add_unit(a.ghc_first[li] + k, gin, ginh, gh, W, 2, 1, 1, 0);
             if (k == 0) p.ghc[li] = u;
+            // float32 y is read by the circular up-sampling (last unit of a scale) and by ghc0.3's float32 weight gradient
+            // (Cout = 32 stays off the bf16 matrix-core path; its input is ghc0.2's y)
+            if (k == 3 || a.convs[a.ghc_first[li] + k].cout % 64 != 0 || (k < 3 && a.convs[a.ghc_first[li] + k + 1].cout % 64 != 0))
+                p.units[u].keep_y32 = 1;
             gin = p.units[u].y;
             ginh = p.units[u].yh;
             gh /= 2;
@@ -166,7 +171,7 @@ int conv_z(const Ctx& c, const Unit& u)
 
 // batch statistics (left in `dstat` by conv_z of the same unit, which must be the last conv launched) ->
 // y = act(bn(z) (+res)); updates the running statistics in place
-int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float momentum)
+int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float momentum, int res_bf16 = 0)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
     const int C = cl.cout;
@@ -181,8 +186,10 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
                                            c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
                                            st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
         return rc;
-    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, c.W + u.y, reinterpret_cast<unsigned char*>(c.W + u.mk),
-                                c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.e->train_bf16, c.s);
+    // bf16 mode: the float32 y is written only where a float32 consumer exists (u.keep_y32): 4 of the pass's bytes per element
+    float* y32 = (c.e->train_bf16 && !u.keep_y32) ? nullptr : c.W + u.y;
+    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, y32, reinterpret_cast<unsigned char*>(c.W + u.mk),
+                                c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.e->train_bf16, res_bf16, c.s);
 }
 
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
@@ -282,6 +289,14 @@ extern "C" int hn_train_debug_unit(int B, int unit, int64_t* out8)
     return 0;
 }
 
+// float offset of the unit's bf16 copy of y (train_precision bf16: the float32 y of most units is not written)
+extern "C" int64_t hn_train_debug_unit_yh(int B, int unit)
+{
+    const TrainPlan pl = make_train_plan(B);
+    if (unit < 0 || unit >= (int)pl.units.size()) return -1;
+    return (int64_t)pl.units[unit].yh;
+}
+
 extern "C" int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* dz_dst)
 {
     HN_REQUIRE(e != nullptr, "hn_train_debug_set: null engine");
@@ -367,13 +382,14 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
             const Unit& u3 = pl.units[i1 + (j == 0 ? 3 : 2)];
             if ((rc = conv_z(c, u1)) || (rc = bn_forward(c, u1, nullptr, 1, bn_momentum))) return rc;
             if ((rc = conv_z(c, u2)) || (rc = bn_forward(c, u2, nullptr, 1, bn_momentum))) return rc;
-            const float* idt = W + u1.x;
+            // identity branch of the block: float32, or (bf16 mode) the bf16 copy the previous pass wrote anyway
+            const float* idt = e->train_bf16 ? W + u1.xh : W + u1.x;
             if (j == 0) {
                 const Unit& ud = pl.units[pl.dsu[li]];
                 if ((rc = conv_z(c, ud)) || (rc = bn_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
-                idt = W + ud.y;
+                idt = e->train_bf16 ? W + ud.yh : W + ud.y;
             }
-            if ((rc = conv_z(c, u3)) || (rc = bn_forward(c, u3, idt, 1, bn_momentum))) return rc;
+            if ((rc = conv_z(c, u3)) || (rc = bn_forward(c, u3, idt, 1, bn_momentum, e->train_bf16))) return rc;
         }
         for (int k = 0; k < 4; ++k) {
             const Unit& ug = pl.units[pl.ghc[li] + k];

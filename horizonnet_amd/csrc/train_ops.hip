@@ -132,13 +132,14 @@ __global__ __launch_bounds__(256) void bn_eval_affine_kernel(const float* gamma,
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ b, const float* __restrict__ res,
                                                          float* __restrict__ y, unsigned char* __restrict__ bmask,
-                                                         unsigned short* __restrict__ y_h, long total4, int C4, int relu, int z_bf16)
+                                                         unsigned short* __restrict__ y_h, long total4, int C4, int relu, int z_bf16,
+                                                         int res_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         f32x4 v = load_z4(z, i * 4, z_bf16);
         v = v * *reinterpret_cast<const f32x4*>(a + c) + *reinterpret_cast<const f32x4*>(b + c);
-        if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
+        if (res) v += load_z4(res, i * 4, res_bf16);     // identity branch: float32, or the bf16 copy (train_precision bf16)
         if (relu) {
             unsigned mk = 0;
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
             }
             if (bmask) bmask[i] = (unsigned char)mk;     // the adjoint reads 1 byte instead of 16 (y > 0)
         }
-        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+        if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;    // (null in bf16 mode where only the bf16 copy is ever read)
         if (y_h) {                   // bf16 copy for the next conv's matrix-core operand (train_precision bf16)
             unsigned lo, hi;
             asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
@@ -495,11 +496,11 @@ int hn_launch_bn_eval_affine(const float* gamma, const float* beta, const float*
 }
 
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
-                         long M, int C, int relu, int z_bf16, hipStream_t s)
+                         long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s)
 {
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, bmask,
-                       reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu, z_bf16);
+                       reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu, z_bf16, res_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }

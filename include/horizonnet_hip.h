@@ -189,6 +189,7 @@ int hn_adam_step(float* const* params, const long long* offsets, const long long
 
 /* debug taps used by the parity tests (see train.hip) */
 int hn_train_debug_unit(int B, int unit, int64_t* out8);
+int64_t hn_train_debug_unit_yh(int B, int unit);   /* float offset of the unit's bf16 copy of y (bf16 mode) */
 int hn_train_debug_set(hn_engine* e, int unit, float* dy_dst, float* dz_dst);
 int hn_train_debug_set2(hn_engine* e, int unit, float* dy_dst, float* dz_dst);   /* a second unit of the same backward pass */
 int64_t hn_grad_offset(const char* name);

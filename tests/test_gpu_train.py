@@ -466,8 +466,10 @@ def test_bf16_train_units_locally_consistent():
             n, C = int(np.prod(shape)), info[u][2]
             stt = ws[info[u][6]:info[u][6] + 2 * C].cpu()
             zraw = st.train_workspace(B)[info[u][4] * 4:info[u][4] * 4 + 2 * n]        # bf16 mode stores z as bf16
+            yh_off = L.hn_train_debug_unit_yh(B, u)                                           # bf16 mode keeps y as bf16 only
+            yraw = st.train_workspace(B)[yh_off * 4:yh_off * 4 + 2 * n]
             out.append(dict(dy=bufs[u][0].cpu().view(shape), dz=bufs[u][1].cpu().view(shape),
-                            z=zraw.view(torch.bfloat16).float().cpu().view(shape), y=ws[info[u][5]:info[u][5] + n].cpu().view(shape),
+                            z=zraw.view(torch.bfloat16).float().cpu().view(shape), y=yraw.view(torch.bfloat16).float().cpu().view(shape),
                             mean=stt[:C], invstd=stt[C:], grads=grads))
         return out
 
