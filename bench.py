@@ -249,12 +249,20 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
     total_iters = max(1, warmup + steps)
     state = {"it": 0, "host_s": 0.0}
 
+    def draws():                                          # the sampler: random indices, then that batch's augmentation draws
+        while True:
+            yield rng.randint(len(data), size=B)
+
+    # host half (augmentation draws + label rasterisation) two batches ahead in a thread, like the reference's DataLoader
+    # workers (train.py:153-160); the device half (fused augmentation launch + label upload) runs in the step
+    batches = data.stream(draws(), rng, depth=2)
+
     def step():
         for g_ in opt.param_groups:                       # misc/utils.py:35-46, power 0.9
             g_["lr"] = 1e-4 * (1.0 - state["it"] / float(total_iters)) ** 0.9
         state["it"] += 1
         th = time.perf_counter()
-        x, y_bon, y_cor = data.batch(rng.randint(len(data), size=B), rng)
+        x, y_bon, y_cor = next(batches)
         state["host_s"] += time.perf_counter() - th
         bon, cor = net(x)
         loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
@@ -286,6 +294,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
     host_s = state["host_s"]
     assert net.hip_status(dev) == 0 and bool(torch.isfinite(loss))
     overlap = None
+    close_batches = batches.close
     if world > 1:                                          # exposed all-reduce time = step with exchange - step without
         net.sync_gradients = False
         local_wall, _ = timed(max(2, steps // 2))
@@ -296,6 +305,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
                    "overlap_fraction": round(1.0 - exposed_ms / rccl["allreduce_ms"], 3) if rccl and rccl["allreduce_ms"] > 0 else None,
                    "note": "backward runs in 5 gradient-completion segments; each finished range of the flat gradient buffer starts its "
                            "RCCL all-reduce at once (64 MB buckets) while the remaining segments compute"}
+    close_batches()
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     flop = 3.0 * FWD_FLOP_PER_PANO * B * world * steps          # fwd + dgrad + wgrad
     out = {"metric": "training panoramas/s (512x1024, data pipeline + fwd + bwd + Adam)", "value": round(B * world * steps / wall, 2),

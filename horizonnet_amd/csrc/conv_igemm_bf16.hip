@@ -1176,9 +1176,10 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
 
 // Data gradient of a forward conv on the bf16 matrix cores (see hn_launch_conv_dgrad in conv_igemm_f32.hip):
 // dz_h: bf16 [B][Ho][Wo][Cout]; w_oihw: the float32 master weights (re-packed per class into w_scratch as bf16);
-// add (optional) and dx are float32.  Needs Cout %% 64 == 0 (one K chunk = 64 bf16 channels of one tap).
+// add (optional) and dx are float32, or -- grad_bf16 -- both bf16 (train.hip keeps the gradients between conv units in bf16).
+// Needs Cout %% 64 == 0 (one K chunk = 64 bf16 channels of one tap).
 int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
-                              const float* ones, const float* zeros, hipStream_t s)
+                              const float* ones, const float* zeros, hipStream_t s, int grad_bf16)
 {
     static const char* env = getenv("HN_XCD_SWIZZLE");
     HN_REQUIRE((d.sh == 1 || d.sh == 2) && (d.sw == 1 || d.sw == 2) && !d.stem, "conv dgrad bf16: strides must be 1 or 2");
@@ -1215,7 +1216,7 @@ int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* 
                 HN_REQUIRE(span * a.Hi * a.Wi * (double)a.xstride * 2.0 < 2147483648.0, "conv dgrad bf16: image too large for 32-bit tile offsets");
                 HN_REQUIRE(128.0 * a.K * 2.0 < 2147483648.0, "conv dgrad bf16: K too large");
             }
-            if (int rc = dispatch<true, true>(a, d.Cin, s)) return rc;
+            if (int rc = grad_bf16 ? dispatch<false, true>(a, d.Cin, s) : dispatch<true, true>(a, d.Cin, s)) return rc;
             wp += (size_t)d.Cin * a.K;
         }
     }

@@ -69,7 +69,7 @@ int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh
 int hn_launch_transpose(const float* in, float* out, int R, int C, hipStream_t s);
 int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s);
 int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd, double* S1,
-                            double* S2, long M, int C, int z_bf16, hipStream_t s);
+                            double* S2, long M, int C, int z_bf16, int dy_bf16, hipStream_t s);
 int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float* a, float* b, float* save_mean, float* save_invstd, int C,
                           hipStream_t s);
@@ -79,11 +79,14 @@ int hn_launch_affine_act(const float* z, const float* a, const float* b, const f
                          long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s);
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
-                           int C, int z_bf16, hipStream_t s);
+                           int C, int z_bf16, int dy_bf16, hipStream_t s);
 int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
 int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
-int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, hipStream_t s);
-int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
+int hn_launch_axpy_bf16(const void* x, void* y, long n, hipStream_t s);
+int hn_launch_bf16_to_f32(const void* in, float* out, long n, hipStream_t s);
+int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, int dout_bf16,
+                          hipStream_t s);
+int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, int out_bf16, hipStream_t s);
 int hn_launch_dropout(const float* in, float* out, long n, float p, unsigned long long seed, hipStream_t s);
 int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, const float* y, float* dy, float* dlin, float* dw,
                        float* db, int T, int B, hipStream_t s);
@@ -104,7 +107,7 @@ int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int K
 int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
                               int sh, int sw, hipStream_t s);
 int hn_launch_conv_dgrad_bf16(const ConvDesc& fwd, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
-                              const float* ones, const float* zeros, hipStream_t s);
+                              const float* ones, const float* zeros, hipStream_t s, int grad_bf16 = 0);
 int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);
 int hn_launch_prep_nhwc4_bf16(const float* x, void* out, int B, int C_in, int H, int W, hipStream_t s);
 int hn_launch_maxpool_bf16(const void* in, void* out, int B, int Hi, int Wi, int C, hipStream_t s);

@@ -137,6 +137,7 @@ struct Ctx {
     float* grads;          // flat gradient buffer (may be null in forward)
     hipStream_t s;
     int B;
+    bool gh() const { return e->train_bf16 != 0; }      // bf16 mode: gradients BETWEEN conv units (dy, identity gradients) live in bf16
     bool bn_eval(const Unit& u) const { return (size_t)u.ci < e->bn_eval.size() && e->bn_eval[u.ci] != 0; }
     const float* bound(const std::string& k) const { return reinterpret_cast<const float*>(e->bound.at(k)); }
     float* bound_mut(const std::string& k) const { return const_cast<float*>(reinterpret_cast<const float*>(e->bound.at(k))); }
@@ -195,8 +196,10 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
 // tensor or null).  Produces dz (gradient w.r.t. the conv output), optional dpre (masked dy, the identity-branch
 // gradient), and the parameter gradients.
-int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0)
+// dy_bf16: dy (and dpre) are bf16 tensors -- every unit in bf16 mode except the stem, whose dy comes from the float32 max-pool adjoint.
+int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0, int dy_bf16 = -1)
 {
+    if (dy_bf16 < 0) dy_bf16 = c.gh() ? 1 : 0;
     // bf16 mode: dz is also written as bf16 (slot 0 / 1 of the staging buffers) for this unit's data-gradient GEMM
     void* dz_h = (c.e->train_bf16 && dzh_slot >= 0 && c.a.convs[u.ci].cout % 64 == 0) ? c.W + c.pl.dzh[dzh_slot] : nullptr;
     const ConvLayer& cl = c.a.convs[u.ci];
@@ -206,7 +209,7 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     // ymask != null: the unit ends in a ReLU; the adjoint reads the bit mask its affine_act pass stored (1/16 of y's bytes)
     const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
-    if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, c.s))) return rc;
+    if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, dy_bf16, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
     if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
     // eval-mode BatchNorm: mean / invstd are constants, so dz = gamma * invstd * g -- the batch-statistics formula with both sums zero
@@ -217,14 +220,20 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
                         (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]);
     const bool f32_dz_needed = !(dz_h && !u.stem && cl.cin % 64 == 0) || cl.has_bias || tapped;
     if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M,
-                                     f32_dz_needed ? dz : nullptr, dpre, dz_h, u.M, C, c.e->train_bf16, c.s)))
+                                     f32_dz_needed ? dz : nullptr, dpre, dz_h, u.M, C, c.e->train_bf16, dy_bf16, c.s)))
         return rc;
     if (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) {
-        if (c.e->debug_dy) HN_HIP(hipMemcpyAsync(c.e->debug_dy, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        if (c.e->debug_dy) {      // taps are float32 whatever the storage type
+            if (dy_bf16) { if ((rc = hn_launch_bf16_to_f32(dy, c.e->debug_dy, (long)u.M * C, c.s))) return rc; }
+            else HN_HIP(hipMemcpyAsync(c.e->debug_dy, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        }
         if (c.e->debug_dz) HN_HIP(hipMemcpyAsync(c.e->debug_dz, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     }
     if (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]) {
-        if (c.e->debug_dy2) HN_HIP(hipMemcpyAsync(c.e->debug_dy2, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        if (c.e->debug_dy2) {
+            if (dy_bf16) { if ((rc = hn_launch_bf16_to_f32(dy, c.e->debug_dy2, (long)u.M * C, c.s))) return rc; }
+            else HN_HIP(hipMemcpyAsync(c.e->debug_dy2, dy, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        }
         if (c.e->debug_dz2) HN_HIP(hipMemcpyAsync(c.e->debug_dz2, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     }
     if (cl.has_bias) {
@@ -253,7 +262,19 @@ int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, f
     d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo;
     if (c.e->train_bf16 && cl.cout % 64 == 0)      // (ghc0.3 has Cout = 32: stays on the f32 path)
         return hn_launch_conv_dgrad_bf16(d, c.W + c.pl.dzh[dzh_slot], c.bound(cl.wkey + ".weight"), add, dx, c.W + c.pl.wsB,
-                                         c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s);
+                                         c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s, /*grad_bf16=*/1);
+    if (c.gh()) {
+        // float32 kernel inside a bf16-gradient pass (only ghc0.3, no identity branch): float32 dX into scratch, then one
+        // conversion pass into the bf16 gradient tensor
+        HN_REQUIRE(add == nullptr, "unit_dgrad: the float32 fallback has no bf16 identity input");
+        const long n = (long)c.B * u.Hi * u.Wi * cl.cin;
+        HN_REQUIRE((size_t)n <= (size_t)T_COLS * c.B * 4096, "unit_dgrad: float32 fallback scratch too small");
+        float* tmp = c.W + c.pl.gx;      // the LSTM gate buffer: free once the recurrent adjoint is done
+        if (int rc = hn_launch_conv_dgrad(d, dz, c.bound(cl.wkey + ".weight"), nullptr, tmp, c.W + c.pl.wsB, c.P + c.a.ones_off,
+                                          c.P + c.a.zeros_off, c.s))
+            return rc;
+        return hn_launch_f32_to_bf16(tmp, dx, n, c.s);
+    }
     return hn_launch_conv_dgrad(d, dz, c.bound(cl.wkey + ".weight"), add, dx, c.W + c.pl.wsB, c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s);
 }
 
@@ -506,7 +527,7 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     // ---- height compression, all four scales: leaves d(C_s) in DC[s] ----
     for (int li = 0; li < 4; ++li) {
         const Unit& ul = pl.units[pl.ghc[li] + 3];
-        if (LIVE && (rc = hn_launch_upsample_flatten_bwd(dseq, G0, B, ul.Ho, ul.Wo, a.convs[ul.ci].cout, 256 * li, s))) return rc;
+        if (LIVE && (rc = hn_launch_upsample_flatten_bwd(dseq, G0, B, ul.Ho, ul.Wo, a.convs[ul.ci].cout, 256 * li, c.gh(), s))) return rc;
         float* gy = G0;
         float* gz = G1;
         float* gx = G3;
@@ -526,7 +547,8 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     float* Gc = G2;
     float* Gd = G3;
     const size_t csz[4] = {(size_t)B * 128 * 256 * 256, (size_t)B * 64 * 128 * 512, (size_t)B * 32 * 64 * 1024, (size_t)B * 16 * 32 * 2048};
-    if (LIVE) HN_HIP(hipMemcpyAsync(Ga, W + pl.DC[3], csz[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const size_t gsz = c.gh() ? 2 : sizeof(float);      // bytes per gradient element between conv units
+    if (LIVE) HN_HIP(hipMemcpyAsync(Ga, W + pl.DC[3], csz[3] * gsz, hipMemcpyDeviceToDevice, s));
     for (int li = 3; li >= 0; --li) {
         seg = li == 3 ? 2 : (li == 2 ? 3 : 4);
         for (int j = kBlocks[li] - 1; j >= 0; --j) {
@@ -551,14 +573,16 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             }
         }
         if (li > 0) {   // the block input of layer li is C_{li-1}: add the height-compression branch's gradient
-            if (LIVE && (rc = hn_launch_axpy(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s))) return rc;
+            if (LIVE && (rc = c.gh() ? hn_launch_axpy_bf16(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s)
+                                     : hn_launch_axpy(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s)))
+                return rc;
         }
     }
     // ---- max-pool + stem ----
     {
         const Unit& u = pl.units[0];
-        if (LIVE && (rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, s))) return rc;     // d(stem y) -> Gb
-        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1))) return rc;
+        if (LIVE && (rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, c.gh(), s))) return rc;     // d(stem y) -> Gb (float32)
+        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/0))) return rc;
     }
 #undef LIVE
     return 0;

@@ -24,7 +24,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const unsigned char* __restrict__ bmask,
                                                          const float* __restrict__ z, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, double* __restrict__ out0,
-                                                         double* __restrict__ out1, long M, int C, int lda, int slab, int z_bf16)
+                                                         double* __restrict__ out1, long M, int C, int lda, int slab, int z_bf16,
+                                                         int a_bf16)
 {
     __shared__ float red[2][256 * 4];
     const int CQ = (C < 256 ? C : 256) / 4;      // column quads per workgroup
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     if (rl < RL) {
         // 4 rows per trip: 4 (MODE 0) or 8-12 (MODE 1) independent 16-byte loads in flight per lane
         auto one = [&](long r, f32x4& a0, f32x4& a1) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(a + r * lda + col);
+            f32x4 v = load_z4(a, r * lda + col, a_bf16);          // (a_bf16: the gradient tensor is kept in bf16, train.hip)
             if (MODE == 0) {
                 a0 += v;
                 a1 += v * v;
@@ -165,11 +166,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ S1, const double* __restrict__ S2, double n,
                                                            float* __restrict__ dz, float* __restrict__ dpre,
-                                                           unsigned short* __restrict__ dz_h, long total4, int C4, int z_bf16)
+                                                           unsigned short* __restrict__ dz_h, long total4, int C4, int z_bf16,
+                                                           int dy_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        f32x4 g = load_z4(dy, i * 4, dy_bf16);
         if (bmask) {
             const unsigned mk = bmask[i];
 #pragma unroll
@@ -191,7 +193,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
             *reinterpret_cast<uint2*>(dz_h + i * 4) = make_uint2(lo, hi);
         }
-        if (dpre) *reinterpret_cast<f32x4*>(dpre + i * 4) = g;
+        if (dpre) {                  // identity-branch gradient, in the gradient tensors' storage type
+            if (dy_bf16) {
+                unsigned lo, hi;
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(g[0]), "v"(g[1]));
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(g[2]), "v"(g[3]));
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dpre) + i * 4) = make_uint2(lo, hi);
+            } else {
+                *reinterpret_cast<f32x4*>(dpre + i * 4) = g;
+            }
+        }
     }
 }
 
@@ -205,6 +216,24 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, 
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
         *reinterpret_cast<f32x4*>(y + i * 4) += *reinterpret_cast<const f32x4*>(x + i * 4);
+}
+
+// y += x on bf16 tensors (f32 add, one rounding)
+__global__ __launch_bounds__(256) void axpy_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = load_z4(reinterpret_cast<const float*>(x), i * 4, 1) + load_z4(reinterpret_cast<const float*>(y), i * 4, 1);
+        unsigned lo, hi;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+        *reinterpret_cast<uint2*>(y + i * 4) = make_uint2(lo, hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        *reinterpret_cast<f32x4*>(out + i * 4) = load_z4(reinterpret_cast<const float*>(in), i * 4, 1);
 }
 
 // max-pool 3x3/2 pad 1 adjoint, deterministic, in two passes: (1) per pooled output, the input position of its
@@ -239,7 +268,8 @@ __global__ __launch_bounds__(256) void maxpool_argmax_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const int* __restrict__ amax, const float* __restrict__ dout,
-                                                          float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C, long total)
+                                                          float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C, long total,
+                                                          int dout_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -255,7 +285,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const int* __restrict_
             for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
                 if (wo >= Wo) continue;
                 const long o = ((b * Ho + ho) * Wo + wo) * (long)C + c;
-                if (amax[o] == me) g += dout[o];
+                if (amax[o] == me)
+                    g += dout_bf16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(dout)[o] << 16) : dout[o];
             }
         }
         din[i] = g;
@@ -264,7 +295,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const int* __restrict_
 
 // adjoint of upsample_flatten: din[b][h][i][c] = sum_t w0(t)[i0(t)==i] * dseq + w1(t)[i1(t)==i] * dseq
 __global__ __launch_bounds__(256) void upsample_flatten_bwd_kernel(const float* __restrict__ dseq, float* __restrict__ din, int B, int hq,
-                                                                   int Wq, int cq, int col0, int f)
+                                                                   int Wq, int cq, int col0, int f, int out_bf16)
 {
     const int i = blockIdx.x;            // input column
     const int b = blockIdx.y;
@@ -286,7 +317,14 @@ __global__ __launch_bounds__(256) void upsample_flatten_bwd_kernel(const float* 
             if (i0 == i) g += w0 * d;
             if (i1 == i) g += w1 * d;
         }
-        din[(((long)b * hq + h) * Wq + i) * cq + c] = g;
+        const long o = (((long)b * hq + h) * Wq + i) * cq + c;
+        if (out_bf16) {
+            unsigned r;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(g), "v"(0.f));
+            reinterpret_cast<unsigned short*>(din)[o] = (unsigned short)(r & 0xffffu);
+        } else {
+            din[o] = g;
+        }
     }
 }
 
@@ -460,18 +498,18 @@ int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int 
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
     hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, s, a, (const unsigned char*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab, 0);
+                       (const float*)nullptr, (const float*)nullptr, sum, sumsq, M, C, lda ? lda : C, slab, 0, 0);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
 int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd, double* S1,
-                            double* S2, long M, int C, int z_bf16, hipStream_t s)
+                            double* S2, long M, int C, int z_bf16, int dy_bf16, hipStream_t s)
 {
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "bn_bwd_reduce: unsupported C=%d", C);
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
-    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, bmask, z, mean, invstd, S1, S2, M, C, C, slab, z_bf16);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, bmask, z, mean, invstd, S1, S2, M, C, C, slab, z_bf16, dy_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -507,11 +545,11 @@ int hn_launch_affine_act(const float* z, const float* a, const float* b, const f
 
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
-                           int C, int z_bf16, hipStream_t s)
+                           int C, int z_bf16, int dy_bf16, hipStream_t s)
 {
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, bmask, z, mean, invstd, gamma, S1, S2, n, dz,
-                       dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4, z_bf16);
+                       dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4, z_bf16, dy_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -532,21 +570,39 @@ int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s)
 }
 
 // scratch: B * (Hi/2) * (Wi/2) * C ints
-int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, hipStream_t s)
+int hn_launch_axpy_bf16(const void* x, void* y, long n, hipStream_t s)
+{
+    HN_REQUIRE(n % 4 == 0, "axpy bf16: n %% 4");
+    hipLaunchKernelGGL(axpy_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(x),
+                       reinterpret_cast<unsigned short*>(y), n / 4);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_bf16_to_f32(const void* in, float* out, long n, hipStream_t s)
+{
+    HN_REQUIRE(n % 4 == 0, "bf16_to_f32: n %% 4");
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(in), out, n / 4);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, int dout_bf16,
+                          hipStream_t s)
 {
     const long total = (long)B * Hi * Wi * C;
     const long total_o = (long)B * (Hi / 2) * (Wi / 2) * C;
     HN_REQUIRE((long)Hi * Wi < 0x7fffffffL, "maxpool_bwd: image too large");
     hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(grid_for(total_o, 256L * 64)), dim3(256), 0, s, in, scratch, Hi, Wi, Hi / 2, Wi / 2, C, total_o);
     HN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, scratch, dout, din, Hi, Wi, Hi / 2, Wi / 2, C, total);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, scratch, dout, din, Hi, Wi, Hi / 2, Wi / 2, C, total, dout_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
 
-int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, hipStream_t s)
+int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, int out_bf16, hipStream_t s)
 {
-    hipLaunchKernelGGL(upsample_flatten_bwd_kernel, dim3(Wq, B), dim3(256), 0, s, dseq, din, B, hq, Wq, cq, col0, 256 / Wq);
+    hipLaunchKernelGGL(upsample_flatten_bwd_kernel, dim3(Wq, B), dim3(256), 0, s, dseq, din, B, hq, Wq, cq, col0, 256 / Wq, out_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -155,11 +155,14 @@ class DeviceBatcher:
         self.flip, self.rotate, self.gamma, self.stretch = flip, rotate, gamma, stretch
         self.p_base, self.max_stretch = p_base, max_stretch
         self.H, self.W = int(images.shape[1]), int(images.shape[2])
+        self._staging, self._next_slot, self._ring = [], 0, 4     # pinned label staging ring (device_half)
 
     def __len__(self):
         return len(self.labels)
 
-    def batch(self, indices, rng=np.random):
+    def host_half(self, indices, rng=np.random):
+        """The host part of one batch: augmentation draws (reference order) + label rasterisation ->
+        (indices, augs, bon [B,2,W] float32, y_cor [B,1,W] float32)."""
         augs, bons, cors = [], [], []
         for i in indices:
             cor, occ = self.labels[i]
@@ -168,8 +171,88 @@ class DeviceBatcher:
             augs.append(a)
             bons.append(bon)
             cors.append(y_cor)
-        x = augment_images(self.data, list(indices), augs)
+        return list(indices), augs, np.stack(bons).astype(np.float32), np.stack(cors).astype(np.float32)
+
+    def device_half(self, indices, augs, bon, y_cor):
+        """The device part: one fused augmentation launch + the label upload.  The labels go through a ring of PINNED
+        staging tensors: a copy from pageable memory is a host-side wait for the stream on ROCm, i.e. one full
+        host <-> GPU synchronisation per training step."""
+        x = augment_images(self.data, indices, augs)
         dev = self.data.device
-        bon = torch.from_numpy(np.stack(bons).astype(np.float32)).to(dev, non_blocking=True)
-        y_cor = torch.from_numpy(np.stack(cors).astype(np.float32)).to(dev, non_blocking=True)
-        return x, bon, y_cor
+        B = len(indices)
+        k = self._next_slot % self._ring
+        self._next_slot += 1
+        if k == len(self._staging):
+            self._staging.append(None)
+        slot = self._staging[k]
+        if slot is None or slot["bon"].shape[0] < B:
+            slot = {"bon": torch.empty((B, 2, self.W), dtype=torch.float32).pin_memory(),
+                    "cor": torch.empty((B, 1, self.W), dtype=torch.float32).pin_memory(), "done": torch.cuda.Event()}
+            self._staging[k] = slot
+        else:
+            slot["done"].synchronize()                  # the upload that last used this slot (ring-size batches ago)
+        slot["bon"][:B].copy_(torch.from_numpy(bon))
+        slot["cor"][:B].copy_(torch.from_numpy(y_cor))
+        with torch.cuda.device(dev):
+            d_bon = slot["bon"][:B].to(dev, non_blocking=True)
+            d_cor = slot["cor"][:B].to(dev, non_blocking=True)
+            slot["done"].record()
+        return x, d_bon, d_cor
+
+    def batch(self, indices, rng=np.random):
+        return self.device_half(*self.host_half(indices, rng))
+
+    def stream(self, index_batches, rng=np.random, depth=2):
+        """Iterate over batches with the host half running `depth` batches AHEAD in a background thread -- the role of
+        the reference's DataLoader workers (train.py:153-160).  `index_batches`: an iterable of index arrays; the thread
+        consumes it and `rng` in order, so a seeded run draws exactly what the unthreaded loop draws.  The engine's
+        forward / backward are single foreign calls (GIL released), so the thread genuinely overlaps with them."""
+        return _BatchStream(self, index_batches, rng, depth)
+
+
+class _BatchStream:
+    def __init__(self, owner, index_batches, rng, depth):
+        import queue
+        import threading
+        self.owner = owner
+        self.q = queue.Queue(maxsize=max(1, int(depth)))
+        self.stop = threading.Event()
+
+        def work():
+            try:
+                for idx in index_batches:
+                    if self.stop.is_set():
+                        return
+                    item = owner.host_half(idx, rng)
+                    while not self.stop.is_set():
+                        try:
+                            self.q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                self.q.put(None)
+            except BaseException as e:                   # surfaces in the consumer, not in a dead thread
+                self.q.put(e)
+
+        self.thread = threading.Thread(target=work, name="horizonnet-batch-host-half", daemon=True)
+        self.thread.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return self.owner.device_half(*item)
+
+    def close(self):
+        self.stop.set()
+        while self.thread.is_alive():
+            try:
+                self.q.get_nowait()
+            except Exception:
+                pass
+            self.thread.join(timeout=0.05)

@@ -191,11 +191,13 @@ def main(argv=None):
             t = torch.from_numpy(perm).to(device)
             dist.broadcast(t, src=0)
             perm = t.cpu().numpy()
+        # host half of every batch (augmentation draws, label rasterisation) two batches ahead in a thread: the role of the
+        # reference's DataLoader workers (train.py:153-160); same np.random draw order as the unthreaded loop
+        batches = train.stream([perm[(it * world + rank) * B:(it * world + rank) * B + B] for it in range(iters_per_epoch)], depth=2)
         for it in range(iters_per_epoch):
             utils.adjust_learning_rate(optimizer, args)
             args.cur_iter += 1
-            lo = (it * world + rank) * B
-            x, y_bon, y_cor = train.batch(perm[lo:lo + B])
+            x, y_bon, y_cor = next(batches)
             losses = feed_forward(net, x, y_bon, y_cor)
             optimizer.zero_grad(set_to_none=True)
             losses["total"].backward()
@@ -207,6 +209,7 @@ def main(argv=None):
                 if rank == 0:
                     print("ep %d it %d lr %.3e bon %.4f cor %.4f" % (epoch, args.cur_iter, args.running_lr, row["bon"], row["cor"]),
                           flush=True)
+        batches.close()
         if dataset_valid is not None:
             scores = validate(net, dataset_valid, device)
             now = scores.get("3DIoU", 0.0)

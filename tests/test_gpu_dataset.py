@@ -97,6 +97,34 @@ def test_device_batcher_equals_per_sample_path():
         assert torch.equal(x[b].cpu(), xs) and torch.equal(bon[b].cpu(), bs) and torch.equal(y_cor[b].cpu(), cs)
 
 
+def test_batch_stream_equals_unthreaded_loop():
+    """DeviceBatcher.stream (host half two batches ahead in a thread, pinned label staging ring) hands out exactly the
+    batches the plain loop does for the same seed, survives more batches than the ring has slots, and raises the
+    thread's exception in the consumer."""
+    kw = dict(flip=True, rotate=True, gamma=True, stretch=True)
+    batcher = ds.DeviceBatcher(ROOT, device=DEV, **kw)
+    draws = [[(3 * i + j) % 4 for j in range(1 + i % 3)] for i in range(11)]          # ragged batch sizes, 11 > ring of 4
+    rng = np.random.RandomState(5)
+    want = [tuple(t.cpu() for t in batcher.batch(idx, rng)) for idx in draws]
+    rng = np.random.RandomState(5)
+    stream = batcher.stream(iter(draws), rng, depth=2)
+    got = [tuple(t.cpu() for t in b) for b in stream]
+    stream.close()
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert all(torch.equal(a, b) for a, b in zip(g, w))
+
+    bad = batcher.stream(iter([[0], [99]]), np.random.RandomState(1))                 # index 99 does not exist
+    next(bad)
+    with pytest.raises(IndexError):
+        next(bad)
+    bad.close()
+    early = batcher.stream(iter([[0]] * 50), np.random.RandomState(1), depth=2)       # closing mid-way must not hang
+    next(early)
+    early.close()
+    assert not early.thread.is_alive()
+
+
 def test_augment_batch_contract_errors():
     batcher = ds.DeviceBatcher(ROOT, device=DEV)
     a = {"kx": 1.0, "ky": 1.0, "flip": 0, "rotate": False, "roll": 0, "gamma": 1.0}

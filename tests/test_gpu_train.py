@@ -499,7 +499,8 @@ def test_bf16_train_units_locally_consistent():
         inv = 1.0 / torch.sqrt(zz.var(0, unbiased=False) + 1e-5)
         ok &= report("bf16 train invstd %s" % cn[-31:], cons["invstd"].numpy(), inv.numpy(), 1e-3 * float(inv.abs().max()))
         z_want.backward(r16(cons["dz"]))
-        ok &= report("bf16 train dy  %s" % pn[-34:], prod["dy"].numpy(), yin.grad.numpy(), 2e-3 * float(yin.grad.abs().max()))
+        # gradients between units are stored rounded to bf16 (f32 accumulators, one rounding at the store)
+        ok &= report("bf16 train dy  %s" % pn[-34:], prod["dy"].numpy(), yin.grad.numpy(), 2.0 ** -8 * float(yin.grad.abs().max()))
         w32 = w.clone().requires_grad_(True)                               # weight gradient: bf16 operands, exact products
         _conv_ref(r16(prod["y"]), w32, stride).backward(r16(cons["dz"]))
         ok &= report("bf16 train dW  %s" % cn[-34:], cons["grads"][cn + ".weight"].numpy(), w32.grad.numpy(), 2e-4 * float(w32.grad.abs().max()))
