@@ -79,7 +79,7 @@ int hn_launch_affine_act(const float* z, const float* a, const float* b, const f
                          long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s);
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
-                           int C, int z_bf16, int dy_bf16, hipStream_t s);
+                           int C, int z_bf16, int dy_bf16, double* db, hipStream_t s);
 int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
 int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
 int hn_launch_axpy_bf16(const void* x, void* y, long n, hipStream_t s);

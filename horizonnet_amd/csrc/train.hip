@@ -218,9 +218,14 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     // debug tap), it is not written at all (4 of the pass's ~16 bytes per element)
     const bool tapped = (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) ||
                         (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]);
-    const bool f32_dz_needed = !(dz_h && !u.stem && cl.cin % 64 == 0) || cl.has_bias || tapped;
+    const bool bf16_gemms = dz_h && !u.stem && cl.cin % 64 == 0;
+    // ... and the conv bias gradient (height-compression convs) is summed inside the all-bf16 apply kernel
+    const bool fused_db = cl.has_bias && bf16_gemms && dy_bf16 && !tapped && C % 8 == 0;
+    const bool f32_dz_needed = !bf16_gemms || (cl.has_bias && !fused_db) || tapped;
+    double* db = ds + 2 * C;
     if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M,
-                                     f32_dz_needed ? dz : nullptr, dpre, dz_h, u.M, C, c.e->train_bf16, dy_bf16, c.s)))
+                                     f32_dz_needed ? dz : nullptr, dpre, dz_h, u.M, C, c.e->train_bf16, dy_bf16, fused_db ? db : nullptr,
+                                     c.s)))
         return rc;
     if (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) {
         if (c.e->debug_dy) {      // taps are float32 whatever the storage type
@@ -237,8 +242,7 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
         if (c.e->debug_dz2) HN_HIP(hipMemcpyAsync(c.e->debug_dz2, dz, (size_t)u.M * C * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     }
     if (cl.has_bias) {
-        double* db = ds + 2 * C;
-        if ((rc = hn_launch_col_stats(dz, db, nullptr, u.M, C, C, c.s))) return rc;
+        if (!fused_db && (rc = hn_launch_col_stats(dz, db, nullptr, u.M, C, C, c.s))) return rc;
         if ((rc = hn_launch_d2f(db, c.grad(cl.wkey + ".bias"), C, c.s))) return rc;
     }
     // weight gradient (packed layout) -> OIHW

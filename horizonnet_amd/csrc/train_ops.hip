@@ -206,6 +206,186 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two BatchNorm-adjoint passes for train_precision bf16, where dy, z, dz and the identity gradient are all bf16:
+// EIGHT channels per lane (16-byte loads, 2-byte mask load), a lane keeps its channels for the whole row slab so every
+// per-channel constant is computed once, and the apply pass is two FMAs per element (no f64 division in the loop).
+//   workgroup = CO column octets x RL row lanes (CO = min(C / 8, 256)), grid = (row slabs, 2048-channel chunks).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float (&o)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = __builtin_bit_cast(float, v[k] << 16);
+        o[2 * k + 1] = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ u32x4_t pack8(const float (&o)[8])
+{
+    u32x4_t r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned t;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(o[2 * k]), "v"(o[2 * k + 1]));
+        r[k] = t;
+    }
+    return r;
+}
+
+// mask bytes hold 4 bits each (affine_act_kernel: one byte per float4) -> 8 channels = 2 bytes
+__device__ __forceinline__ unsigned mask8(const unsigned char* bmask, long e)
+{
+    const unsigned m = *reinterpret_cast<const unsigned short*>(bmask + (e >> 2));
+    return (m & 0xfu) | ((m >> 4) & 0xf0u);
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_h8_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ bmask,
+                                                               const unsigned short* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, double* __restrict__ S1,
+                                                               double* __restrict__ S2, long M, int C, int slab)
+{
+    __shared__ float red[2][256 * 8];
+    const int C8 = C / 8;
+    const int CO = C8 < 256 ? C8 : 256;
+    const int RL = 256 / CO;
+    const int co = threadIdx.x % CO, rl = threadIdx.x / CO;
+    const int col = blockIdx.y * 2048 + co * 8;
+    const long r0 = (long)blockIdx.x * slab;
+    long r1 = r0 + slab;
+    if (r1 > M) r1 = M;
+    float za[8], zb[8], s0[8], s1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        za[k] = invstd[col + k];                  // zhat = z * za + zb
+        zb[k] = -mean[col + k] * za[k];
+        s0[k] = 0.f;
+        s1[k] = 0.f;
+    }
+    auto accum = [&](const u32x4_t gv, const u32x4_t zv, unsigned mk) __attribute__((always_inline)) {
+        float g[8], zz[8];
+        unpack8(gv, g);
+        unpack8(zv, zz);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = (!MASK || ((mk >> k) & 1u)) ? g[k] : 0.f;
+            s0[k] += gk;
+            s1[k] += gk * (zz[k] * za[k] + zb[k]);
+        }
+    };
+    long r = r0 + rl;
+    for (; r + 3L * RL < r1; r += 4L * RL) {       // 4 rows per trip: 8 sixteen-byte loads in flight per lane
+        u32x4_t gv[4], zv[4];
+        unsigned mk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long e = (r + (long)j * RL) * C + col;
+            gv[j] = *reinterpret_cast<const u32x4_t*>(dy + e);
+            zv[j] = *reinterpret_cast<const u32x4_t*>(z + e);
+            if (MASK) mk[j] = mask8(bmask, e);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accum(gv[j], zv[j], mk[j]);
+    }
+    for (; r < r1; r += RL) {
+        const long e = r * C + col;
+        accum(*reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(z + e), MASK ? mask8(bmask, e) : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][threadIdx.x * 8 + k] = s0[k];
+        red[1][threadIdx.x * 8 + k] = s1[k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CO * 8; t += 256) {
+        const int q = t / 8, k = t % 8;
+        float t0 = 0.f, t1 = 0.f;
+        for (int j = 0; j < RL; ++j) {
+            t0 += red[0][(j * CO + q) * 8 + k];
+            t1 += red[1][(j * CO + q) * 8 + k];
+        }
+        const int c = blockIdx.y * 2048 + q * 8 + k;
+        atomicAdd(S1 + c, (double)t0);
+        atomicAdd(S2 + c, (double)t1);
+    }
+}
+
+// BIAS: also accumulate the column sums of dz (the conv bias gradient of the height-compression convs) into db
+template <bool MASK, bool BIAS>
+__global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ bmask,
+                                                              const unsigned short* __restrict__ z, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const double* __restrict__ S1, const double* __restrict__ S2, double n,
+                                                              unsigned short* __restrict__ dpre, unsigned short* __restrict__ dz_h,
+                                                              double* __restrict__ db, long M, int C, int slab)
+{
+    __shared__ float red[BIAS ? 256 * 8 : 1];
+    const int C8 = C / 8;
+    const int CO = C8 < 256 ? C8 : 256;
+    const int RL = 256 / CO;
+    const int co = threadIdx.x % CO, rl = threadIdx.x / CO;
+    const int col = blockIdx.y * 2048 + co * 8;
+    const long r0 = (long)blockIdx.x * slab;
+    long r1 = r0 + slab;
+    if (r1 > M) r1 = M;
+    // dz = gamma*invstd * (g - S1/n - zhat * S2/n) = ka * g + kz * z + kc   (the same f32 roundings of S1/n, S2/n as the generic kernel)
+    float ka[8], kz[8], kc[8], sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sb[k] = 0.f;
+        const float is = invstd[col + k], mu = mean[col + k];
+        const float m1 = (float)(S1[col + k] / n), m2 = (float)(S2[col + k] / n);
+        ka[k] = gamma[col + k] * is;
+        kz[k] = -ka[k] * is * m2;
+        kc[k] = -ka[k] * m1 - kz[k] * mu;
+    }
+    auto one = [&](long e, const u32x4_t gv, const u32x4_t zv, unsigned mk) __attribute__((always_inline)) {
+        float g[8], zz[8], o[8];
+        unpack8(gv, g);
+        unpack8(zv, zz);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (MASK) g[k] = ((mk >> k) & 1u) ? g[k] : 0.f;
+            o[k] = ka[k] * g[k] + (kz[k] * zz[k] + kc[k]);
+            if (BIAS) sb[k] += o[k];
+        }
+        *reinterpret_cast<u32x4_t*>(dz_h + e) = pack8(o);
+        if (dpre) *reinterpret_cast<u32x4_t*>(dpre + e) = MASK ? pack8(g) : gv;
+    };
+    long r = r0 + rl;
+    for (; r + 3L * RL < r1; r += 4L * RL) {
+        u32x4_t gv[4], zv[4];
+        unsigned mk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long e = (r + (long)j * RL) * C + col;
+            gv[j] = *reinterpret_cast<const u32x4_t*>(dy + e);
+            zv[j] = *reinterpret_cast<const u32x4_t*>(z + e);
+            if (MASK) mk[j] = mask8(bmask, e);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) one((r + (long)j * RL) * C + col, gv[j], zv[j], mk[j]);
+    }
+    for (; r < r1; r += RL) {
+        const long e = r * C + col;
+        one(e, *reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(z + e), MASK ? mask8(bmask, e) : 0u);
+    }
+    if (BIAS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sb[k];
+        __syncthreads();
+        for (int t = threadIdx.x; t < CO * 8; t += 256) {
+            const int q = t / 8, k = t % 8;
+            float t0 = 0.f;
+            for (int j = 0; j < RL; ++j) t0 += red[(j * CO + q) * 8 + k];
+            atomicAdd(db + blockIdx.y * 2048 + q * 8 + k, (double)t0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void d2f_kernel(const double* in, float* out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,6 +664,16 @@ inline unsigned grid_for(long total, long cap = 256L * 16)
 
 // Rows per workgroup of the column reductions: enough workgroups (>= ~2048) to fill 256 CUs several times over
 // even for the deep layers (M = a few thousand rows), at most 1024 rows so the f32 partial sums stay short.
+// eight-channels-per-lane kernels: C / 8 octets must tile a 256-lane workgroup (or be a multiple of it)
+static bool h8_shape(int C) { return C % 8 == 0 && (C / 8 <= 256 ? 256 % (C / 8) == 0 : (C / 8) % 256 == 0); }
+static int h8_slab(long M, int C)
+{
+    const long col_blocks = (C + 2047) / 2048;
+    long slab = (M * col_blocks + 4095) / 4096;
+    slab = (slab + 63) / 64 * 64;
+    return (int)(slab < 64 ? 64 : (slab > 1024 ? 1024 : slab));
+}
+
 static int reduce_slab(long M, int C)
 {
     const long col_blocks = (C + 255) / 256;
@@ -507,6 +697,16 @@ int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const f
                             double* S2, long M, int C, int z_bf16, int dy_bf16, hipStream_t s)
 {
     HN_REQUIRE(C % 4 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), "bn_bwd_reduce: unsupported C=%d", C);
+    if (z_bf16 && dy_bf16 && h8_shape(C)) {        // all-bf16 operands: the eight-channels-per-lane kernel
+        const int slab8 = h8_slab(M, C);
+        dim3 grid8((unsigned)((M + slab8 - 1) / slab8), (unsigned)((C + 2047) / 2048));
+        const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy);
+        const unsigned short* zh = reinterpret_cast<const unsigned short*>(z);
+        if (bmask) hipLaunchKernelGGL(bn_bwd_reduce_h8_kernel<true>, grid8, dim3(256), 0, s, dyh, bmask, zh, mean, invstd, S1, S2, M, C, slab8);
+        else hipLaunchKernelGGL(bn_bwd_reduce_h8_kernel<false>, grid8, dim3(256), 0, s, dyh, bmask, zh, mean, invstd, S1, S2, M, C, slab8);
+        HN_LAUNCH_CHECK();
+        return 0;
+    }
     const int slab = reduce_slab(M, C);
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)((C + 255) / 256));
     hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, dy, bmask, z, mean, invstd, S1, S2, M, C, C, slab, z_bf16, dy_bf16);
@@ -545,8 +745,29 @@ int hn_launch_affine_act(const float* z, const float* a, const float* b, const f
 
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
-                           int C, int z_bf16, int dy_bf16, hipStream_t s)
+                           int C, int z_bf16, int dy_bf16, double* db, hipStream_t s)
 {
+    // db (optional, zeroed by the caller): column sums of dz, accumulated by the all-bf16 kernel only -- the float32 path
+    // leaves it to a separate hn_launch_col_stats over the float32 dz
+    HN_REQUIRE(!db || (z_bf16 && dy_bf16 && !dz && dz_h && h8_shape(C)), "bn_bwd_apply: db needs the all-bf16 kernel");
+    if (z_bf16 && dy_bf16 && !dz && dz_h && h8_shape(C)) {
+        const int slab8 = h8_slab(M, C);
+        dim3 grid8((unsigned)((M + slab8 - 1) / slab8), (unsigned)((C + 2047) / 2048));
+        const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy);
+        const unsigned short* zh = reinterpret_cast<const unsigned short*>(z);
+        unsigned short* dph = reinterpret_cast<unsigned short*>(dpre);
+        unsigned short* dzh = reinterpret_cast<unsigned short*>(dz_h);
+#define HN_APPLY_H8(MASK, BIAS)                                                                                                       \
+    hipLaunchKernelGGL((bn_bwd_apply_h8_kernel<MASK, BIAS>), grid8, dim3(256), 0, s, dyh, bmask, zh, mean, invstd, gamma, S1, S2, n, dph, \
+                       dzh, db, M, C, slab8)
+        if (bmask && db) HN_APPLY_H8(true, true);
+        else if (bmask) HN_APPLY_H8(true, false);
+        else if (db) HN_APPLY_H8(false, true);
+        else HN_APPLY_H8(false, false);
+#undef HN_APPLY_H8
+        HN_LAUNCH_CHECK();
+        return 0;
+    }
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, bmask, z, mean, invstd, gamma, S1, S2, n, dz,
                        dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4, z_bf16, dy_bf16);
