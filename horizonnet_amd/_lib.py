@@ -36,6 +36,9 @@ SIGNATURES = {
     "hn_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_lstm_bf16_exchange_bytes": (_sz, []),
     "hn_lstm_layer_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "hn_lstm_layer_bf16_train": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "hn_lstm_bwd_bf16_exchange_bytes": (_sz, []),
+    "hn_lstm_layer_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "hn_train_workspace_bytes": (_sz, [_i]),
     "hn_train_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _f, _f, _f, _c.c_uint64, _vp]),
     "hn_set_bn_eval": (_i, [_vp, _c.c_char_p, _i]),

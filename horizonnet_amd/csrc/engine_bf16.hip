@@ -287,6 +287,23 @@ extern "C" int hn_lstm_layer_bf16(const float* gx, const void* whh_fwd_bf16, con
     return hn_launch_lstm_layer_bf16(gx, whh_fwd_bf16, whh_rev_bf16, y, y_bf16, T, B, exchange, sync_ws, (hipStream_t)stream);
 }
 
+// per-stage entries (tests): the training step's forms of that layer -- forward also storing (i, f, g, o, c), and the adjoint
+extern "C" int hn_lstm_layer_bf16_train(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, float* saved, int T,
+                                        int B, void* exchange, void* sync_ws, void* stream)
+{
+    HN_REQUIRE(gx && whh_fwd_bf16 && whh_rev_bf16 && y && saved && exchange && sync_ws, "hn_lstm_layer_bf16_train: null pointer");
+    return hn_launch_lstm_layer_bf16(gx, whh_fwd_bf16, whh_rev_bf16, y, nullptr, T, B, exchange, sync_ws, (hipStream_t)stream, saved);
+}
+
+extern "C" size_t hn_lstm_bwd_bf16_exchange_bytes(void) { return hn_lstm_bwd_bf16_xch_bytes(); }
+
+extern "C" int hn_lstm_layer_bwd_bf16(const float* saved, const float* dy, const void* whhT_fwd_bf16, const void* whhT_rev_bf16, float* dgx,
+                                      int T, int B, void* exchange, void* sync_ws, void* stream)
+{
+    HN_REQUIRE(saved && dy && whhT_fwd_bf16 && whhT_rev_bf16 && dgx && exchange && sync_ws, "hn_lstm_layer_bwd_bf16: null pointer");
+    return hn_launch_lstm_layer_bwd_bf16(saved, dy, whhT_fwd_bf16, whhT_rev_bf16, dgx, T, B, exchange, sync_ws, (hipStream_t)stream);
+}
+
 // per-stage entry point for the parity tests: x / w / res / y are bf16 device buffers (y f32 when out_f32)
 extern "C" int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
                                    const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,

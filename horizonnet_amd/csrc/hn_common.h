@@ -120,5 +120,8 @@ int hn_launch_conv1x1_dual_bf16(const void* t2, const void* w1, const float* sca
                                 int K2, int s2, int Cout, hipStream_t s);
 size_t hn_lstm_bf16_xch_bytes(void);
 int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B, void* xch,
-                              void* sync_ws, hipStream_t s);
+                              void* sync_ws, hipStream_t s, float* save = nullptr);
+size_t hn_lstm_bwd_bf16_xch_bytes(void);
+int hn_launch_lstm_layer_bwd_bf16(const float* saved, const float* dy, const void* whhT_f, const void* whhT_r, float* dgx, int T, int B,
+                                  void* xch, void* sync_ws, hipStream_t s);
 int hn_launch_add_vec(const float* a, const float* b, float* out, long n, hipStream_t s);

@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned bf16_rn(float x)
 __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __restrict__ gx, const u16* __restrict__ whh_f,
                                                               const u16* __restrict__ whh_r, float* __restrict__ y,
                                                               u16* __restrict__ y_h, u64* xch, int T, int B, int b0, int bc,
-                                                              unsigned* sync)
+                                                              unsigned* sync, float* __restrict__ save)
 {
     __shared__ __attribute__((aligned(16))) u16 hs[2][BPG][LH];      // h_{t-1} of the group's two panoramas, by step parity
 
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __res
                 const float h = og * tanhf(c_state[r]);
                 if (r < nvalid) {
                     const size_t o = ((size_t)t * B + b0 + bfirst + r) * 1024 + dir * LH + u0 + col;
+                    if (save) {      // training: post-activation gates + cell state for the adjoint, [t][b][dir][5][512]
+                        float* sv = save + (((size_t)t * B + b0 + bfirst + r) * 2 + dir) * 5 * LH + u0 + col;
+                        sv[0] = ig; sv[LH] = fg; sv[2 * LH] = gg; sv[3 * LH] = og; sv[4 * LH] = c_state[r];
+                    }
                     y[o] = h;
                     if (y_h) y_h[o] = (u16)bf16_rn(h);
                     packed |= bf16_rn(h) << (16 * r);
@@ -168,14 +172,170 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The adjoint of the recurrence in the same shape (train_precision bf16; autograd of nn.LSTM under train.py:273-278):
+//   dh_t = dy_t + W_hh^T dg_{t+1};  dc = dc_rec + dh o (1 - tanh^2 c);  dg_t = gate adjoints;  dc_rec = dc f
+// The recurrence is independent per panorama, so again group = (direction, pair of panoramas), 8 members, member = 64
+// hidden units: it computes the gate adjoints of ITS units (dh of its own units is all that needs) and the W_hh^T product
+// for ITS units' dh -- which needs the dg of ALL 2048 gate rows of the group's two panoramas.  Those travel as 2048
+// {tag, dg(pan 0) | dg(pan 1) << 16} bf16 granules per step (each wave sweeps 512), W_hh^T lives in registers as 64 B
+// fragments per lane (k = gate row), and dg itself is written in float32 for the weight-gradient GEMMs that follow.
+// Replaces 2 launches per time step (lstm_bwd_gates + lstm_bwd_dh: 1024 launches per backward pass) by one per layer.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int GR = 4 * LH;                    // gate rows
+
+__global__ __launch_bounds__(256) void lstm_layer_bwd_bf16_kernel(const float* __restrict__ saved, const float* __restrict__ dy,
+                                                                  const u16* __restrict__ whhT_f, const u16* __restrict__ whhT_r,
+                                                                  float* __restrict__ dgx, u64* xch, int T, int B, int b0, int bc,
+                                                                  unsigned* sync)
+{
+    __shared__ __attribute__((aligned(16))) u16 dgs[2][BPG][GR];      // dg of the previous step, both panoramas, by step parity
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int grp = (bid & 7) | ((bid >> 6) << 3);     // a group's 8 members share an XCD (speed only)
+    const int mem = (bid >> 3) & 7;
+    const int dir = grp & 1;
+    const int pair = grp >> 1;
+    const int bfirst = pair * BPG;
+    if (bfirst >= bc) return;
+    const int nvalid = (bc - bfirst) < BPG ? (bc - bfirst) : BPG;
+    const u16* whhT = dir ? whhT_r : whhT_f;           // [512 units][2048 gate rows]
+    const int col = lane & 15;
+    const int kb = lane >> 4;
+    const int u0 = mem * UPC + wave * 16;
+    const int unit = u0 + col;
+    u64* slots = xch + (size_t)grp * GR;               // [parity][NGRP][GR] granules
+
+    // B fragments of W_hh^T: column = unit, k = gate row ks*32 + kb*8 .. +8
+    u32x4 wf[64];
+    {
+        const u16* wr = whhT + (size_t)unit * GR + kb * 8;
+#pragma unroll
+        for (int ks = 0; ks < 64; ++ks) wf[ks] = *reinterpret_cast<const u32x4*>(wr + ks * 32);
+    }
+
+    const bool gate_lane = lane < 16;
+    float dc_rec[BPG] = {0.f, 0.f};
+    bool failed = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : T - 1 - step;       // each direction's own time order, backwards
+        const int tprev = dir ? t + 1 : t - 1;         // the step that ran BEFORE t in that direction's forward pass
+
+        float sv[BPG][5], cprev[BPG], dyv[BPG];
+        if (gate_lane) {
+#pragma unroll
+            for (int r = 0; r < BPG; ++r) {
+                const int bb = b0 + bfirst + (r < nvalid ? r : 0);
+                const float* sp = saved + (((size_t)t * B + bb) * 2 + dir) * 5 * LH + unit;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sv[r][k] = sp[k * LH];
+                cprev[r] = (tprev >= 0 && tprev < T) ? saved[((((size_t)tprev * B + bb) * 2 + dir) * 5 + 4) * LH + unit] : 0.f;
+                dyv[r] = dy[((size_t)t * B + bb) * 1024 + dir * LH + unit];
+            }
+        }
+
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            const int par = step & 1;
+            {
+                // every wave sweeps a quarter of the group's 2048 granules of step-1 (tag == step), then spreads them into LDS
+                const u64* src = slots + (size_t)((step - 1) & 1) * NGRP * GR + wave * 512;
+                unsigned v[8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const u64 x = __hip_atomic_load(src + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[k] = (unsigned)x;
+                        ok = ok && (unsigned)(x >> 32) == (unsigned)step;
+                    }
+                    if (__all(ok) || failed) break;
+                    if (++spins > SPIN_LIMIT_H) {
+                        __hip_atomic_store(sync + HN_STATUS_WORD, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        failed = true;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    dgs[par][0][wave * 512 + k * 64 + lane] = (u16)(v[k] & 0xffffu);
+                    dgs[par][1][wave * 512 + k * 64 + lane] = (u16)(v[k] >> 16);
+                }
+            }
+            __syncthreads();
+            const u16* arow = &dgs[par][col < BPG ? col : 0][kb * 8];      // A rows >= 2 are dead
+#pragma unroll
+            for (int ks = 0; ks < 64; ++ks) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(arow + ks * 32);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wf[ks]), acc, 0, 0, 0);
+            }
+        }
+
+        if (gate_lane) {
+            unsigned packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int r = 0; r < BPG; ++r) {
+                const float ig = sv[r][0], fg = sv[r][1], gg = sv[r][2], og = sv[r][3];
+                const float dh = dyv[r] + acc[r];
+                const float tc = tanhf(sv[r][4]);
+                const float dc = dc_rec[r] + dh * og * (1.f - tc * tc);
+                float g[4];
+                g[0] = dc * gg * ig * (1.f - ig);
+                g[1] = dc * cprev[r] * fg * (1.f - fg);
+                g[2] = dc * ig * (1.f - gg * gg);
+                g[3] = dh * tc * og * (1.f - og);
+                dc_rec[r] = dc * fg;
+                if (r < nvalid) {
+                    float* gp = dgx + ((size_t)t * B + b0 + bfirst + r) * 4096 + dir * GR + unit;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        gp[k * LH] = g[k];
+                        packed[k] |= bf16_rn(g[k]) << (16 * r);
+                    }
+                }
+            }
+            u64* dst = slots + (size_t)(step & 1) * NGRP * GR + unit;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __hip_atomic_store(dst + k * LH, ((u64)(unsigned)(step + 1) << 32) | packed[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace
+
+size_t hn_lstm_bwd_bf16_xch_bytes(void) { return (size_t)2 * NGRP * GR * sizeof(u64); }
+
+// saved: [T][B][2][5][512] float32 (i, f, g, o, c) of the forward pass; dy: [T*B][1024] gradient of the layer output;
+// whhT_*: bf16 [512][2048] = W_hh transposed; dgx: [T*B][4096] float32 gate pre-activation gradients (out);
+// xch: hn_lstm_bwd_bf16_xch_bytes() of scratch
+int hn_launch_lstm_layer_bwd_bf16(const float* saved, const float* dy, const void* whhT_f, const void* whhT_r, float* dgx, int T, int B,
+                                  void* xch, void* sync_ws, hipStream_t s)
+{
+    HN_REQUIRE(T >= 1 && B >= 1 && T < 0x7fffffff, "lstm bwd bf16: bad T/B");
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int bc = (B - b0) < 32 ? (B - b0) : 32;
+        HN_HIP(hipMemsetAsync(xch, 0, hn_lstm_bwd_bf16_xch_bytes(), s));
+        hipLaunchKernelGGL(lstm_layer_bwd_bf16_kernel, dim3(NGRP * GRP), dim3(256), 0, s, saved, dy, reinterpret_cast<const u16*>(whhT_f),
+                           reinterpret_cast<const u16*>(whhT_r), dgx, reinterpret_cast<u64*>(xch), T, B, b0, bc,
+                           reinterpret_cast<unsigned*>(sync_ws));
+        HN_LAUNCH_CHECK();
+    }
+    return 0;
+}
 
 size_t hn_lstm_bf16_xch_bytes(void) { return (size_t)2 * NGRP * LH * sizeof(u64); }
 
 // gx: [T*B][4096] float32 gate pre-activations (both directions); whh_*: bf16 [2048][512]; y: float32 [T*B][1024];
 // y_h: optional bf16 copy of y (the next layer's GEMM operand); xch: hn_lstm_bf16_xch_bytes() of scratch
+// save: optional [T][B][2][5][512] float32 (i, f, g, o, c) for the training step's adjoint
 int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B, void* xch,
-                              void* sync_ws, hipStream_t s)
+                              void* sync_ws, hipStream_t s, float* save)
 {
     HN_REQUIRE(T >= 1 && B >= 1 && T < 0x7fffffff, "lstm bf16: bad T/B");
     for (int b0 = 0; b0 < B; b0 += 32) {
@@ -183,7 +343,7 @@ int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* wh
         HN_HIP(hipMemsetAsync(xch, 0, hn_lstm_bf16_xch_bytes(), s));       // every tag back to 0 before every launch
         hipLaunchKernelGGL(lstm_layer_bf16_kernel, dim3(NGRP * GRP), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
                            reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), reinterpret_cast<u64*>(xch), T, B, b0,
-                           bc, reinterpret_cast<unsigned*>(sync_ws));
+                           bc, reinterpret_cast<unsigned*>(sync_ws), save);
         HN_LAUNCH_CHECK();
     }
     return 0;

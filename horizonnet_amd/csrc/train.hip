@@ -28,6 +28,7 @@ struct TrainPlan {
     std::vector<Unit> units;
     int blk[4][6], dsu[4], ghc[4];         // unit indices
     size_t xn8, poolh, dzh[2];             // bf16: NHWC4 normalised image, max-pool output, two dz staging buffers
+    size_t lxch;                           // bf16: granule exchange scratch of the persistent LSTM kernels
     size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
     size_t stat_fwd_doubles, stat_bwd_first, stat_bwd_doubles, stat_lstm;   // layout of the statistics arena at `dstat` (doubles)
     size_t gmax;
@@ -113,6 +114,7 @@ TrainPlan make_train_plan(int B)
     for (int i = 0; i < 2; ++i) p.dzh[i] = take(p.gmax / 2);
     const size_t csz[4] = {b * 128 * 256 * 256, b * 64 * 128 * 512, b * 32 * 64 * 1024, b * 16 * 32 * 2048};
     for (int i = 0; i < 4; ++i) p.DC[i] = take(csz[i]);
+    p.lxch = take((hn_lstm_bwd_bf16_xch_bytes() > hn_lstm_bf16_xch_bytes() ? hn_lstm_bwd_bf16_xch_bytes() : hn_lstm_bf16_xch_bytes()) / sizeof(float));
     p.dhrec = take(b * 1024);
     p.dcrec = take(b * 1024);
     p.wsA = take((size_t)1024 * 18432 + 64);      // largest packed weight (ghc3.0) / wgrad scratch
@@ -431,8 +433,19 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     const float pdrop[2] = {p_rnn, p_head};
     for (int l = 0; l < 2; ++l) {
         if ((rc = gemm_rows(lin, 0, c.P + a.wih_off[l], c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
-        if ((rc = hn_launch_lstm_layer(W + pl.gx, c.P + a.whh_off[l][0], c.P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s,
-                                       W + pl.save[l])))
+        if (e->train_bf16) {
+            // bf16 mode: the batch-partitioned persistent kernel of the bf16 forward (W_hh on the bf16 matrix cores, bf16 h
+            // hand-off), also storing the gates for the adjoint; the weights change every step, so they are re-rounded here
+            float* whh_h = W + pl.wsA;                    // [2][2048][512] bf16 (the conv weight scratch is idle by now)
+            for (int d = 0; d < 2; ++d)
+                if ((rc = hn_launch_f32_to_bf16(c.P + a.whh_off[l][d], reinterpret_cast<unsigned short*>(whh_h) + (size_t)d * 2048 * 512,
+                                                (long)2048 * 512, s)))
+                    return rc;
+            if ((rc = hn_launch_lstm_layer_bf16(W + pl.gx, whh_h, reinterpret_cast<unsigned short*>(whh_h) + (size_t)2048 * 512, ybuf[l], nullptr,
+                                                T_COLS, B, W + pl.lxch, W + pl.sync, s, W + pl.save[l])))
+                return rc;
+        } else if ((rc = hn_launch_lstm_layer(W + pl.gx, c.P + a.whh_off[l][0], c.P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s,
+                                              W + pl.save[l])))
             return rc;
         if (pdrop[l] > 0.f) {
             if ((rc = hn_launch_dropout(ybuf[l], ydrop[l], rows * 1024, pdrop[l], seed * 2 + 1 + l, s))) return rc;
@@ -493,6 +506,14 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
         float* whhT = W + pl.wsB;                     // [2][512][2048]: recurrent weights, k-major, for the adjoint GEMV
         if (LIVE && (rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sf), whhT, 2048, 512, s))) return rc;
         if (LIVE && (rc = hn_launch_transpose(c.bound("bi_rnn.weight_hh" + sr), whhT + (size_t)512 * 2048, 2048, 512, s))) return rc;
+        if (e->train_bf16) {
+            // bf16 mode: ONE persistent launch per layer (W_hh^T as bf16 fragments in registers, bf16 dg hand-off)
+            unsigned short* whhT_h = reinterpret_cast<unsigned short*>(whhT + (size_t)2 * 512 * 2048);
+            if (LIVE && (rc = hn_launch_f32_to_bf16(whhT, whhT_h, (long)2 * 512 * 2048, s))) return rc;
+            if (LIVE && (rc = hn_launch_lstm_layer_bwd_bf16(W + pl.save[l], dy, whhT_h, whhT_h + (size_t)512 * 2048, dgx, T_COLS, B,
+                                                            W + pl.lxch, W + pl.sync, s)))
+                return rc;
+        } else
         for (int step = 0; step < T_COLS; ++step) {
             if (LIVE && (rc = hn_launch_lstm_bwd_gates(W + pl.save[l], dy, W + pl.dhrec, W + pl.dcrec, dgx, T_COLS, B, step, s))) return rc;
             const int tf = T_COLS - 1 - step, tr = step;

@@ -127,6 +127,17 @@ size_t hn_lstm_bf16_exchange_bytes(void);
 int hn_lstm_layer_bf16(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, void* y_bf16, int T, int B,
                        void* exchange, void* sync_ws, void* stream);
 
+/* per-stage (tests): the same layer as the bf16 training step runs it (train_precision "bf16"; autograd of nn.LSTM under
+ * reference train.py:273-278).  Forward: as hn_lstm_layer_bf16, also storing saved [T][B][2][5][512] float32 = post-activation
+ * (i, f, g, o) and the cell state c per direction.  Adjoint: one persistent launch, dy [T*B][1024] float32 gradient of the
+ * layer output, whhT_*_bf16 [512][2048] bf16 = W_hh transposed, dgx [T*B][4096] float32 gradient of the gate
+ * pre-activations (out); exchange: hn_lstm_bwd_bf16_exchange_bytes() of scratch. */
+int hn_lstm_layer_bf16_train(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, float* saved, int T, int B,
+                             void* exchange, void* sync_ws, void* stream);
+size_t hn_lstm_bwd_bf16_exchange_bytes(void);
+int hn_lstm_layer_bwd_bf16(const float* saved, const float* dy, const void* whhT_fwd_bf16, const void* whhT_rev_bf16, float* dgx, int T,
+                           int B, void* exchange, void* sync_ws, void* stream);
+
 /* ---- training step: autograd of net(x) at reference train.py:44-58,272-281 (float32) ---------- */
 
 /* Workspace bytes for a training step at batch B (keeps every conv input / pre-BN / post-activation

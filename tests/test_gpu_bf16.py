@@ -167,6 +167,80 @@ def test_lstm_layer_bf16_batch_sizes(B):
     assert torch.equal(first, y)          # deterministic, independent of what the previous launch left in the exchange buffer
 
 
+@pytest.mark.parametrize("B", [1, 3, 32, 34])
+def test_lstm_layer_bf16_training_forms(B):
+    """The bf16 training step's LSTM layer: forward with the gates stored, and the persistent adjoint (one launch instead
+    of 512: W_hh^T in registers, bf16 dg hand-off), against a float64 restatement in which exactly the quantities that
+    re-enter the matrix cores (h, dg) are rounded to bf16.  The adjoint is fed the ENGINE's stored gates, so the two
+    checks are independent."""
+    from hiputil import P, lib, sp
+    L = lib()
+    T = 256
+    gen = torch.Generator().manual_seed(300 + B)
+    gx = (torch.rand(T * B, 4096, generator=gen) - 0.5) * 2.0
+    dy = (torch.rand(T * B, 1024, generator=gen) - 0.5) * 1e-2
+    whh = [((torch.rand(2048, 512, generator=gen) - 0.5) * 0.12).to(torch.bfloat16) for _ in range(2)]
+    r16 = lambda v: v.float().to(torch.bfloat16).double()      # noqa: E731
+    g3 = gx.view(T, B, 4096).double()
+    want_y = torch.zeros(T, B, 1024, dtype=torch.float64)
+    want_sv = torch.zeros(T, B, 2, 5, 512, dtype=torch.float64)
+    for d in range(2):
+        w = whh[d].double()
+        h = torch.zeros(B, 512, dtype=torch.float64)
+        c = torch.zeros(B, 512, dtype=torch.float64)
+        for stp in range(T):
+            t = T - 1 - stp if d else stp
+            i_, f_, gg, o_ = (g3[t, :, d * 2048:(d + 1) * 2048] + r16(h) @ w.t()).chunk(4, dim=1)
+            i_, f_, gg, o_ = torch.sigmoid(i_), torch.sigmoid(f_), torch.tanh(gg), torch.sigmoid(o_)
+            c = f_ * c + i_ * gg
+            h = o_ * torch.tanh(c)
+            want_y[t, :, d * 512:(d + 1) * 512] = h
+            want_sv[t, :, d] = torch.stack([i_, f_, gg, o_, c], 1)
+    gxd, dyd = gx.to(DEV), dy.to(DEV)
+    wd = [w.to(DEV).contiguous() for w in whh]
+    wtd = [w.t().contiguous().to(DEV) for w in whh]
+    y = torch.full((T * B, 1024), float("nan"), device=DEV)
+    sv = torch.full((T, B, 2, 5, 512), float("nan"), device=DEV)
+    dgx = torch.full((T * B, 4096), float("nan"), device=DEV)
+    xch = torch.empty(max(L.hn_lstm_bf16_exchange_bytes(), L.hn_lstm_bwd_bf16_exchange_bytes()), dtype=torch.uint8, device=DEV)
+    sync = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    _lib.check(L.hn_lstm_layer_bf16_train(P(gxd), P(wd[0]), P(wd[1]), P(y), P(sv), T, B, P(xch), P(sync), sp()), "hn_lstm_layer_bf16_train")
+    torch.cuda.synchronize()
+    assert int(sync.view(torch.int32)[512]) == 0
+    assert report("bf16 train LSTM y B=%d" % B, y.view(T, B, 1024).cpu().numpy(), want_y.numpy(), 2e-3)
+    assert report("bf16 train LSTM saved gates B=%d" % B, sv.cpu().numpy(), want_sv.numpy(), 4e-3)
+
+    # adjoint on the engine's own stored gates
+    S = sv.cpu().double()
+    d3 = dy.view(T, B, 1024).double()
+    want_dg = torch.zeros(T, B, 4096, dtype=torch.float64)
+    for d in range(2):
+        w = whh[d].double()
+        dh_rec = torch.zeros(B, 512, dtype=torch.float64)
+        dc_rec = torch.zeros(B, 512, dtype=torch.float64)
+        for stp in range(T):
+            t = stp if d else T - 1 - stp
+            tprev = t + 1 if d else t - 1
+            i_, f_, gg, o_, c = (S[t, :, d, k] for k in range(5))
+            cprev = S[tprev, :, d, 4] if 0 <= tprev < T else torch.zeros(B, 512, dtype=torch.float64)
+            dh = d3[t, :, d * 512:(d + 1) * 512] + dh_rec
+            tc = torch.tanh(c)
+            dc = dc_rec + dh * o_ * (1 - tc * tc)
+            dg = torch.cat([dc * gg * i_ * (1 - i_), dc * cprev * f_ * (1 - f_), dc * i_ * (1 - gg * gg), dh * tc * o_ * (1 - o_)], 1)
+            want_dg[t, :, d * 2048:(d + 1) * 2048] = dg
+            dc_rec = dc * f_
+            dh_rec = r16(dg) @ w
+    for rep in range(2):
+        _lib.check(L.hn_lstm_layer_bwd_bf16(P(sv), P(dyd), P(wtd[0]), P(wtd[1]), P(dgx), T, B, P(xch), P(sync), sp()), "hn_lstm_layer_bwd_bf16")
+        torch.cuda.synchronize()
+        assert int(sync.view(torch.int32)[512]) == 0, "bf16 LSTM adjoint reported a spin time-out"
+        got = dgx.view(T, B, 4096).cpu().numpy()
+        assert report("bf16 LSTM adjoint dgx B=%d (run %d)" % (B, rep), got, want_dg.numpy(), 4e-3 * float(want_dg.abs().max()))
+        if rep == 0:
+            first = dgx.clone()
+    assert torch.equal(first, dgx)
+
+
 def test_forward_bf16_batch32_consistency():
     net = _net(0, "random")
     base = torch.rand(4, 3, 512, 1024, generator=torch.Generator().manual_seed(4321))
