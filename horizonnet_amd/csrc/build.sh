@@ -3,12 +3,12 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libhorizonnet_hip.so
-SRCS="engine.hip engine_bf16.hip train.hip conv_igemm_f32.hip conv_wgrad_f32.hip conv_wgrad_bf16.hip conv_igemm_bf16.hip elementwise.hip train_ops.hip lstm.hip lstm_bf16.hip panostretch.hip augment.hip peaks.hip"
+SRCS="engine.hip engine_bf16.hip train.hip conv_igemm_f32.hip conv_wgrad_f32.hip conv_wgrad_bf16.hip conv_igemm_bf16.hip elementwise.hip train_ops.hip lstm.hip lstm_bf16.hip panostretch.hip augment.hip peaks.hip multi_job.hip"
 mkdir -p ../../build/obj
 OBJS=""
 for f in $SRCS; do
   o=../../build/obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ hn_common.h -nt "$o" ] || [ engine_internal.h -nt "$o" ] || [ ../../include/horizonnet_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ hn_common.h -nt "$o" ] || [ engine_internal.h -nt "$o" ] || [ multi_job.h -nt "$o" ] || [ ../../include/horizonnet_hip.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -c "$f" -o "$o"
   fi
   OBJS="$OBJS $o"

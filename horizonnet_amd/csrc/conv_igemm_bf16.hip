@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dual_bf16_kernel(DualArgsH p)
 // and cuts the second to 0.75 KiB, with one workgroup per CU (128 KiB of LDS for the two stages) whose second wave per
 // SIMD covers the other's barrier / fragment-read gaps.  Loader, swizzle, OOB handling and k order are the 4-wave
 // kernel's (same results bit for bit: the accumulation order over k does not depend on the tile shape).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32>
+// STATS: train-mode BatchNorm statistics of the stored rows (per-channel sum / sum of squares -> one f64 atomic per channel and
+// workgroup), as in the 4-wave kernel's epilogue; a separate instantiation so that the inference kernel's registers stay as they are.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
 {
     static_assert(WAVES_M * WAVES_N == 8, "8 waves per workgroup");
@@ -785,6 +787,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
     const f32x4 sf1 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol + 4);
     const bool has_res = p.res != nullptr;
+    f32x4 st1a = {0.f, 0.f, 0.f, 0.f}, st1b = st1a, st2a = st1a, st2b = st1a;     // STATS: sums of this thread's 8 columns
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         u32x4 rres[NPASS];
@@ -825,6 +828,10 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
                 for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
             }
             if (m < p.M) {
+                if (STATS) {
+                    st1a += v0; st1b += v1;
+                    st2a += v0 * v0; st2b += v1 * v1;
+                }
                 if (OUT_F32) {
                     float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n0 + ccol;
                     *reinterpret_cast<f32x4*>(yo) = v0;
@@ -838,13 +845,33 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
             }
         }
     }
+    if (STATS) {             // per-channel sums of the stored tile: threads of one column group -> LDS -> one f64 atomic per channel
+        static_assert(2 * RPP * BN * 4 <= 2 * STAGE_BYTES, "statistics scratch must fit in the staging LDS");
+        __syncthreads();
+        float* red = cs;                         // [2][RPP][BN]
+        *reinterpret_cast<f32x4*>(red + crow * BN + ccol) = st1a;
+        *reinterpret_cast<f32x4*>(red + crow * BN + ccol + 4) = st1b;
+        *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol) = st2a;
+        *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol + 4) = st2b;
+        __syncthreads();
+        if (tid < BN) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) {
+                a1 += red[r * BN + tid];
+                a2 += red[(RPP + r) * BN + tid];
+            }
+            atomicAdd(p.stat_sum + n0 + tid, (double)a1);
+            atomicAdd(p.stat_sq + n0 + tid, (double)a2);
+        }
+    }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false>
 int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
 {
     const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32>;
+    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32, STATS>;
     static bool attr_done[64] = {};   // per instantiation, per device
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));
@@ -868,8 +895,16 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     const char* env = getenv("HN_BF16_W8");              // read per call: tools/conv_sweep.py flips it between launches
     const int force = env ? atoi(env) : -1;
     *taken = true;
-    if (force == 0 || a.stat_sum != nullptr) { *taken = false; return 0; }
+    if (force == 0) { *taken = false; return 0; }
     const long M = a.M;
+    if (a.stat_sum != nullptr) {
+        // train-mode forward (batch statistics in the epilogue): the 256x256 tile under the same >= 224-workgroup rule, bf16 z only
+        static const char* tenv = getenv("HN_BF16_W8_TRAIN");
+        const long t = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
+        if (!OUT_F32 && !(tenv && atoi(tenv) == 0) && a.res == nullptr && t >= 224) return launch_cfg_w8<256, 256, 2, 4, false, true>(a, s);
+        *taken = false;
+        return 0;
+    }
     const long t256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
     const long t128x256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 128) * (Cout / 256) : 0;
     const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
@@ -1175,7 +1210,8 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
 }
 
 // Data gradient of a forward conv on the bf16 matrix cores (see hn_launch_conv_dgrad in conv_igemm_f32.hip):
-// dz_h: bf16 [B][Ho][Wo][Cout]; w_oihw: the float32 master weights (re-packed per class into w_scratch as bf16);
+// dz_h: bf16 [B][Ho][Wo][Cout]; w_oihw: the float32 master weights (re-packed per class into w_scratch as bf16), or NULL when
+// w_scratch already holds the class packings (the training step: packed once per optimiser step by hn_pack_weights_bf16);
 // add (optional) and dx are float32, or -- grad_bf16 -- both bf16 (train.hip keeps the gradients between conv units in bf16).
 // Needs Cout %% 64 == 0 (one K chunk = 64 bf16 channels of one tap).
 int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
@@ -1204,7 +1240,7 @@ int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* 
             a.M = d.B * a.cHo * a.cWo;
             a.K = a.ntdh * a.ntdw * d.Cout;
             a.nk = a.K / BKE;
-            if (a.K > 0) {
+            if (a.K > 0 && w_oihw != nullptr) {       // (null: w_scratch already holds the class packings, hn_pack_weights_bf16)
                 const long total = (long)d.Cin * a.K;
                 hipLaunchKernelGGL(pack_dgrad_class_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, w_oihw, wp, d.Cout, d.Cin, d.KH,
                                    d.KW, a.tdh[0], a.tdh[1], a.tdh[2], a.ntdh, a.tdw[0], a.tdw[1], a.tdw[2], a.ntdw);

@@ -243,11 +243,11 @@ int launch_wgrad_h(WgradArgsH a, hipStream_t s)
 
 }  // namespace
 
-// x_h, dz_h: NHWC bf16; dw_packed: hn_packed_conv_weight_floats() floats, zeroed here and accumulated by the kernel.
+// x_h, dz_h: NHWC bf16; dw_packed: hn_packed_conv_weight_floats() floats, zeroed here (unless `prezeroed`) and accumulated by the kernel.
 // Needs Cout %% 64 == 0 and Cin %% 64 == 0 (every conv of the network except the 7x7 stem and ghc0.3, which keep the f32
 // kernel).
 int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                              int sh, int sw, hipStream_t s)
+                              int sh, int sw, hipStream_t s, int prezeroed)
 {
     HN_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad bf16: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
     WgradArgsH a;
@@ -260,7 +260,7 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     a.mchunk = 0;
     HN_REQUIRE((double)B * Hi * Wi * Cin * 2.0 < 2147483648.0 && (double)a.M * Cout * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
-    HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
+    if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
     if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad_h<128, 128>(a, s);
     if (Cout % 128 == 0) return launch_wgrad_h<128, 64>(a, s);
     if (Cin % 128 == 0) return launch_wgrad_h<64, 128>(a, s);

@@ -296,9 +296,9 @@ int launch_wgrad(WgradArgs a, hipStream_t s)
 
 }  // namespace
 
-// dw_packed must hold hn_packed_conv_weight_floats() floats; it is zeroed here and accumulated by the kernel.
+// dw_packed must hold hn_packed_conv_weight_floats() floats; it is zeroed here (unless `prezeroed`) and accumulated by the kernel.
 int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s)
+                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed)
 {
     WgradArgs a;
     a.x = x; a.dz = dz; a.dw = dw_packed;
@@ -313,12 +313,12 @@ int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int 
         HN_REQUIRE(KH == 7 && KW == 7 && Cout == 64, "wgrad: stem expects 7x7, Cout=64");
         a.Cin = 4;
         a.K = 8 * 32;                       // scratch layout [64][8 dh (7 used)][8 dw (7 used)][4 c (3 used)]; k' tiles are 64 wide
-        HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
+        if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
         return launch_wgrad<64, 64, true>(a, s);
     }
     HN_REQUIRE(Cin % 64 == 0 && Cout % 32 == 0, "wgrad: Cin=%d must be a multiple of 64, Cout=%d of 32", Cin, Cout);
     a.K = KH * KW * Cin;
-    HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
+    if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
     if (Cout % 64 != 0) return launch_wgrad<64, 64, false>(a, s);
     if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad<128, 128, false>(a, s);
     if (Cout % 128 == 0) return launch_wgrad<128, 64, false>(a, s);

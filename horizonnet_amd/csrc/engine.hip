@@ -194,6 +194,10 @@ extern "C" int hn_destroy(hn_engine* e)
             if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
         }
         if (e->branch_stream) (void)hipStreamDestroy(e->branch_stream);
+        DeviceGuard guard(e->device);
+        e->jt_pack.release();
+        e->jt_pack_h.release();
+        for (JobTable& t : e->jt_bwd) t.release();
     }
     delete e;
     return 0;
@@ -278,29 +282,31 @@ extern "C" int hn_pack_weights(hn_engine* e, void* packed, size_t packed_bytes, 
     hipStream_t s = (hipStream_t)stream;
     float* P = reinterpret_cast<float*>(packed);
     auto get = [&](const std::string& k) { return reinterpret_cast<const float*>(e->bound.at(k)); };
+    // one table-driven launch for all 69 conv packings + BatchNorm folds + the LSTM / head copies (multi_job.h); it used to be
+    // ~150 launches, repeated after every optimiser step of a training loop
+    std::vector<MJob> jobs;
+    jobs.reserve(2 * a.convs.size() + 20);
     for (const auto& c : a.convs) {
-        if (int rc = hn_launch_pack_conv(get(c.wkey + ".weight"), P + c.w_off, c.cout, c.cin, c.k, c.k, s)) return rc;
-        if (int rc = hn_launch_fold_bn(get(c.bnkey + ".weight"), get(c.bnkey + ".bias"), get(c.bnkey + ".running_mean"),
-                                       get(c.bnkey + ".running_var"), c.has_bias ? get(c.wkey + ".bias") : nullptr,
-                                       P + c.scale_off, P + c.shift_off, c.cout, s))
-            return rc;
+        jobs.push_back(mj_pack_f32(get(c.wkey + ".weight"), P + c.w_off, c.cout, c.cin, c.k, c.k));
+        jobs.push_back(mj_fold_bn(get(c.bnkey + ".weight"), get(c.bnkey + ".bias"), get(c.bnkey + ".running_mean"),
+                                  get(c.bnkey + ".running_var"), c.has_bias ? get(c.wkey + ".bias") : nullptr, P + c.scale_off,
+                                  P + c.shift_off, c.cout));
     }
     for (int l = 0; l < 2; ++l) {
         for (int d = 0; d < 2; ++d) {
             const std::string suf = "_l" + std::to_string(l) + (d ? "_reverse" : "");
-            HN_HIP(hipMemcpyAsync(P + a.wih_off[l] + (size_t)d * 2048 * 1024, get("bi_rnn.weight_ih" + suf),
-                                  (size_t)2048 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
-            HN_HIP(hipMemcpyAsync(P + a.whh_off[l][d], get("bi_rnn.weight_hh" + suf), (size_t)2048 * 512 * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s));
-            if (int rc = hn_launch_add_vec(get("bi_rnn.bias_ih" + suf), get("bi_rnn.bias_hh" + suf),
-                                           P + a.lbias_off[l] + d * 2048, 2048, s))
-                return rc;
+            jobs.push_back(mj_make(MJ_COPY_F32, get("bi_rnn.weight_ih" + suf), P + a.wih_off[l] + (size_t)d * 2048 * 1024, (long long)2048 * 1024));
+            jobs.push_back(mj_make(MJ_COPY_F32, get("bi_rnn.weight_hh" + suf), P + a.whh_off[l][d], (long long)2048 * 512));
+            MJob add = mj_make(MJ_ADD_VEC, get("bi_rnn.bias_ih" + suf), P + a.lbias_off[l] + d * 2048, 2048);
+            add.aux[0] = get("bi_rnn.bias_hh" + suf);
+            jobs.push_back(add);
         }
     }
     // ones / zeros vectors: scale of the LSTM input-projection "conv" (no BN there)
-    if (int rc = hn_launch_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, P + a.ones_off, P + a.zeros_off, 4096, s)) return rc;
-    HN_HIP(hipMemcpyAsync(P + a.linw_off, get("linear.weight"), 12 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HN_HIP(hipMemcpyAsync(P + a.linb_off, get("linear.bias"), 12 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    jobs.push_back(mj_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, P + a.ones_off, P + a.zeros_off, 4096));
+    jobs.push_back(mj_make(MJ_COPY_F32, get("linear.weight"), P + a.linw_off, 12 * 1024));
+    jobs.push_back(mj_make(MJ_COPY_F32, get("linear.bias"), P + a.linb_off, 12));
+    if (int rc = e->jt_pack.run(jobs, s)) return rc;
     e->packed = P;
     return 0;
 }

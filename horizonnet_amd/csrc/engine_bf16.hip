@@ -12,6 +12,7 @@ typedef unsigned short u16;
 
 struct HOff {
     std::vector<size_t> conv;      // element offsets of the packed bf16 conv weights, arch().convs order
+    std::vector<size_t> dgrad;     // ... of the per-class data-gradient packings [Cin][taps of the class][Cout] ((size_t)-1: none)
     size_t wih[2];
     size_t whh[2][2];              // recurrent weights [layer][direction], bf16 [2048][512] (lstm_bf16.hip)
     size_t total;                  // elements
@@ -27,6 +28,9 @@ const HOff& hoff()
         for (int l = 0; l < 2; ++l) h.wih[l] = take((size_t)4096 * 1024);
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < 2; ++d) h.whh[l][d] = take((size_t)2048 * 512);
+        // data-gradient packings (training): the classes of one conv partition its taps, so together they are one weight tensor
+        for (const auto& c : arch().convs)
+            h.dgrad.push_back(c.k != 7 && c.cout % 64 == 0 && c.cin % 32 == 0 ? take((size_t)c.cout * c.k * c.k * c.cin) : (size_t)-1);
         h.total = off;
         return h;
     }();
@@ -36,6 +40,7 @@ const HOff& hoff()
 }  // namespace
 
 size_t hn_bf16_conv_offset(int ci) { return hoff().conv[ci]; }
+size_t hn_bf16_dgrad_offset(int ci) { return hoff().dgrad[ci]; }
 
 namespace {
 
@@ -119,18 +124,43 @@ extern "C" int hn_pack_weights_bf16(hn_engine* e, void* packed_h, size_t bytes, 
     const Arch& a = arch();
     const HOff& h = hoff();
     u16* H = reinterpret_cast<u16*>(packed_h);
-    int rc;
+    // one table-driven launch (multi_job.h): the forward packings, the LSTM / input-GEMM weights, and the per-class
+    // data-gradient packings the bf16 training step's backward pass reads (they used to be re-packed inside every backward
+    // pass, ~90 launches; as weights they only change with the optimiser step that also triggers this call)
+    std::vector<MJob> jobs;
+    jobs.reserve(3 * a.convs.size() + 8);
     for (size_t i = 0; i < a.convs.size(); ++i) {
         const ConvLayer& c = a.convs[i];
         auto it = e->bound.find(c.wkey + ".weight");
         HN_REQUIRE(it != e->bound.end(), "hn_pack_weights_bf16: '%s.weight' was never bound", c.wkey.c_str());
-        if ((rc = hn_launch_pack_conv_bf16(reinterpret_cast<const float*>(it->second), H + h.conv[i], c.cout, c.cin, c.k, c.k, s))) return rc;
+        const float* w = reinterpret_cast<const float*>(it->second);
+        jobs.push_back(mj_pack_bf16(w, H + h.conv[i], c.cout, c.cin, c.k, c.k));
+        if (h.dgrad[i] == (size_t)-1) continue;
+        int sh = 1, sw = 1;
+        hn_conv_strides((int)i, &sh, &sw);
+        u16* wp = H + h.dgrad[i];
+        const int ph = c.k / 2, pw = c.k / 2;
+        for (int ca = 0; ca < sh; ++ca) {
+            for (int cb = 0; cb < sw; ++cb) {        // same class order and tap lists as hn_launch_conv_dgrad_bf16
+                int tdh[3] = {0, 0, 0}, tdw[3] = {0, 0, 0}, ntdh = 0, ntdw = 0;
+                for (int t = 0; t < c.k; ++t) if ((ca + ph - t) % sh == 0) tdh[ntdh++] = t;
+                for (int t = 0; t < c.k; ++t) if ((cb + pw - t) % sw == 0) tdw[ntdw++] = t;
+                const long long total = (long long)c.cin * ntdh * ntdw * c.cout;
+                if (total == 0) continue;
+                MJob j = mj_make(MJ_PACK_DGRAD_BF16, w, wp, total);
+                j.p[0] = c.cout; j.p[1] = c.cin; j.p[2] = c.k; j.p[3] = c.k;
+                j.p[4] = tdh[0]; j.p[5] = tdh[1]; j.p[6] = tdh[2]; j.p[7] = ntdh;
+                j.p[8] = tdw[0]; j.p[9] = tdw[1]; j.p[10] = tdw[2]; j.p[11] = ntdw;
+                jobs.push_back(j);
+                wp += total;
+            }
+        }
     }
     for (int l = 0; l < 2; ++l) {
-        if ((rc = hn_launch_f32_to_bf16(e->packed + a.wih_off[l], H + h.wih[l], (long)4096 * 1024, s))) return rc;
-        for (int d = 0; d < 2; ++d)
-            if ((rc = hn_launch_f32_to_bf16(e->packed + a.whh_off[l][d], H + h.whh[l][d], (long)2048 * 512, s))) return rc;
+        jobs.push_back(mj_make(MJ_F32_TO_BF16, e->packed + a.wih_off[l], H + h.wih[l], (long long)4096 * 1024));
+        for (int d = 0; d < 2; ++d) jobs.push_back(mj_make(MJ_F32_TO_BF16, e->packed + a.whh_off[l][d], H + h.whh[l][d], (long long)2048 * 512));
     }
+    if (int rc = e->jt_pack_h.run(jobs, s)) return rc;
     e->packed_h = packed_h;
     return 0;
 }

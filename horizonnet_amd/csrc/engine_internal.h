@@ -2,6 +2,7 @@
 #pragma once
 #include "hn_common.h"
 #include "../../include/horizonnet_hip.h"
+#include "multi_job.h"
 
 #include <string>
 #include <unordered_map>
@@ -84,6 +85,9 @@ struct hn_engine {
     int debug_unit2 = -1;                // second tap (hn_train_debug_set2): lets a test read two units of the SAME backward pass
     float* debug_dy2 = nullptr;
     float* debug_dz2 = nullptr;
+    // engine-owned job tables of the batched small kernels (multi_job.h): weight packing (f32 / bf16 + data-gradient classes)
+    // and, per gradient-completion segment of the backward pass, the deferred gradient un-packs / double -> float copies
+    JobTable jt_pack, jt_pack_h, jt_bwd[HN_GRAD_SEGMENTS];
     std::vector<ProfEntry> prof;         // entries of the last profiled hn_forward
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -118,3 +122,8 @@ struct ProfScope {
 
 // element offset of conv `ci`'s packed bf16 weights inside the hn_pack_weights_bf16 buffer (engine_bf16.hip)
 size_t hn_bf16_conv_offset(int ci);
+// ... and of its per-class data-gradient packing (classes in (row parity, column parity) order, as hn_launch_conv_dgrad_bf16
+// walks them); (size_t)-1 for convs without a bf16 data gradient (the stem, Cout % 64 != 0)
+size_t hn_bf16_dgrad_offset(int ci);
+// strides of conv `ci` inside the network (train.hip's plan: the architecture fixes them)
+void hn_conv_strides(int ci, int* sh, int* sw);

@@ -77,6 +77,10 @@ int hn_launch_bn_eval_affine(const float* gamma, const float* beta, const float*
                               float* b, float* save_mean, float* save_invstd, int C, hipStream_t s);
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
                          long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s);
+int hn_launch_affine_act_bn(const float* z, const double* sum, const double* sumsq, double n, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float* a, float* b, float* save_mean,
+                            float* save_invstd, const float* res, float* y, unsigned char* bmask, void* y_h, long M, int C, int relu,
+                            int z_bf16, int res_bf16, hipStream_t s);
 int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const double* S1, const double* S2, double n, float* dz, float* dpre, void* dz_h, long M,
                            int C, int z_bf16, int dy_bf16, double* db, hipStream_t s);
@@ -98,14 +102,14 @@ int hn_launch_pack_conv(const float* w, float* out, int Cout, int Cin, int KH, i
 int hn_launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                       float* scale, float* shift, int C, hipStream_t s);
 int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s);
+                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed = 0);
 int hn_launch_unpack_conv(const float* wp, float* w_oihw, int Cout, int Cin, int KH, int KW, int packed_rows, hipStream_t s);
 int hn_launch_pack_conv_dgrad(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 // bf16 family (conv_igemm_bf16.hip): buffers are bf16 unless noted
 int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s);
 int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                              int sh, int sw, hipStream_t s);
+                              int sh, int sw, hipStream_t s, int prezeroed = 0);
 int hn_launch_conv_dgrad_bf16(const ConvDesc& fwd, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
                               const float* ones, const float* zeros, hipStream_t s, int grad_bf16 = 0);
 int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);

@@ -21,6 +21,7 @@ struct Unit {
     size_t xh, yh;                 // float offsets of the bf16 copies of the input / of y (train_precision bf16)
     int keep_y32;                  // bf16 mode: 1 = a float32 consumer of y exists (max-pool, up-sampling, an f32 weight-gradient fallback)
     size_t sf, sb;                 // this unit's slots in the statistics arena (doubles): forward [sum | sumsq], backward [S1 | S2 | dbias]
+    size_t wg;                     // float offset of this unit's packed weight-gradient scratch (un-packed in one batch per segment)
     long M;
 };
 
@@ -32,6 +33,7 @@ struct TrainPlan {
     size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
     size_t stat_fwd_doubles, stat_bwd_first, stat_bwd_doubles, stat_lstm;   // layout of the statistics arena at `dstat` (doubles)
     size_t gmax;
+    size_t wg_first, wg_floats;            // the units' weight-gradient scratches: one contiguous range (one memset per backward pass)
 };
 
 const int kBlocks[4] = {3, 4, 6, 3};
@@ -99,6 +101,12 @@ TrainPlan make_train_plan(int B)
             gh /= 2;
         }
     }
+    p.wg_first = off;
+    for (Unit& u : p.units) {
+        const ConvLayer& c = a.convs[u.ci];
+        u.wg = take(u.stem ? (size_t)c.cout * 8 * 32 : (size_t)c.cout * c.k * c.k * c.cin);
+    }
+    p.wg_floats = off - p.wg_first;
     const size_t rows = (size_t)T_COLS * b;
     p.seq = take(rows * 1024);
     p.gx = take(rows * 4096);
@@ -139,6 +147,7 @@ struct Ctx {
     float* grads;          // flat gradient buffer (may be null in forward)
     hipStream_t s;
     int B;
+    std::vector<MJob>* jobs;   // backward: deferred gradient un-packs / double -> float copies of the running segment (null: launch at once)
     bool gh() const { return e->train_bf16 != 0; }      // bf16 mode: gradients BETWEEN conv units (dy, identity gradients) live in bf16
     bool bn_eval(const Unit& u) const { return (size_t)u.ci < e->bn_eval.size() && e->bn_eval[u.ci] != 0; }
     const float* bound(const std::string& k) const { return reinterpret_cast<const float*>(e->bound.at(k)); }
@@ -181,18 +190,19 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + u.sf;
     float* st = c.W + u.st;
     int rc;
-    if (c.bn_eval(u)) {       // frozen block (train.py:245-256): running statistics, untouched
-        if ((rc = hn_launch_bn_eval_affine(c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"), c.bound(cl.bnkey + ".running_mean"),
-                                           c.bound(cl.bnkey + ".running_var"), st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
-            return rc;
-    } else if ((rc = hn_launch_bn_finalize(ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
-                                           c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
-                                           st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
-        return rc;
     // bf16 mode: the float32 y is written only where a float32 consumer exists (u.keep_y32): 4 of the pass's bytes per element
     float* y32 = (c.e->train_bf16 && !u.keep_y32) ? nullptr : c.W + u.y;
-    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, y32, reinterpret_cast<unsigned char*>(c.W + u.mk),
-                                c.e->train_bf16 ? c.W + u.yh : nullptr, u.M, C, relu, c.e->train_bf16, res_bf16, c.s);
+    void* yh = c.e->train_bf16 ? c.W + u.yh : nullptr;
+    unsigned char* mk = reinterpret_cast<unsigned char*>(c.W + u.mk);
+    if (!c.bn_eval(u))        // statistics -> affine (+ running-stat update) inside the element pass's launch
+        return hn_launch_affine_act_bn(c.W + u.z, ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
+                                       c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
+                                       st + 2 * C, st + 3 * C, st, st + C, res, y32, mk, yh, u.M, C, relu, c.e->train_bf16, res_bf16, c.s);
+    // frozen block (train.py:245-256): running statistics, untouched
+    if ((rc = hn_launch_bn_eval_affine(c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"), c.bound(cl.bnkey + ".running_mean"),
+                                       c.bound(cl.bnkey + ".running_var"), st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
+        return rc;
+    return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, y32, mk, yh, u.M, C, relu, c.e->train_bf16, res_bf16, c.s);
 }
 
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
@@ -212,9 +222,18 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
     if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, dy_bf16, c.s))) return rc;
-    if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
-    if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
-    // eval-mode BatchNorm: mean / invstd are constants, so dz = gamma * invstd * g -- the batch-statistics formula with both sums zero
+    // S2 / S1 are the BatchNorm weight / bias gradients: double -> float into the flat gradient buffer, deferred to the
+    // segment's one batched launch (the sums stay untouched until then) ...
+    const bool defer = c.jobs != nullptr && !c.bn_eval(u);
+    if (defer) {
+        c.jobs->push_back(mj_make(MJ_D2F, ds + C, c.grad(cl.bnkey + ".weight"), C));
+        c.jobs->push_back(mj_make(MJ_D2F, ds, c.grad(cl.bnkey + ".bias"), C));
+    } else {
+        if ((rc = hn_launch_d2f(ds + C, c.grad(cl.bnkey + ".weight"), C, c.s))) return rc;
+        if ((rc = hn_launch_d2f(ds, c.grad(cl.bnkey + ".bias"), C, c.s))) return rc;
+    }
+    // ... except under an eval-mode BatchNorm, whose sums are cleared right away: mean / invstd are constants there, so
+    // dz = gamma * invstd * g -- the batch-statistics formula with both sums zero
     if (c.bn_eval(u)) HN_HIP(hipMemsetAsync(ds, 0, 2 * (size_t)C * sizeof(double), c.s));
     // bf16 mode: when both GEMMs of this unit read the bf16 copy and nothing else needs the float32 dz (no conv bias, no
     // debug tap), it is not written at all (4 of the pass's ~16 bytes per element)
@@ -245,16 +264,23 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     }
     if (cl.has_bias) {
         if (!fused_db && (rc = hn_launch_col_stats(dz, db, nullptr, u.M, C, C, c.s))) return rc;
-        if ((rc = hn_launch_d2f(db, c.grad(cl.wkey + ".bias"), C, c.s))) return rc;
+        if (c.jobs) c.jobs->push_back(mj_make(MJ_D2F, db, c.grad(cl.wkey + ".bias"), C));
+        else if ((rc = hn_launch_d2f(db, c.grad(cl.wkey + ".bias"), C, c.s))) return rc;
     }
-    // weight gradient (packed layout) -> OIHW
-    float* scratch = c.W + c.pl.wsA;
+    // weight gradient (packed layout, the unit's own scratch: zeroed with all the others at the start of the pass) -> OIHW in
+    // the segment's batched un-pack
+    float* scratch = c.jobs ? c.W + u.wg : c.W + c.pl.wsA;
+    const int prezeroed = c.jobs ? 1 : 0;
     if (dz_h && !u.stem && cl.cin % 64 == 0) {     // bf16 mode: both operands exist as bf16 copies (input: u.xh, dz: staging slot)
-        if ((rc = hn_launch_conv_wgrad_bf16(c.W + u.xh, dz_h, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, c.s)))
+        if ((rc = hn_launch_conv_wgrad_bf16(c.W + u.xh, dz_h, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, c.s, prezeroed)))
             return rc;
     } else if ((rc = hn_launch_conv_wgrad(c.W + u.x, dz, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, 0, 0, u.stem,
-                                          c.s)))
+                                          c.s, prezeroed)))
         return rc;
+    if (c.jobs) {
+        c.jobs->push_back(mj_unpack(scratch, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, u.stem ? 8 : 0));
+        return 0;
+    }
     return hn_launch_unpack_conv(scratch, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, u.stem ? 8 : 0, c.s);
 }
 
@@ -266,9 +292,14 @@ int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, f
     memset(&d, 0, sizeof(d));
     d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = cl.cin; d.Cout = cl.cout; d.KH = cl.k; d.KW = cl.k;
     d.sh = u.sh; d.sw = u.sw; d.ph = cl.k / 2; d.pw = cl.k / 2; d.Ho = u.Ho; d.Wo = u.Wo;
-    if (c.e->train_bf16 && cl.cout % 64 == 0)      // (ghc0.3 has Cout = 32: stays on the f32 path)
-        return hn_launch_conv_dgrad_bf16(d, c.W + c.pl.dzh[dzh_slot], c.bound(cl.wkey + ".weight"), add, dx, c.W + c.pl.wsB,
-                                         c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s, /*grad_bf16=*/1);
+    if (c.e->train_bf16 && cl.cout % 64 == 0) {    // (ghc0.3 has Cout = 32: stays on the f32 path)
+        // the per-class bf16 weight packings were written by hn_pack_weights_bf16 (once per optimiser step, one launch)
+        const size_t doff = hn_bf16_dgrad_offset(u.ci);
+        HN_REQUIRE(doff != (size_t)-1, "unit_dgrad: conv %d has no bf16 data-gradient packing", u.ci);
+        void* wpk = const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(c.e->packed_h) + doff);
+        return hn_launch_conv_dgrad_bf16(d, c.W + c.pl.dzh[dzh_slot], nullptr, add, dx, wpk, c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s,
+                                         /*grad_bf16=*/1);
+    }
     if (c.gh()) {
         // float32 kernel inside a bf16-gradient pass (only ghc0.3, no identity branch): float32 dX into scratch, then one
         // conversion pass into the bf16 gradient tensor
@@ -296,6 +327,14 @@ int gemm_rows(const float* x, int xstride, const float* w, const float* scale, c
 }
 
 }  // namespace
+
+void hn_conv_strides(int ci, int* sh, int* sw)
+{
+    static const std::vector<Unit> units = make_train_plan(1).units;
+    *sh = *sw = 1;
+    for (const Unit& u : units)
+        if (u.ci == ci) { *sh = u.sh; *sw = u.sw; return; }
+}
 
 extern "C" size_t hn_train_workspace_bytes(int B)
 {
@@ -379,7 +418,7 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
                pl.total * sizeof(float));
     DeviceGuard guard(e->device);
     HN_REQUIRE(guard.ok, "hn_train_forward: cannot select device %d", e->device);
-    Ctx c{e, arch(), pl, reinterpret_cast<float*>(workspace), e->packed, nullptr, (hipStream_t)stream, B};
+    Ctx c{e, arch(), pl, reinterpret_cast<float*>(workspace), e->packed, nullptr, (hipStream_t)stream, B, nullptr};
     const Arch& a = c.a;
     float* W = c.W;
     hipStream_t s = c.s;
@@ -472,7 +511,9 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_train_backward: workspace too small");
     DeviceGuard guard(e->device);
     HN_REQUIRE(guard.ok, "hn_train_backward: cannot select device %d", e->device);
-    Ctx c{e, arch(), pl, reinterpret_cast<float*>(workspace), e->packed, grads, (hipStream_t)stream, B};
+    std::vector<MJob> jobs;
+    jobs.reserve(256);
+    Ctx c{e, arch(), pl, reinterpret_cast<float*>(workspace), e->packed, grads, (hipStream_t)stream, B, &jobs};
     const Arch& a = c.a;
     float* W = c.W;
     hipStream_t s = c.s;
@@ -483,8 +524,18 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     float* G2 = W + pl.G[2];
     float* G3 = W + pl.G[3];
     double* ds = reinterpret_cast<double*>(W + pl.dstat) + pl.stat_lstm;      // LSTM bias-gradient sums (zeroed where used)
-    if (seg_lo == 0)      // the pass starts: every unit's [S1 | S2 | dbias] slot in one go
+    if (seg_lo == 0) {    // the pass starts: every unit's [S1 | S2 | dbias] slot and every unit's weight-gradient scratch in one go each
         HN_HIP(hipMemsetAsync(reinterpret_cast<double*>(W + pl.dstat) + pl.stat_bwd_first, 0, pl.stat_bwd_doubles * sizeof(double), s));
+        HN_HIP(hipMemsetAsync(W + pl.wg_first, 0, pl.wg_floats * sizeof(float), s));
+    }
+    // the deferred small jobs of a segment (gradient un-packs, double -> float copies) run as ONE launch where the segment
+    // ends, i.e. before its range of the flat gradient buffer is declared final
+    auto flush = [&](int sg) -> int {
+        if (jobs.empty()) return 0;
+        const int r = e->jt_bwd[sg].run(jobs, s);
+        jobs.clear();
+        return r;
+    };
 
     // ---- head: Linear + dropout ----
     if (LIVE && (rc = hn_launch_head_bwd(dbon, dcor, c.bound("linear.weight"), W + pl.y2d, G0, W + pl.dlin, c.grad("linear.weight"),
@@ -546,6 +597,7 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
         if (LIVE && (rc = gemm_rows(dgx, 0, wt, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s))) return rc;
         dy = dx_buf[l];
     }
+    if ((rc = flush(seg))) return rc;
     seg = 1;
     float* dseq = dy;                                  // = G2: gradient w.r.t. the [256*B][1024] sequence matrix
 
@@ -566,6 +618,7 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     }
 
     // ---- backbone, layer4 -> layer1 ----
+    if ((rc = flush(seg))) return rc;
     seg = 2;
     float* Ga = G0;
     float* Gb = G1;
@@ -575,7 +628,9 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     const size_t gsz = c.gh() ? 2 : sizeof(float);      // bytes per gradient element between conv units
     if (LIVE) HN_HIP(hipMemcpyAsync(Ga, W + pl.DC[3], csz[3] * gsz, hipMemcpyDeviceToDevice, s));
     for (int li = 3; li >= 0; --li) {
-        seg = li == 3 ? 2 : (li == 2 ? 3 : 4);
+        const int seg_li = li == 3 ? 2 : (li == 2 ? 3 : 4);
+        if (seg_li != seg && (rc = flush(seg))) return rc;
+        seg = seg_li;
         for (int j = kBlocks[li] - 1; j >= 0; --j) {
             const int i1 = pl.blk[li][j];
             const Unit& u1 = pl.units[i1];
@@ -609,6 +664,7 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
         if (LIVE && (rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, c.gh(), s))) return rc;     // d(stem y) -> Gb (float32)
         if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/0))) return rc;
     }
+    if ((rc = flush(seg))) return rc;
 #undef LIVE
     return 0;
 }

@@ -160,6 +160,66 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
+// bn_finalize_kernel + affine_act_kernel in one launch (the training forward's 69 units each had a ~5 us finalize launch
+// between the conv that produced the sums and this pass): every workgroup derives the affine of ALL channels from the
+// double sums into LDS with bn_finalize_kernel's arithmetic (so a / b are the same bits everywhere), workgroup 0 also stores
+// a / b / mean / invstd for the adjoint and updates the running statistics; then the element pass reads a / b from LDS.
+__global__ __launch_bounds__(256) void affine_act_bn_kernel(const float* __restrict__ z, const double* __restrict__ sum,
+                                                            const double* __restrict__ sumsq, double n, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                            float momentum, float* a_out, float* b_out, float* save_mean,
+                                                            float* save_invstd, const float* __restrict__ res, float* __restrict__ y,
+                                                            unsigned char* __restrict__ bmask, unsigned short* __restrict__ y_h,
+                                                            long total4, int C4, int relu, int z_bf16, int res_bf16)
+{
+    extern __shared__ __attribute__((aligned(16))) float ab[];      // [2][C]
+    const int C = C4 * 4;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double m = sum[c] / n;
+        double var = sumsq[c] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float aa = gamma[c] * invstd;
+        const float bb = beta[c] - (float)m * aa;
+        ab[c] = aa;
+        ab[C + c] = bb;
+        if (blockIdx.x == 0) {
+            a_out[c] = aa;
+            b_out[c] = bb;
+            save_mean[c] = (float)m;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = load_z4(z, i * 4, z_bf16);
+        v = v * *reinterpret_cast<const f32x4*>(ab + c) + *reinterpret_cast<const f32x4*>(ab + C + c);
+        if (res) v += load_z4(res, i * 4, res_bf16);
+        if (relu) {
+            unsigned mk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mk |= (v[k] > 0.f ? 1u : 0u) << k;
+                v[k] = fmaxf(v[k], 0.f);
+            }
+            if (bmask) bmask[i] = (unsigned char)mk;
+        }
+        if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;
+        if (y_h) {
+            unsigned lo, hi;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+            *reinterpret_cast<uint2*>(y_h + i * 4) = make_uint2(lo, hi);
+        }
+    }
+}
+
 // BN backward apply: g = dy * mask;  dz = gamma*invstd * (g - S1/N - zhat * S2/N);  optional dpre = g (identity branch)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ bmask,
                                                            const float* __restrict__ z, const float* __restrict__ mean,
@@ -738,6 +798,20 @@ int hn_launch_affine_act(const float* z, const float* a, const float* b, const f
 {
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4)), dim3(256), 0, s, z, a, b, res, y, bmask,
+                       reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu, z_bf16, res_bf16);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_affine_act_bn(const float* z, const double* sum, const double* sumsq, double n, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float* a, float* b, float* save_mean,
+                            float* save_invstd, const float* res, float* y, unsigned char* bmask, void* y_h, long M, int C, int relu,
+                            int z_bf16, int res_bf16, hipStream_t s)
+{
+    HN_REQUIRE(C % 4 == 0 && C <= 4096, "affine_act_bn: C=%d", C);
+    const long total4 = M * C / 4;
+    hipLaunchKernelGGL(affine_act_bn_kernel, dim3(grid_for(total4)), dim3(256), 2 * (size_t)C * sizeof(float), s, z, sum, sumsq, n, gamma,
+                       beta, running_mean, running_var, momentum, a, b, save_mean, save_invstd, res, y, bmask,
                        reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu, z_bf16, res_bf16);
     HN_LAUNCH_CHECK();
     return 0;
