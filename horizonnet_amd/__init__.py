@@ -18,9 +18,9 @@ from .model import HorizonNet  # noqa: F401
 from .panostretch import pano_stretch, pano_stretch_batch  # noqa: F401
 from .peaks import find_N_peaks, find_peaks_batch  # noqa: F401
 from . import postproc  # noqa: F401
-from .inference import inference, inference_batch  # noqa: F401
+from .inference import inference, inference_batch, inference_stream  # noqa: F401
 from .parallel import allreduce_mean_, broadcast_module_  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 
-__all__ = ["HorizonNet", "pano_stretch", "pano_stretch_batch", "find_N_peaks", "find_peaks_batch", "inference", "inference_batch", "postproc",
+__all__ = ["HorizonNet", "pano_stretch", "pano_stretch_batch", "find_N_peaks", "find_peaks_batch", "inference", "inference_batch", "inference_stream", "postproc",
            "allreduce_mean_", "broadcast_module_", "FusedAdam"]

@@ -175,27 +175,112 @@ def _fit_pool(workers):
     return _POOL["pool"]
 
 
+def _undo_mean_device(y, tags):
+    """`augment_undo(y, tags).mean(0)` without leaving the device: the flips / rolls are exact, the mean is numpy's own
+    arithmetic (slices summed in order, then ONE true division), so the result is bit-identical to the host path."""
+    sz = y.shape[0] // len(tags)
+    acc = None
+    for i, tag in enumerate(tags):
+        part = y[i * sz:(i + 1) * sz]
+        if tag == "flip":
+            part = torch.flip(part, dims=[-1])
+        elif tag.startswith("rotate"):
+            part = torch.roll(part, -int(tag.split()[-1]), dims=-1)
+        elif tag != "":
+            raise NotImplementedError()
+        acc = part if acc is None else acc + part
+    if len(tags) > 1:       # a 0-dim DEVICE divisor: a python scalar would be turned into a multiplication by 1/A
+        acc = acc / torch.tensor(float(len(tags)), dtype=acc.dtype, device=acc.device)
+    return acc
+
+
+class _HostRing:
+    """Pinned host buffers for the signals / peak masks of the batches in flight (page-locked: the copies are asynchronous)."""
+
+    def __init__(self):
+        self.slots = {}
+        self.turn = 0
+
+    def take(self, B, W, nmask, depth):
+        self.turn += 1
+        key = (B, W, nmask, self.turn % (depth + 1))
+        if key not in self.slots:
+            self.slots[key] = (torch.empty((B, 2, W), dtype=torch.float32).pin_memory(),
+                               torch.empty((B, W), dtype=torch.float32).pin_memory(),
+                               torch.empty((nmask, B, W), dtype=torch.uint8).pin_memory())
+        return self.slots[key]
+
+
+_RING = _HostRing()
+
+
+def _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth):
+    """Device half of one batch, enqueued without any host synchronisation: forward of B x A views, augmentation undo + mean,
+    sigmoid, one hn_find_peaks launch per threshold, asynchronous copies into pinned host buffers, one event."""
+    from .peaks import find_peaks_batch
+    W = int(x.shape[-1])
+    B = int(x.shape[0])
+    x_aug, tags = augment(x.to(device), flip, rotate)
+    y_bon, y_cor = net(x_aug)
+    bon = _undo_mean_device(y_bon, tags)
+    prob = _undo_mean_device(torch.sigmoid(y_cor), tags)[:, 0].contiguous()
+    mv = (0.0 if force_cuboid else 0.05) if min_v is None else float(min_v)
+    rr = int(round(W * r / 2))
+    keys = [mv] + ([0.0] if mv != 0.0 else [])      # the cuboid fallback of inference.py:121-126 re-detects with min_v = 0
+    h_bon, h_cor, h_mask = _RING.take(B, W, len(keys), depth)
+    h_bon.copy_(bon, non_blocking=True)
+    h_cor.copy_(prob, non_blocking=True)
+    for i, k in enumerate(keys):
+        h_mask[i].copy_(find_peaks_batch(prob, rr, k)[0], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(torch.device(device)))
+    return {"event": ev, "bon": h_bon, "cor": h_cor, "mask": h_mask, "keys": keys, "B": B, "keep": (bon, prob)}
+
+
+def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers):
+    """Host half: wait for THIS batch's copies, then the Manhattan fits (worker processes for batches of 8 or more)."""
+    st["event"].synchronize()
+    B = st["B"]
+    y_bon, y_cor, masks = st["bon"].numpy(), st["cor"].numpy(), st["mask"].numpy()
+    jobs = [(y_bon[b].copy(), y_cor[b].copy(), H, W, force_cuboid, force_raw, min_v, r,
+             {k: masks[i, b].copy() for i, k in enumerate(st["keys"])}) for b in range(B)]
+    if workers is None:
+        workers = min(_usable_cores(), 32) if B >= 8 else 0
+    if workers <= 1:
+        return [_fit_one(j) for j in jobs]
+    return _fit_pool(workers).map(_fit_one, jobs, chunksize=max(1, B // (4 * workers)))
+
+
 def inference_batch(net, x, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
                     peaks_fn=None, workers=None):
     """x [B,3,512,1024]: one engine forward for all B x augmentations, ONE peak-detection launch per threshold for the
     whole batch (hn_find_peaks), then the host Manhattan fit of the B panoramas spread over `workers` processes
     (default: the usable host cores, inline for small batches; 0 = inline).  -> list of (cor_id, z0, z1), identical to
     B calls of ``inference``."""
-    from .peaks import find_peaks_batch
     H, W = tuple(x.shape[2:])
     B = int(x.shape[0])
-    _, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
     if peaks_fn is not None:                     # caller-supplied peak finder: the per-panorama path
+        _, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
         return [layout_from_signals(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn) for b in range(B)]
-    mv = (0.0 if force_cuboid else 0.05) if min_v is None else float(min_v)
-    rr = int(round(W * r / 2))
-    prob = torch.from_numpy(np.ascontiguousarray(y_cor[:, 0], dtype=np.float32)).to(device)
-    masks = {mv: find_peaks_batch(prob, rr, mv)[0].cpu().numpy()}
-    if 0.0 not in masks:                         # the cuboid fallback of inference.py:121-126 re-detects with min_v = 0
-        masks[0.0] = find_peaks_batch(prob, rr, 0.0)[0].cpu().numpy()
-    jobs = [(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, {k: v[b] for k, v in masks.items()}) for b in range(B)]
-    if workers is None:
-        workers = min(_usable_cores(), 32) if B >= 8 else 0
-    if workers <= 1:
-        return [_fit_one(j) for j in jobs]
-    return _fit_pool(workers).map(_fit_one, jobs, chunksize=max(1, B // (4 * workers)))
+    st = _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth=1)
+    return _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers)
+
+
+def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
+                     workers=None, depth=2):
+    """Pipelined ``inference_batch`` over an iterable of batches x [B,3,512,1024]: yields one list of (cor_id, z0, z1) per
+    batch, in order, identical to ``inference_batch`` batch by batch.  The device half of the next `depth - 1` batches
+    (forward, peaks, copies to pinned memory: all asynchronous) is enqueued BEFORE the host half of the current one (the
+    Manhattan fits) runs, so the GPU works on batch i + 1 while the host cores fit batch i -- the per-batch loop of
+    inference.py:187-209 leaves each side idle while the other works."""
+    from collections import deque
+    pending = deque()
+    for x in batches:
+        H, W = tuple(x.shape[2:])
+        pending.append((_stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth), H, W))
+        if len(pending) >= depth:
+            st, h, w = pending.popleft()
+            yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers)
+    while pending:
+        st, h, w = pending.popleft()
+        yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers)

@@ -502,3 +502,12 @@ def test_inference_batch_pooled_equals_per_panorama_and_reference(golden_dir):
                 assert float(np.abs(cor_id - want).max()) < 1e-6 and abs(z1 - float(g["infz1_%d_%d" % (k, j)])) < 1e-9
         one = inference(sr.SignalNet(), xs[:1], DEV, **kw)
         assert np.array_equal(one[0], out[0][0]) and one[2] == out[0][2]
+        # the pipelined form (device half of the next batches enqueued before the host half of the current one): ragged
+        # batches, results in order, bit-identical to inference_batch
+        from horizonnet_amd.inference import inference_stream
+        cuts = [0, 5, 6, 14, len(sel)]
+        parts = list(inference_stream(sr.SignalNet(), (xs[a:b] for a, b in zip(cuts[:-1], cuts[1:])), DEV, workers=4, depth=3, **kw))
+        assert [len(p_) for p_ in parts] == [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+        flat = [t for p_ in parts for t in p_]
+        for a, b in zip(flat, out):
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]

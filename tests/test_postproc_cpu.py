@@ -126,6 +126,20 @@ def test_inference_batch_equals_single(gold):
         assert np.array_equal(cor_id, one[0]) and z1 == one[2]
 
 
+def test_device_side_augmentation_mean_is_numpys_mean():
+    """inference_batch / inference_stream undo the test-time augmentation and average the views on the device
+    (_undo_mean_device) instead of numpy (augment_undo(...).mean(0), inference.py:46-62,84-85): same bits for 1..5 views."""
+    from horizonnet_amd.inference import _undo_mean_device
+    g = torch.Generator().manual_seed(5)
+    for flip, rotate in ((False, []), (True, []), (True, [0.125]), (False, [0.3, -0.2]), (True, [0.1, 0.2, 0.33])):
+        x = torch.rand(3, 3, 4, 1024, generator=g)
+        xa, tags = augment(x, flip, rotate)
+        y = (torch.rand(xa.shape[0], 2, 1024, generator=g) - 0.5) * 3.0
+        want = augment_undo(y, tags).mean(0)
+        got = _undo_mean_device(y, tags).numpy()
+        assert want.dtype == np.float32 and got.dtype == np.float32 and np.array_equal(want, got), (flip, rotate)
+
+
 def test_augment_round_trip_and_visualize(gold):
     g, _ = gold
     x = image_of(g, 0)

@@ -45,7 +45,7 @@ def _pair_iou(args):
 
 def run_layout_eval(dev, n=1000, batch=32, precisions=("f32", "bf16"), timing_repeats=1):
     from horizonnet_amd import HorizonNet
-    from horizonnet_amd.inference import inference_batch
+    from horizonnet_amd.inference import inference_stream
     z, ref_cor = load_reference()
     n = min(n, int(z["n"]))
     res = {"panoramas": n, "batch": batch, "host_cores": _cores(),
@@ -70,9 +70,9 @@ def run_layout_eval(dev, n=1000, batch=32, precisions=("f32", "bf16"), timing_re
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 out = []
-                for lo in range(0, n, batch):
-                    x = lut[data[lo:lo + batch].long()].permute(0, 3, 1, 2).contiguous()
-                    out += inference_batch(net, x, dev)
+                feed = (lut[data[lo:lo + batch].long()].permute(0, 3, 1, 2).contiguous() for lo in range(0, n, batch))
+                for part in inference_stream(net, feed, dev, depth=3):    # GPU on batch i+1, i+2 while the host cores fit batch i
+                    out += part
                 torch.cuda.synchronize(dev)
                 if rep > 0 or timing_repeats == 0:
                     times.append(time.perf_counter() - t0)
