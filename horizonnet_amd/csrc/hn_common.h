@@ -34,6 +34,8 @@ constexpr int HN_SYNC_WORDS = 1024;     // 4096 bytes
 constexpr int HN_GRAD_SEGMENTS = 5;     // gradient-completion segments of the backward pass (train.hip)
 constexpr int HN_STATUS_WORD = 512;
 
+constexpr size_t HN_HEAD_BWD_SCRATCH_FLOATS = 32 * 12 * 1024 + 32 * 12;   // hn_launch_head_bwd: row-slice partials behind dlin
+
 static inline int hn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- internal launchers (defined in the .hip files, used by engine.hip) ----
@@ -88,8 +90,8 @@ int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
 int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
 int hn_launch_axpy_bf16(const void* x, void* y, long n, hipStream_t s);
 int hn_launch_bf16_to_f32(const void* in, float* out, long n, hipStream_t s);
-int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, int dout_bf16,
-                          hipStream_t s);
+int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi, int Wi, int C, hipStream_t s);
+int hn_launch_maxpool_bwd_idx(const void* idx, const float* dout, float* din, int B, int Hi, int Wi, int C, int dout_bf16, hipStream_t s);
 int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, int out_bf16, hipStream_t s);
 int hn_launch_dropout(const float* in, float* out, long n, float p, unsigned long long seed, hipStream_t s);
 int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, const float* y, float* dy, float* dlin, float* dw,

@@ -28,6 +28,7 @@ struct Unit {
 struct TrainPlan {
     std::vector<Unit> units;
     int blk[4][6], dsu[4], ghc[4];         // unit indices
+    size_t pidx;                           // max-pool winners (one byte per pooled output), written by the forward pass
     size_t xn8, poolh, dzh[2];             // bf16: NHWC4 normalised image, max-pool output, two dz staging buffers
     size_t lxch;                           // bf16: granule exchange scratch of the persistent LSTM kernels
     size_t sync, xn, pool, seq, gx, y1, y1d, y2, y2d, save[2], dlin, G[4], DC[4], dhrec, dcrec, wsA, wsB, dstat, total;
@@ -72,6 +73,7 @@ TrainPlan make_train_plan(int B)
     (void)us;
     p.pool = take(b * 128 * 256 * 64);
     p.poolh = take(b * 128 * 256 * 64 / 2);
+    p.pidx = take(b * 128 * 256 * 64 / 4);
     size_t cur = p.pool, curh = p.poolh;
     int H = 128, W = 256;
     for (int li = 0; li < 4; ++li) {
@@ -116,7 +118,7 @@ TrainPlan make_train_plan(int B)
     p.y2d = take(rows * 1024);
     p.save[0] = take(rows * 2 * 5 * 512);
     p.save[1] = take(rows * 2 * 5 * 512);
-    p.dlin = take(rows * 12);
+    p.dlin = take(rows * 12 + HN_HEAD_BWD_SCRATCH_FLOATS);     // d(Linear output) + the partial sums of the head's weight gradient
     p.gmax = b * 256 * 512 * 64;                 // largest gradient tensor: d(stem output)
     for (int i = 0; i < 4; ++i) p.G[i] = take(p.gmax);
     for (int i = 0; i < 2; ++i) p.dzh[i] = take(p.gmax / 2);
@@ -436,7 +438,7 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
         const Unit& u = pl.units[0];
         if ((rc = conv_z(c, u))) return rc;
         if ((rc = bn_forward(c, u, nullptr, 1, bn_momentum))) return rc;
-        if ((rc = hn_launch_maxpool(W + u.y, W + pl.pool, B, 256, 512, 64, s))) return rc;
+        if ((rc = hn_launch_maxpool_idx(W + u.y, W + pl.pool, W + pl.pidx, B, 256, 512, 64, s))) return rc;
         if (e->train_bf16 && (rc = hn_launch_f32_to_bf16(W + pl.pool, W + pl.poolh, (long)B * 128 * 256 * 64, s))) return rc;
     }
     // backbone + height compression
@@ -661,7 +663,7 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     // ---- max-pool + stem ----
     {
         const Unit& u = pl.units[0];
-        if (LIVE && (rc = hn_launch_maxpool_bwd(W + u.y, Ga, Gb, reinterpret_cast<int*>(Gd), B, 256, 512, 64, c.gh(), s))) return rc;     // d(stem y) -> Gb (float32)
+        if (LIVE && (rc = hn_launch_maxpool_bwd_idx(W + pl.pidx, Ga, Gb, B, 256, 512, 64, c.gh(), s))) return rc;     // d(stem y) -> Gb (float32)
         if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/0))) return rc;
     }
     if ((rc = flush(seg))) return rc;

@@ -476,60 +476,67 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const unsigned short* 
         *reinterpret_cast<f32x4*>(out + i * 4) = load_z4(reinterpret_cast<const float*>(in), i * 4, 1);
 }
 
-// max-pool 3x3/2 pad 1 adjoint, deterministic, in two passes: (1) per pooled output, the input position of its
-// arg-max (first maximum in row-major window order, as torch); (2) per input pixel, gather from the <= 4 windows that
-// contain it and selected it.
-__global__ __launch_bounds__(256) void maxpool_argmax_kernel(const float* __restrict__ in, int* __restrict__ amax, int Hi, int Wi, int Ho,
-                                                             int Wo, int C, long total)
+// max-pool 3x3/2 pad 1 in the training step (torchvision ResNet.maxpool, reference model.py:76) and its adjoint.  The forward
+// pass also records WHICH of the 9 window positions won (first maximum in row-major window order, as torch: one byte per
+// output), so the adjoint is ONE deterministic gather pass with 16-byte stores: per input pixel, the <= 4 windows that contain
+// it.  (It used to be an arg-max pass over the 1 GB float32 stem output plus a scalar gather: 0.70 + 1.41 ms of a 60 ms step.)
+__global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              unsigned* __restrict__ idx, int Hi, int Wi, int Ho, int Wo, int C4, long total)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c4 = (int)(i % C4);
+        long t = i / C4;
         const int wo = (int)(t % Wo);
         t /= Wo;
         const int ho = (int)(t % Ho);
         const long b = t / Ho;
-        float best = -INFINITY;
-        int pos = -1;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned pos[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
-            const int h2 = ho * 2 - 1 + dh;
-            if ((unsigned)h2 >= (unsigned)Hi) continue;
+            const int hi = ho * 2 - 1 + dh;
+            if ((unsigned)hi >= (unsigned)Hi) continue;
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
-                const int w2 = wo * 2 - 1 + dw;
-                if ((unsigned)w2 >= (unsigned)Wi) continue;
-                const float u = in[((b * Hi + h2) * Wi + w2) * (long)C + c];
-                if (u > best) { best = u; pos = h2 * Wi + w2; }
+                const int wi = wo * 2 - 1 + dw;
+                if ((unsigned)wi >= (unsigned)Wi) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((b * Hi + hi) * Wi + wi) * (long)C4 + c4) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > m[k]) { m[k] = v[k]; pos[k] = (unsigned)(dh * 3 + dw); }
             }
         }
-        amax[i] = pos;
+        *reinterpret_cast<f32x4*>(out + i * 4) = m;
+        idx[i] = pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24);
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const int* __restrict__ amax, const float* __restrict__ dout,
-                                                          float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C, long total,
-                                                          int dout_bf16)
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned* __restrict__ idx, const float* __restrict__ dout,
+                                                              float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C4, long total,
+                                                              int dout_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c4 = (int)(i % C4);
+        long t = i / C4;
         const int wi = (int)(t % Wi);
         t /= Wi;
         const int hi = (int)(t % Hi);
         const long b = t / Hi;
-        const int me = hi * Wi + wi;
-        float g = 0.f;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
         for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {             // windows covering row hi: 2*ho-1 <= hi <= 2*ho+1
             if (ho >= Ho) continue;
             for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
                 if (wo >= Wo) continue;
-                const long o = ((b * Ho + ho) * Wo + wo) * (long)C + c;
-                if (amax[o] == me)
-                    g += dout_bf16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(dout)[o] << 16) : dout[o];
+                const long o = ((b * Ho + ho) * Wo + wo) * (long)C4 + c4;
+                const unsigned a = idx[o];
+                const unsigned me = (unsigned)((hi - (2 * ho - 1)) * 3 + (wi - (2 * wo - 1)));
+                const f32x4 d = load_z4(dout, o * 4, dout_bf16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((a >> (8 * k)) & 255u) == me) g[k] += d[k];
             }
         }
-        din[i] = g;
+        *reinterpret_cast<f32x4*>(din + i * 4) = g;
     }
 }
 
@@ -606,19 +613,26 @@ __global__ __launch_bounds__(256) void head_bwd_dy_kernel(const float* __restric
         dy[row * 1024 + k] = s;
     }
 }
-// dW[o][k] = sum_rows dlin[row][o] * y[row][k];  db[o] = sum_rows dlin[row][o]   (one workgroup per 64 k-columns, f64 atomics-free)
+// dW[o][k] = sum_rows dlin[row][o] * y[row][k];  db[o] = sum_rows dlin[row][o].  Grid = 16 column blocks (64 k each) x
+// HEAD_SLICES row slices: every workgroup reduces its rows (4 strided partitions, combined through LDS) into a partial
+// [slice][12][1024] (+ [slice][12] for the bias); head_bwd_dw_reduce_kernel adds the slices in index order -- deterministic,
+// and 512 workgroups instead of the 16 that used to walk all T*B rows (0.78 ms of a 60 ms step).
+constexpr int HEAD_SLICES = 32;
+static_assert((size_t)HEAD_SLICES * 12 * 1024 + HEAD_SLICES * 12 == HN_HEAD_BWD_SCRATCH_FLOATS, "head_bwd scratch");
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ dlin, const float* __restrict__ y,
-                                                          float* __restrict__ dw, float* __restrict__ db, long rows)
+                                                          float* __restrict__ part_w, float* __restrict__ part_b, long rows)
 {
     const int k = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;                 // 4 row partitions
+    const int sl = blockIdx.y;
+    const long r_lo = rows * sl / HEAD_SLICES, r_hi = rows * (sl + 1) / HEAD_SLICES;
     float acc[12];
 #pragma unroll
     for (int o = 0; o < 12; ++o) acc[o] = 0.f;
     float bsum[12];
 #pragma unroll
     for (int o = 0; o < 12; ++o) bsum[o] = 0.f;
-    for (long r = part; r < rows; r += 4) {
+    for (long r = r_lo + part; r < r_hi; r += 4) {
         const float yv = y[r * 1024 + k];
 #pragma unroll
         for (int o = 0; o < 12; ++o) {
@@ -638,9 +652,25 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
     if (part == 0) {
 #pragma unroll
         for (int o = 0; o < 12; ++o)
-            dw[o * 1024 + k] = red[0][o][threadIdx.x] + red[1][o][threadIdx.x] + red[2][o][threadIdx.x] + red[3][o][threadIdx.x];
+            part_w[((size_t)sl * 12 + o) * 1024 + k] = red[0][o][threadIdx.x] + red[1][o][threadIdx.x] + red[2][o][threadIdx.x] + red[3][o][threadIdx.x];
     }
-    if (blockIdx.x == 0 && threadIdx.x < 12) db[threadIdx.x] = redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 12)
+        part_b[sl * 12 + threadIdx.x] = redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dw_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                                                 float* __restrict__ dw, float* __restrict__ db)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;      // 12 * 1024 weight entries, then 12 bias entries
+    if (i < 12 * 1024) {
+        float s = 0.f;
+        for (int sl = 0; sl < HEAD_SLICES; ++sl) s += part_w[(size_t)sl * 12 * 1024 + i];
+        dw[i] = s;
+    } else if (i < 12 * 1024 + 12) {
+        float s = 0.f;
+        for (int sl = 0; sl < HEAD_SLICES; ++sl) s += part_b[sl * 12 + (i - 12 * 1024)];
+        db[i - 12 * 1024] = s;
+    }
 }
 
 // LSTM gate adjoint for ONE time index per direction (fwd at t_f, rev at t_r):
@@ -685,29 +715,63 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* const* __restrict
                                                         long long total, float lr, float b1, float b2, float eps, float wd, float bc1,
                                                         float bc2_sqrt, float inv_grad_scale)
 {
+    // A workgroup walks chunks of 4096 consecutive elements (4 x 16 bytes per lane and tensor stream).  The tensor search runs
+    // once per chunk on its first element (uniform: scalar loads), lanes then step forward from there -- almost always zero
+    // steps, the tensors are thousands of elements long.  Groups of 4 that lie inside one active tensor (all but the odd
+    // tail: the flat layout starts every tensor on a 64-element boundary) go through 16-byte accesses.
+    constexpr int CH = 4096;
     const float step_size = lr / bc1;
-    for (long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < total; i4 += (long long)gridDim.x * blockDim.x * 4) {
-        int lo = 0, hi = n_tensors - 1;                  // last tensor whose first element is <= i4
+    auto one = [&](float gi, float pi, float& mi, float& vi) -> float {
+        gi = gi * inv_grad_scale + wd * pi;
+        mi = b1 * mi + (1.f - b1) * gi;
+        vi = b2 * vi + (1.f - b2) * gi * gi;
+        return pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    };
+    for (long long base = (long long)blockIdx.x * CH; base < total; base += (long long)gridDim.x * CH) {
+        int lo = 0, hi = n_tensors - 1;                  // last tensor whose first element is <= base
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (offsets[mid] <= i4) lo = mid; else hi = mid - 1;
+            if (offsets[mid] <= base) lo = mid; else hi = mid - 1;
         }
-        int t = lo;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long i = i4 + k;
-            if (i >= total) break;
-            while (t + 1 < n_tensors && i >= offsets[t + 1]) ++t;
-            if (i >= ends[t] || !active[t]) continue;   // alignment gap between two tensors of the flat layout / frozen tensor
-            float* p = params[t] + (i - offsets[t]);
-            float gi = g[i] * inv_grad_scale;
-            const float pi = *p;
-            gi += wd * pi;
-            const float mi = b1 * m[i] + (1.f - b1) * gi;
-            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-            m[i] = mi;
-            v[i] = vi;
-            *p = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        for (int u = 0; u < 4; ++u) {
+            const long long i4 = base + ((long long)u * 256 + threadIdx.x) * 4;
+            if (i4 >= total) break;
+            int t = lo;
+            while (t + 1 < n_tensors && i4 >= offsets[t + 1]) ++t;
+            const long long off = offsets[t];
+            if (i4 + 3 < ends[t] && ((i4 - off) & 3) == 0) {
+                if (!active[t]) continue;
+                float* p = params[t] + (i4 - off);
+                if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i4);
+                    f32x4 pv = *reinterpret_cast<const f32x4*>(p);
+                    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i4);
+                    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float mi = mv[k], vi = vv[k];
+                        pv[k] = one(gv[k], pv[k], mi, vi);
+                        mv[k] = mi;
+                        vv[k] = vi;
+                    }
+                    *reinterpret_cast<f32x4*>(m + i4) = mv;
+                    *reinterpret_cast<f32x4*>(v + i4) = vv;
+                    *reinterpret_cast<f32x4*>(p) = pv;
+                    continue;
+                }
+            }
+            for (int k = 0; k < 4; ++k) {                // tails, gaps, unaligned storage: element by element
+                const long long i = i4 + k;
+                if (i >= total) break;
+                while (t + 1 < n_tensors && i >= offsets[t + 1]) ++t;
+                if (i >= ends[t] || !active[t]) continue;   // alignment gap between two tensors of the flat layout / frozen tensor
+                float* p = params[t] + (i - offsets[t]);
+                float mi = m[i], vi = v[i];
+                *p = one(g[i], *p, mi, vi);
+                m[i] = mi;
+                v[i] = vi;
+            }
         }
     }
 }
@@ -882,15 +946,22 @@ int hn_launch_bf16_to_f32(const void* in, float* out, long n, hipStream_t s)
     return 0;
 }
 
-int hn_launch_maxpool_bwd(const float* in, const float* dout, float* din, int* scratch, int B, int Hi, int Wi, int C, int dout_bf16,
-                          hipStream_t s)
+int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi, int Wi, int C, hipStream_t s)
 {
-    const long total = (long)B * Hi * Wi * C;
-    const long total_o = (long)B * (Hi / 2) * (Wi / 2) * C;
-    HN_REQUIRE((long)Hi * Wi < 0x7fffffffL, "maxpool_bwd: image too large");
-    hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(grid_for(total_o, 256L * 64)), dim3(256), 0, s, in, scratch, Hi, Wi, Hi / 2, Wi / 2, C, total_o);
+    HN_REQUIRE(C % 4 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "maxpool_idx: C %% 4, even sizes");
+    const long total = (long)B * (Hi / 2) * (Wi / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_idx_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, in, out, reinterpret_cast<unsigned*>(idx), Hi,
+                       Wi, Hi / 2, Wi / 2, C / 4, total);
     HN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, scratch, dout, din, Hi, Wi, Hi / 2, Wi / 2, C, total, dout_bf16);
+    return 0;
+}
+
+int hn_launch_maxpool_bwd_idx(const void* idx, const float* dout, float* din, int B, int Hi, int Wi, int C, int dout_bf16, hipStream_t s)
+{
+    HN_REQUIRE(C % 4 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "maxpool_bwd_idx: C %% 4, even sizes");
+    const long total = (long)B * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, reinterpret_cast<const unsigned*>(idx), dout,
+                       din, Hi, Wi, Hi / 2, Wi / 2, C / 4, total, dout_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -915,7 +986,12 @@ int hn_launch_head_bwd(const float* dbon, const float* dcor, const float* w, con
     const long rows = (long)T * B;
     hipLaunchKernelGGL(head_bwd_dy_kernel, dim3((unsigned)rows), dim3(256), 0, s, dbon, dcor, w, dy, dlin, T, B);
     HN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(16), dim3(256), 0, s, dlin, y, dw, db, rows);
+    // partial sums live behind the T*B*12 floats of dlin (the caller's buffer holds HN_HEAD_BWD_SCRATCH_FLOATS more)
+    float* part_w = dlin + rows * 12;
+    float* part_b = part_w + (size_t)HEAD_SLICES * 12 * 1024;
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(16, HEAD_SLICES), dim3(256), 0, s, dlin, y, part_w, part_b, rows);
+    HN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_dw_reduce_kernel, dim3((12 * 1024 + 12 + 255) / 256), dim3(256), 0, s, part_w, part_b, dw, db);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -940,7 +1016,7 @@ extern "C" int hn_adam_step(float* const* params, const long long* offsets, cons
     HN_REQUIRE(n_tensors >= 1 && total >= 1 && step >= 1 && grad_scale > 0.f, "hn_adam_step: bad sizes / step");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for((total + 3) / 4, 256L * 32)), dim3(256), 0, (hipStream_t)stream, params, offsets, ends, active,
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for((total + 15) / 16, 256L * 16)), dim3(256), 0, (hipStream_t)stream, params, offsets, ends, active,
                        n_tensors, grads, m, v, total, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), 1.f / grad_scale);
     HN_LAUNCH_CHECK();
     return 0;
