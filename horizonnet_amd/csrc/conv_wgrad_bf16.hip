@@ -39,6 +39,7 @@ struct WgradArgsH {
     int Hi, Wi, Cin, Ho, Wo, Cout;
     int KW, sh, sw, ph, pw;
     int M, K, mchunk;
+    int xstride, dzstride;   // elements between input pixels / between dz rows (>= Cin / Cout: column views of wider matrices)
 };
 
 __device__ __forceinline__ u32x4 hbuf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff)
@@ -110,11 +111,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
 
     const int hw_out = p.Ho * p.Wo;
     const int b_first = mlo / hw_out;
-    const size_t img_elems = (size_t)p.Hi * p.Wi * p.Cin;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
     const __amdgpu_buffer_rsrc_t rsrc_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_dz =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.dz + (size_t)mlo * p.Cout), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.dz + (size_t)mlo * p.dzstride), 0, 0x7fffffff, 0x00020000);
 
     const int n_row = tid / N_TPR, n_col = (tid % N_TPR) * 8;
     const int k_row = tid / K_TPR, k_col = (tid % K_TPR) * 8;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
 #pragma unroll
         for (int q = 0; q < N_PS; ++q) {
             const int m = mc + n_row + q * N_RPP;
-            const unsigned off = m < mhi ? (unsigned)((size_t)(m - mlo) * p.Cout + n0 + n_col) * 2u : OOB;
+            const unsigned off = m < mhi ? (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 2u : OOB;
             rdz[q] = hbuf_load16(rsrc_dz, off);
         }
 #pragma unroll
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
             wi = wi < 0 ? wi + p.Wi : wi;
             wi = wi >= p.Wi ? wi - p.Wi : wi;
             const unsigned pix = (unsigned)(r_b[q] * hw_in + hi * p.Wi + wi);
-            const unsigned in_off = (pix * (unsigned)p.Cin + (unsigned)(c0 + k_col)) * 2u;
+            const unsigned in_off = (pix * (unsigned)p.xstride + (unsigned)(c0 + k_col)) * 2u;
             ra[q] = hbuf_load16(rsrc_x, (m < mhi && (unsigned)hi < (unsigned)p.Hi) ? in_off : OOB);
             if (wide) {
                 int wn = r_wo[q] + WCHB;
@@ -247,7 +248,7 @@ int launch_wgrad_h(WgradArgsH a, hipStream_t s)
 // Needs Cout %% 64 == 0 and Cin %% 64 == 0 (every conv of the network except the 7x7 stem and ghc0.3, which keep the f32
 // kernel).
 int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                              int sh, int sw, hipStream_t s, int prezeroed)
+                              int sh, int sw, hipStream_t s, int prezeroed, int xstride, int dzstride)
 {
     HN_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad bf16: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
     WgradArgsH a;
@@ -258,7 +259,10 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     a.M = B * a.Ho * a.Wo;
     a.K = KH * KW * Cin;
     a.mchunk = 0;
-    HN_REQUIRE((double)B * Hi * Wi * Cin * 2.0 < 2147483648.0 && (double)a.M * Cout * 2.0 < 4294967296.0,
+    a.xstride = xstride ? xstride : Cin;
+    a.dzstride = dzstride ? dzstride : Cout;
+    HN_REQUIRE(a.xstride >= Cin && a.dzstride >= Cout && a.xstride % 8 == 0 && a.dzstride % 8 == 0, "wgrad bf16: bad strides");
+    HN_REQUIRE((double)B * Hi * Wi * a.xstride * 2.0 < 2147483648.0 && (double)a.M * a.dzstride * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
     if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad_h<128, 128>(a, s);

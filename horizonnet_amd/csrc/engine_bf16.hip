@@ -41,6 +41,8 @@ const HOff& hoff()
 
 size_t hn_bf16_conv_offset(int ci) { return hoff().conv[ci]; }
 size_t hn_bf16_dgrad_offset(int ci) { return hoff().dgrad[ci]; }
+size_t hn_bf16_wih_offset(int l) { return hoff().wih[l]; }
+size_t hn_bf16_whh_offset(int l, int d) { return hoff().whh[l][d]; }
 
 namespace {
 

@@ -125,5 +125,8 @@ size_t hn_bf16_conv_offset(int ci);
 // ... and of its per-class data-gradient packing (classes in (row parity, column parity) order, as hn_launch_conv_dgrad_bf16
 // walks them); (size_t)-1 for convs without a bf16 data gradient (the stem, Cout % 64 != 0)
 size_t hn_bf16_dgrad_offset(int ci);
+// ... of the LSTM weights in that buffer: W_ih of layer l ([4096][1024], both directions stacked), W_hh of (layer, direction)
+size_t hn_bf16_wih_offset(int l);
+size_t hn_bf16_whh_offset(int l, int d);
 // strides of conv `ci` inside the network (train.hip's plan: the architecture fixes them)
 void hn_conv_strides(int ci, int* sh, int* sw);

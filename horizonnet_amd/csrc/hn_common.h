@@ -111,7 +111,7 @@ int hn_launch_pack_conv_dgrad(const float* w, float* out, int Cout, int Cin, int
 int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s);
 int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                              int sh, int sw, hipStream_t s, int prezeroed = 0);
+                              int sh, int sw, hipStream_t s, int prezeroed = 0, int xstride = 0, int dzstride = 0);
 int hn_launch_conv_dgrad_bf16(const ConvDesc& fwd, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
                               const float* ones, const float* zeros, hipStream_t s, int grad_bf16 = 0);
 int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);

@@ -328,6 +328,17 @@ int gemm_rows(const float* x, int xstride, const float* w, const float* scale, c
     return hn_launch_conv(d, s);
 }
 
+// y[rows][N] (f32) = x_h[rows][K] (bf16) @ w_h[N][K]^T (bf16) * scale + shift on the bf16 matrix cores
+int gemm_rows_bf16(const void* x_h, const void* w_h, const float* scale, const float* shift, float* y, long rows, int K, int N, hipStream_t s)
+{
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = reinterpret_cast<const float*>(x_h); d.w = reinterpret_cast<const float*>(w_h); d.scale = scale; d.shift = shift; d.res = nullptr; d.y = y;
+    d.B = 1; d.Hi = 1; d.Wi = (int)rows; d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1;
+    d.Ho = 1; d.Wo = (int)rows; d.relu = 0; d.ldy = N;
+    return hn_launch_conv_bf16(d, 1, s);
+}
+
 }  // namespace
 
 void hn_conv_strides(int ci, int* sh, int* sw)
@@ -473,21 +484,24 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     float* ydrop[2] = {W + pl.y1d, W + pl.y2d};
     const float pdrop[2] = {p_rnn, p_head};
     for (int l = 0; l < 2; ++l) {
-        if ((rc = gemm_rows(lin, 0, c.P + a.wih_off[l], c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
         if (e->train_bf16) {
-            // bf16 mode: the batch-partitioned persistent kernel of the bf16 forward (W_hh on the bf16 matrix cores, bf16 h
-            // hand-off), also storing the gates for the adjoint; the weights change every step, so they are re-rounded here
-            float* whh_h = W + pl.wsA;                    // [2][2048][512] bf16 (the conv weight scratch is idle by now)
-            for (int d = 0; d < 2; ++d)
-                if ((rc = hn_launch_f32_to_bf16(c.P + a.whh_off[l][d], reinterpret_cast<unsigned short*>(whh_h) + (size_t)d * 2048 * 512,
-                                                (long)2048 * 512, s)))
-                    return rc;
-            if ((rc = hn_launch_lstm_layer_bf16(W + pl.gx, whh_h, reinterpret_cast<unsigned short*>(whh_h) + (size_t)2048 * 512, ybuf[l], nullptr,
+            // bf16 mode (the reference runs the whole net under autocast, train.py:273): the input projection on the bf16 matrix
+            // cores from a bf16 copy of the layer input and the W_ih / W_hh roundings hn_pack_weights_bf16 made for this step;
+            // the batch-partitioned persistent recurrence of the bf16 forward, also storing the gates for the adjoint
+            const unsigned short* H = reinterpret_cast<const unsigned short*>(e->packed_h);
+            unsigned short* lin_h = reinterpret_cast<unsigned short*>(W + pl.wsB);
+            HN_REQUIRE((size_t)rows * 1024 <= ((size_t)1024 * 18432) * 2, "hn_train_forward: batch too large for the bf16 LSTM input staging");
+            if ((rc = hn_launch_f32_to_bf16(lin, lin_h, rows * 1024, s))) return rc;
+            if ((rc = gemm_rows_bf16(lin_h, H + hn_bf16_wih_offset(l), c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
+            if ((rc = hn_launch_lstm_layer_bf16(W + pl.gx, H + hn_bf16_whh_offset(l, 0), H + hn_bf16_whh_offset(l, 1), ybuf[l], nullptr,
                                                 T_COLS, B, W + pl.lxch, W + pl.sync, s, W + pl.save[l])))
                 return rc;
-        } else if ((rc = hn_launch_lstm_layer(W + pl.gx, c.P + a.whh_off[l][0], c.P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s,
-                                              W + pl.save[l])))
-            return rc;
+        } else {
+            if ((rc = gemm_rows(lin, 0, c.P + a.wih_off[l], c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
+            if ((rc = hn_launch_lstm_layer(W + pl.gx, c.P + a.whh_off[l][0], c.P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s,
+                                           W + pl.save[l])))
+                return rc;
+        }
         if (pdrop[l] > 0.f) {
             if ((rc = hn_launch_dropout(ybuf[l], ydrop[l], rows * 1024, pdrop[l], seed * 2 + 1 + l, s))) return rc;
         } else {
@@ -575,15 +589,34 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
                 return rc;
         }
         // dW_hh = sum_t dg_t^T h_{t-1}   (fwd: rows m >= B pair with y rows m - B; rev: rows m < (T-1)B pair with y rows m + B)
-        if (LIVE && (rc = hn_launch_conv_wgrad(layer_out[l], dgx + (size_t)B * 4096, c.grad("bi_rnn.weight_hh" + sf), 1, 1, (int)(rows - B), 512,
-                                       2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
-            return rc;
-        if (LIVE && (rc = hn_launch_conv_wgrad(layer_out[l] + (size_t)B * 1024 + 512, dgx + 2048, c.grad("bi_rnn.weight_hh" + sr), 1, 1,
-                                       (int)(rows - B), 512, 2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
-            return rc;
-        // dW_ih (both directions stacked) and the bias gradients
+        // dW_ih (both directions stacked) and the bias gradients;  dx = dg @ [W_ih_fwd; W_ih_rev]
         float* wsc = W + pl.wsA;
-        if (LIVE && (rc = hn_launch_conv_wgrad(layer_in[l], dgx, wsc, 1, 1, (int)rows, 1024, 4096, 1, 1, 1, 1, 1024, 4096, 0, s))) return rc;
+        float* wt = W + pl.wsB;                       // transpose of the stacked W_ih: GEMM weights [N=1024][K=4096]
+        if (e->train_bf16) {
+            // bf16 mode: the three weight-gradient GEMMs and the data-gradient GEMM on the bf16 matrix cores from bf16 copies of
+            // dg, the layer input and the layer output (G3 is idle during the LSTM adjoint); float32 accumulation and results
+            unsigned short* dg_h = reinterpret_cast<unsigned short*>(G3);                     // [rows][4096]
+            unsigned short* in_h = dg_h + (size_t)rows * 4096;                                // [rows][1024]
+            unsigned short* out_h = in_h + (size_t)rows * 1024;                               // [rows][1024]
+            if (LIVE && (rc = hn_launch_f32_to_bf16(dgx, dg_h, rows * 4096, s))) return rc;
+            if (LIVE && (rc = hn_launch_f32_to_bf16(layer_in[l], in_h, rows * 1024, s))) return rc;
+            if (LIVE && (rc = hn_launch_f32_to_bf16(layer_out[l], out_h, rows * 1024, s))) return rc;
+            if (LIVE && (rc = hn_launch_conv_wgrad_bf16(out_h, dg_h + (size_t)B * 4096, c.grad("bi_rnn.weight_hh" + sf), 1, 1, (int)(rows - B), 512,
+                                                        2048, 1, 1, 1, 1, s, 0, 1024, 4096)))
+                return rc;
+            if (LIVE && (rc = hn_launch_conv_wgrad_bf16(out_h + (size_t)B * 1024 + 512, dg_h + 2048, c.grad("bi_rnn.weight_hh" + sr), 1, 1,
+                                                        (int)(rows - B), 512, 2048, 1, 1, 1, 1, s, 0, 1024, 4096)))
+                return rc;
+            if (LIVE && (rc = hn_launch_conv_wgrad_bf16(in_h, dg_h, wsc, 1, 1, (int)rows, 1024, 4096, 1, 1, 1, 1, s))) return rc;
+        } else {
+            if (LIVE && (rc = hn_launch_conv_wgrad(layer_out[l], dgx + (size_t)B * 4096, c.grad("bi_rnn.weight_hh" + sf), 1, 1, (int)(rows - B), 512,
+                                           2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
+                return rc;
+            if (LIVE && (rc = hn_launch_conv_wgrad(layer_out[l] + (size_t)B * 1024 + 512, dgx + 2048, c.grad("bi_rnn.weight_hh" + sr), 1, 1,
+                                           (int)(rows - B), 512, 2048, 1, 1, 1, 1, 1024, 4096, 0, s)))
+                return rc;
+            if (LIVE && (rc = hn_launch_conv_wgrad(layer_in[l], dgx, wsc, 1, 1, (int)rows, 1024, 4096, 1, 1, 1, 1, 1024, 4096, 0, s))) return rc;
+        }
         if (LIVE) HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sf), wsc, (size_t)2048 * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (LIVE) HN_HIP(hipMemcpyAsync(c.grad("bi_rnn.weight_ih" + sr), wsc + (size_t)2048 * 1024, (size_t)2048 * 1024 * sizeof(float),
                               hipMemcpyDeviceToDevice, s));
@@ -593,10 +626,13 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
         if (LIVE && (rc = hn_launch_d2f(ds, c.grad("bi_rnn.bias_hh" + sf), 2048, s))) return rc;
         if (LIVE && (rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_ih" + sr), 2048, s))) return rc;
         if (LIVE && (rc = hn_launch_d2f(ds + 2048, c.grad("bi_rnn.bias_hh" + sr), 2048, s))) return rc;
-        // dx = dg @ [W_ih_fwd; W_ih_rev]   (GEMM weights [N=1024][K=4096] = transpose of the stacked W_ih)
-        float* wt = W + pl.wsB;
         if (LIVE && (rc = hn_launch_transpose(c.P + a.wih_off[l], wt, 4096, 1024, s))) return rc;
-        if (LIVE && (rc = gemm_rows(dgx, 0, wt, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s))) return rc;
+        if (e->train_bf16) {
+            unsigned short* wt_h = reinterpret_cast<unsigned short*>(wt + (size_t)4096 * 1024);
+            if (LIVE && (rc = hn_launch_f32_to_bf16(wt, wt_h, (long)4096 * 1024, s))) return rc;
+            if (LIVE && (rc = gemm_rows_bf16(G3, wt_h, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s))) return rc;
+        } else if (LIVE && (rc = gemm_rows(dgx, 0, wt, c.P + a.ones_off, c.P + a.zeros_off, dx_buf[l], rows, 4096, 1024, s)))
+            return rc;
         dy = dx_buf[l];
     }
     if ((rc = flush(seg))) return rc;
