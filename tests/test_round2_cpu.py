@@ -12,6 +12,7 @@ import torch
 from horizonnet_amd import HorizonNet
 from horizonnet_amd import utils as hutils
 from horizonnet_amd import model as hmodel
+from horizonnet_amd import evaluation as ev_mod
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -151,3 +152,72 @@ def test_frozen_block_fixture_is_consistent(golden_dir):
     assert [k for k, p in net.named_parameters() if p.requires_grad] == meta["live"]
     bn_names = [k for k, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)]
     assert len(bn_names) == 69 and all(any(b.startswith(n) for n in bn_names) for b in meta["frozen_bn_buffers"])
+
+
+# ---- general polygon intersection (eval_general.py:69-79: shapely / GEOS in the reference) --------------------------------
+def test_exact_polygon_oracle_closed_forms():
+    """oracle/polygon_ref.py (rational arithmetic, boundary-integral form) against areas known in closed form, including
+    every degenerate contact two Manhattan floor plans produce: shared walls, identical rings, touching corners."""
+    from fractions import Fraction as Fr
+    from oracle.polygon_ref import area_exact, intersection_area_exact as ix
+    sq = [(0, 0), (2, 0), (2, 2), (0, 2)]
+    ell = [(0, 0), (4, 0), (4, 1), (1, 1), (1, 4), (0, 4)]
+    assert ix(sq, [(1, 1), (3, 1), (3, 3), (1, 3)]) == 1
+    assert ix(sq, sq) == 4 and ix(sq, sq[::-1]) == 4 and ix(sq, sq + [sq[0]]) == 4           # identical, reversed, closed ring
+    assert ix(ell, ell[2:] + ell[:2]) == area_exact(ell) == 7
+    assert ix(sq, [(2, 0), (4, 0), (4, 2), (2, 2)]) == 0                                     # shared wall, interiors apart
+    assert ix(sq, [(2, 2), (3, 2), (3, 3), (2, 3)]) == 0                                     # touching corner
+    assert ix(sq, [(1, 0), (3, 0), (3, 2), (1, 2)]) == 2                                     # two shared walls, overlapping
+    assert ix(sq, [(0.5, 0.5), (1.5, 0.5), (1.5, 1.5), (0.5, 1.5)]) == 1                     # nested
+    assert ix(sq, [(0, 0), (1, 0), (1, 1), (0, 1)]) == 1                                     # nested, sharing a corner and two half walls
+    assert ix(sq, [(5, 5), (6, 5), (6, 6)]) == 0
+    assert ix(ell, [(0.5, 0.5), (3, 0.5), (3, 3), (0.5, 3)]) == Fr(9, 4)
+    assert ix(ell, [(0, 0), (4, 0), (4, 4), (0, 4)]) == 7                                    # notch of the L lies on the square's inside
+    assert ix([(0, 0), (4, 0), (0, 4)], [(0, 0), (4, 0), (4, 4)]) == 4                       # crossing diagonals: triangle (0,0),(4,0),(2,2)
+    tri = [(0, 0), (3, 0), (0, 3)]
+    assert ix(tri, [(1, -1), (2, -1), (2, 5), (1, 5)]) == Fr(3, 2)                           # strip through a triangle: x in [1,2], y in [0,3-x]
+
+
+def test_polygon_intersection_area_matches_exact_oracle():
+    """The product's float64 slab decomposition (horizonnet_amd/evaluation.py) against the exact oracle on random rooms:
+    non-convex star polygons in general position, Manhattan rooms against shifted / re-notched copies (shared and
+    collinear-overlapping walls), and identical rings.  |error| <= 1e-12 x area scale."""
+    from oracle.polygon_ref import intersection_area_exact as ix
+    from tools.synth_rooms import manhattan_polygon
+    rng = np.random.RandomState(7)
+    worst = 0.0
+
+    def check(a, b):
+        nonlocal worst
+        want = float(ix(a, b))
+        got = ev_mod.polygon_intersection_area(a, b)
+        scale = max(ev_mod.polygon_area(a), ev_mod.polygon_area(b))
+        worst = max(worst, abs(got - want) / scale)
+        assert abs(got - want) <= 1e-12 * scale, (a, b, got, want)
+        return want
+
+    def star(n):
+        from horizonnet_amd import postproc
+        while True:                 # vertices sorted by angle: simple unless an angular gap exceeds pi -- reject those
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+            rad = rng.uniform(0.6, 3.0, n)
+            p = np.stack([rad * np.cos(ang) + rng.uniform(-0.5, 0.5), rad * np.sin(ang) + rng.uniform(-0.5, 0.5)], 1)
+            if postproc.polygon_is_simple(p):
+                return p
+
+    nonzero = 0
+    for _ in range(60):
+        nonzero += check(star(rng.randint(3, 12)), star(rng.randint(3, 12))) > 0
+    for _ in range(60):
+        a = manhattan_polygon(rng, int(rng.choice([4, 6, 8, 10, 12])))
+        b = manhattan_polygon(rng, int(rng.choice([4, 6, 8, 10, 12])))
+        nonzero += check(a, b) > 0
+        check(a, a.copy())                                                       # identical rings: every wall shared
+        shift = np.array([rng.choice([0.0, 0.25, -0.5]), rng.choice([0.0, 0.125, 1.0])])
+        check(a, a + shift)                                                      # collinear overlapping walls
+        c = a.copy()
+        c[:, 0] = np.where(c[:, 0] == c[:, 0].max(), c[:, 0] - 0.3, c[:, 0])     # one wall moved, the others shared
+        check(a, c)
+        check(a, star(7))                                                        # Manhattan against general position
+    assert nonzero >= 100
+    print("[parity] polygon intersection vs exact rational oracle: worst relative error %.2e" % worst)
