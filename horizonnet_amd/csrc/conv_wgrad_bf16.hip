@@ -23,7 +23,6 @@
 
 namespace {
 
-constexpr int WCHB = 32;                // m rows per chunk = two k16 steps
 constexpr int PITCH = 320;              // bytes per LDS image row (128 bf16 + pad)
 constexpr unsigned OOB = 0x80000000u;
 
@@ -64,7 +63,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int l
 #endif
 }
 
-template <int TN, int TK>
+// WCHB: m rows per chunk (one barrier per chunk): 32 = two k16 steps (8 MFMAs per wave and barrier for the 128x128 tile, 40 KB of
+// LDS: 4 workgroups per CU), 64 = four (16 MFMAs per barrier, 80 KB: 2 workgroups per CU)
+template <int TN, int TK, int WCHB>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
 {
     static_assert(TN == 128 && TK == 128 || TN == 64 || TK == 64, "tile");
@@ -225,11 +226,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
             }
 }
 
-template <int TN, int TK>
-int launch_wgrad_h(WgradArgsH a, hipStream_t s)
+template <int TN, int TK, int WCHB>
+int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
 {
     const int NT = a.Cout / TN, KT = a.K / TK;
-    long split = 2048 / ((long)NT * KT);
+    long split = target / ((long)NT * KT);
     if (split < 1) split = 1;
     long mchunk = (a.M + split - 1) / split;
     if (mchunk < 8 * WCHB) mchunk = 8 * WCHB;
@@ -237,9 +238,35 @@ int launch_wgrad_h(WgradArgsH a, hipStream_t s)
     split = (a.M + mchunk - 1) / mchunk;
     a.mchunk = (int)mchunk;
     const size_t lds = 4 * (size_t)WCHB * PITCH;
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK>), dim3((unsigned)(NT * KT * split)), dim3(256), lds, s, a);
+    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB>;
+    if (lds > 65536) {
+        static bool attr_done[64] = {};   // per instantiation, per device
+        int dev = 0;
+        HN_HIP(hipGetDevice(&dev));
+        if (dev < 64 && !attr_done[dev]) {
+            HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(NT * KT * split)), dim3(256), lds, s, a);
     HN_LAUNCH_CHECK();
     return 0;
+}
+
+// Rows per chunk and the number of workgroups the m range is split into, measured on the training step at B = 32
+// (tools/trace_timeline.py over prof_train_target.py, profiles/r2_wgrad_split_sweep.txt): every workgroup ends with TN x TK float
+// atomics, so MORE workgroups is not better -- 512 (one resident round at 2 per CU with the 80 KB of the 64-row chunk) takes
+// the 61 launches of the 128x128 tile from 9.7 ms (32 rows, 2048 workgroups) to 7.4 ms; 4096 workgroups cost 13.5 ms, 256 leave
+// half the chip idle (10.3 ms).  The small 64x64 tile (layer1's 64-channel convs: tiny output, huge m) keeps 32 / 2048.
+template <int TN, int TK>
+int launch_wgrad_h(const WgradArgsH& a, hipStream_t s)
+{
+    static const char* env = getenv("HN_WGRAD_WCH");          // A/B switches (tools): rows per chunk, workgroup target
+    static const char* envw = getenv("HN_WGRAD_H_WGS");
+    const bool small = TN == 64 && TK == 64;
+    const int wch = env ? atoi(env) : (small ? 32 : 64);
+    const long target = envw ? atol(envw) : (small ? 2048 : 512);
+    return wch == 64 ? launch_wgrad_h_w<TN, TK, 64>(a, s, target) : launch_wgrad_h_w<TN, TK, 32>(a, s, target);
 }
 
 }  // namespace
