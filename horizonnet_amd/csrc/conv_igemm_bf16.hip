@@ -867,333 +867,6 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     }
 }
 
-// ---- 256x256 tile, four phases per K chunk, LDS-DMA in flight ACROSS the barriers ("w8p") -------------------------------------
-// The kernel above waits for its whole next stage (vmcnt(0)) in front of the one barrier of a K chunk, so the DMA queue drains
-// once per chunk and the 64 KB of a stage arrive as one burst that competes with the fragment reads.  Here a stage is four
-// independently recycled 16 KB regions -- the A rows of the waves' upper / lower 64-row halves (A0 / A1) and the B columns of
-// their left / right 32-column halves (B0 / B1) -- and a chunk is four phases, one 64x32 quadrant of every wave's 128x64 tile
-// each (8 MFMAs): (A0,B0), (A0,B1), (A1,B1), (A1,B0).  A region is free again one phase after its last read, so every phase
-// re-fills ONE region (2 DMA instructions per wave): B0 of chunk t+1 in phase 1, A0 / B1 / A1 of chunk t+2 in phases 2-4.  The
-// only wait is a COUNTED one, once per chunk (phase 4: vmcnt(6) = the three newest half-tiles stay in flight), followed by
-// that phase's barrier (raw s_barrier: __syncthreads() would drain the queue) -- the data of chunk t+1 is then complete for
-// every wave.  Same k order per accumulator as the other bf16 kernels: bit-identical outputs (tools/conv_sweep.py asserts it).
-// Chunks past the end are "loaded" with out-of-range offsets (zeros, no memory traffic) so that the instruction counts the
-// vmcnt arithmetic relies on never change.
-// STRICT: the MFMAs of a phase are pinned in front of its barrier (sched_barrier); otherwise the compiler may let them trail
-// into the next phase behind that phase's fragment reads.  Either way every fragment read of a phase has RETURNED (lgkmcnt(0))
-// before the phase's barrier, so the region it came from may be re-filled by any wave right after it.
-// PHASES = 2: the same regions and counted wait with TWO barriers per chunk -- phase X = quadrants (A0,B0), (A0,B1) and the refill
-// of the other buffer's A1 (chunk t + 1), phase Y = quadrants (A1,B1), (A1,B0) from the B fragments still in registers and the
-// refill of A0 / B0 / B1 of this buffer (chunk t + 2); 24 fragment reads per chunk instead of 28.
-template <bool OUT_F32, bool STRICT, int PHASES = 4>
-__global__ __launch_bounds__(512) void conv_igemm_bf16_w8p_kernel(ConvArgsH p)
-{
-    constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 4, NW = 8;
-    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
-    constexpr int REGION = 128 * ROWB;              // one half-tile: 128 rows x 128 bytes
-    constexpr int BUFB = 4 * REGION;                // A0 | A1 | B0 | B1
-    constexpr int R_A0 = 0, R_A1 = REGION, R_B0 = 2 * REGION, R_B1 = 3 * REGION;
-    constexpr int STAGE_BYTES = BUFB;               // (name used by the shared epilogue's static_assert)
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int lrow = tid >> 3;                              // 0..63: region row of loader pass 0 (pass 1: + 64)
-    const int lslot = tid & 7;
-    const int lcol = lslot ^ ((lrow >> 1) & 7);             // source-side swizzle (the same for both passes: 64 keeps bits 1..3)
-
-    int bid = blockIdx.x;
-    if (p.xcd_swizzle) {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int NT = p.Cout / BN;
-    const int nt = bid % NT;
-    const int mt = bid / NT;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
-
-    const int hw_out = p.Ho * p.Wo;
-    const int b_first = m0 / hw_out;
-    const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
-    const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w + (size_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
-
-    // loader rows: entry e = h * 2 + q (half h, pass q): A region row lrow + 64 q <-> tile row q * 128 + h * 64 + lrow;
-    //              B region row lrow + 64 q <-> tile column ((lrow >> 5) + 2 q) * 64 + h * 32 + (lrow & 31)
-    int a_pix0[4], a_hi0[4], a_wi0[4];
-    unsigned w_off[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int h = e >> 1, q = e & 1;
-        const int m = m0 + q * 128 + h * 64 + lrow;
-        if (m < p.M) {
-            const int wo = m % p.Wo;
-            const int t = m / p.Wo;
-            const int ho = t % p.Ho;
-            const int b = t / p.Ho;
-            a_pix0[e] = (b - b_first) * p.Hi * p.Wi;
-            a_hi0[e] = ho * p.sh - p.ph;
-            a_wi0[e] = wo * p.sw - p.pw;
-        } else {
-            a_pix0[e] = -1;
-            a_hi0[e] = 0;
-            a_wi0[e] = 0;
-        }
-        const int ncol = ((lrow >> 5) + 2 * q) * 64 + h * 32 + (lrow & 31);
-        w_off[e] = (unsigned)(ncol * p.K + lcol * 8) * 2u;
-    }
-
-    // A-side state of the chunk that is staged next (chunk index ta): tap (dh, dw), first channel c0, per-entry byte offsets
-    unsigned a_off[4];
-    int dh = 0, dw = 0, c0 = 0, ta = 0;
-    auto tap_offsets = [&]() {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int hi = a_hi0[e] + dh;
-            int wi = a_wi0[e] + dw;
-            wi = wi < 0 ? wi + p.Wi : wi;
-            wi = wi >= p.Wi ? wi - p.Wi : wi;
-            const bool ok = ta < p.nk && a_pix0[e] >= 0 && ((unsigned)hi < (unsigned)p.Hi);
-            const unsigned pix = (unsigned)(a_pix0[e] + hi * p.Wi + wi);
-            a_off[e] = ok ? (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u : OOB;
-        }
-    };
-    auto advance_a = [&]() {            // -> the next chunk's tap / channel block
-        ++ta;
-        c0 += BKE;
-        if (c0 == p.Cin) {
-            c0 = 0;
-            if (++dw == p.KW) { dw = 0; ++dh; }
-        }
-        tap_offsets();
-    };
-    unsigned c0_staged = 0;             // channel offset (bytes) that belongs to a_off (soff of the A DMAs)
-    auto stage_a = [&](int buf, int h) {        // A half h of chunk ta -> region A_h of `buf`
-        char* dst = smem + buf * BUFB + (h ? R_A1 : R_A0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) dma16(rsrc_a, dst + (q * NW + wave) * 1024, a_off[h * 2 + q], c0_staged);
-    };
-    auto stage_b = [&](int buf, int h, int t) {  // B half h of chunk t -> region B_h of `buf`
-        char* dst = smem + buf * BUFB + (h ? R_B1 : R_B0);
-        const bool live = t < p.nk;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) dma16(rsrc_w, dst + (q * NW + wave) * 1024, live ? w_off[h * 2 + q] : OOB, live ? (unsigned)t * (unsigned)ROWB : 0u);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int fr = lane & 31;
-    const int half = lane >> 5;
-    const int fswz = (fr >> 1) & 7;
-
-    // ---- prologue: chunk 0 completely, chunk 1 without its B0 (phase 1 of chunk 0 brings that) ----
-    tap_offsets();
-    c0_staged = (unsigned)c0 * 2u;
-    stage_a(0, 0);
-    stage_a(0, 1);
-    stage_b(0, 0, 0);
-    stage_b(0, 1, 0);
-    advance_a();                        // ta = 1
-    c0_staged = (unsigned)c0 * 2u;
-    stage_a(1, 0);
-    stage_b(1, 1, 1);
-    if (PHASES == 4) {
-        stage_a(1, 1);
-        advance_a();                    // ta = 2
-        c0_staged = (unsigned)c0 * 2u;
-    } else {
-        stage_b(1, 0, 1);               // (two-phase form: A1 of chunk 1 comes in phase X of chunk 0; ta stays 1 until then)
-    }
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // chunk 0's eight pieces have landed (this wave's)
-    asm volatile("s_barrier" ::: "memory");
-    auto phase_end = [&]() {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (STRICT) __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (STRICT) __builtin_amdgcn_sched_barrier(0);
-#endif
-    };
-
-    {
-        u32x4 fa[2][4], fb0[4], fb1[4];
-        auto ld_a = [&](int buf, int h) {
-            const char* base = smem + buf * BUFB + (h ? R_A1 : R_A0) + (wm * 64 + fr) * ROWB;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    fa[i][ks] = *reinterpret_cast<const u32x4*>(base + i * 32 * ROWB + (((2 * ks + half) ^ fswz) * 16));
-        };
-        auto ld_b = [&](u32x4 (&fb)[4], int buf, int h) {
-            const char* base = smem + buf * BUFB + (h ? R_B1 : R_B0) + (wn * 32 + fr) * ROWB;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const u32x4*>(base + (((2 * ks + half) ^ fswz) * 16));
-        };
-        auto mma_q = [&](int ih, int j, const u32x4 (&fb)[4]) {      // quadrant (A half ih, B half j): 8 MFMAs, k ascending per accumulator
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[ih * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][ks]), __builtin_bit_cast(bf16x8, fb[ks]),
-                                                                                 acc[ih * 2 + i][j], 0, 0, 0);
-        };
-        if (PHASES == 2) {
-            for (int t = 0; t < p.nk; ++t) {
-                const int buf = t & 1;
-                // phase X: quadrants (A0,B0), (A0,B1); A1 of the other buffer (last read in phase Y of chunk t - 1) <- chunk t + 1
-                ld_a(buf, 0);
-                ld_b(fb0, buf, 0);
-                ld_b(fb1, buf, 1);
-                stage_a(buf ^ 1, 1);            // a_off / c0_staged describe chunk ta = t + 1 here
-                advance_a();                    // ta = t + 2
-                c0_staged = (unsigned)c0 * 2u;
-                mma_q(0, 0, fb0);
-                mma_q(0, 1, fb1);
-                phase_end();
-                // phase Y: quadrants (A1,B1), (A1,B0); A0 / B0 / B1 of this buffer (last read in phase X) <- chunk t + 2
-                ld_a(buf, 1);
-                stage_a(buf, 0);
-                stage_b(buf, 0, t + 2);
-                stage_b(buf, 1, t + 2);
-                mma_q(1, 1, fb1);
-                mma_q(1, 0, fb0);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // all but this phase's three half-tiles: chunk t + 1 is complete
-                phase_end();
-            }
-        } else
-        for (int t = 0; t < p.nk; ++t) {
-            const int buf = t & 1;
-            // phase 1: quadrant (A0, B0); refill B0 of the other buffer with chunk t + 1
-            ld_a(buf, 0);
-            ld_b(fb0, buf, 0);
-            stage_b(buf ^ 1, 0, t + 1);
-            mma_q(0, 0, fb0);
-            phase_end();
-            // phase 2: quadrant (A0, B1); A0 of this buffer is free: chunk t + 2
-            ld_b(fb1, buf, 1);
-            stage_a(buf, 0);
-            mma_q(0, 1, fb1);
-            phase_end();
-            // phase 3: quadrant (A1, B1); B1 of this buffer is free: chunk t + 2
-            ld_a(buf, 1);
-            stage_b(buf, 1, t + 2);
-            mma_q(1, 1, fb1);
-            phase_end();
-            // phase 4: quadrant (A1, B0); A1 of this buffer is free: chunk t + 2.  Counted wait: everything but the three
-            // half-tiles of chunk t + 2 has landed, i.e. chunk t + 1 is complete once every wave has passed the barrier
-            ld_b(fb0, buf, 0);
-            stage_a(buf, 1);
-            advance_a();
-            c0_staged = (unsigned)c0 * 2u;
-            mma_q(1, 0, fb0);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            phase_end();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filling dummies of the last chunks, before LDS is reused
-        __syncthreads();
-    }
-
-    // ---- epilogue: identical to conv_igemm_bf16_w8_kernel<256, 256, 2, 4> ----
-    constexpr int CS = BN + 4;
-    constexpr int SLAB = 32 * CS;                           // floats
-    static_assert(WAVES_M * SLAB * 4 <= 2 * STAGE_BYTES, "C slabs must fit in the staging LDS");
-    constexpr int TPR = BN / 8;
-    constexpr int RPP = 512 / TPR;
-    constexpr int NPASS = WAVES_M * 32 / RPP;
-    float* cs = reinterpret_cast<float*>(smem);
-    const int ccol = (tid % TPR) * 8;
-    const int crow = tid / TPR;
-    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
-    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol + 4);
-    const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
-    const f32x4 sf1 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol + 4);
-    const bool has_res = p.res != nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        u32x4 rres[NPASS];
-        if (has_res) {
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int sr = crow + ps * RPP;
-                const int m = m0 + (sr >> 5) * WM + i * 32 + (sr & 31);
-                const int mc = m < p.M ? m : p.M - 1;
-                rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
-            }
-        }
-        if (i > 0) __syncthreads();
-        {
-            float* c_w = cs + wm * SLAB + (4 * half) * CS + wn * WN + fr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c_w[((r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int sr = crow + ps * RPP;
-            const int m = m0 + (sr >> 5) * WM + i * 32 + (sr & 31);
-            const float* src = cs + (sr >> 5) * SLAB + (sr & 31) * CS + ccol;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-            v0 = v0 * sc0 + sf0;
-            v1 = v1 * sc1 + sf1;
-            if (has_res) {
-                const u32x4 rr = rres[ps];
-                v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
-                v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
-            }
-            if (m < p.M) {
-                if (OUT_F32) {
-                    float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n0 + ccol;
-                    *reinterpret_cast<f32x4*>(yo) = v0;
-                    *reinterpret_cast<f32x4*>(yo + 4) = v1;
-                } else {
-                    u32x4 o;
-                    o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
-                    o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + n0 + ccol) = o;
-                }
-            }
-        }
-    }
-}
-
-template <bool OUT_F32, bool STRICT, int PHASES = 4>
-int launch_w8p(const ConvArgsH& a, hipStream_t s)
-{
-    const size_t lds = 2 * 4 * (size_t)128 * ROWB;          // 128 KB
-    auto kern = conv_igemm_bf16_w8p_kernel<OUT_F32, STRICT, PHASES>;
-    static bool attr_done[64] = {};   // per instantiation, per device
-    int dev = 0;
-    HN_HIP(hipGetDevice(&dev));
-    if (dev < 64 && !attr_done[dev]) {
-        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[dev] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(hn_cdiv(a.M, 256) * (a.Cout / 256))), dim3(512), lds, s, a);
-    HN_LAUNCH_CHECK();
-    return 0;
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false>
 int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
 {
@@ -1236,10 +909,6 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     const long t128x256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 128) * (Cout / 256) : 0;
     const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
     if (force == 1 && t256) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
-    if (force == 4 && t256) return launch_w8p<OUT_F32, true>(a, s);
-    if (force == 5 && t256) return launch_w8p<OUT_F32, false>(a, s);
-    if (force == 6 && t256) return launch_w8p<OUT_F32, false, 2>(a, s);
-    if (force == 7 && t256) return launch_w8p<OUT_F32, true, 2>(a, s);
     if (force == 2 && t256x128) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
     if (force == 3 && t128x256) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
     // measured on every conv shape of the B = 32 forward (tools/conv_sweep.py, profiles/r2_conv_tile_sweep.txt): the

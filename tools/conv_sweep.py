@@ -1,9 +1,9 @@
 """Per-layer tile sweep of the bf16 implicit-GEMM convolution on the network's real shapes (MEASUREMENT TOOL).
 
 For every distinct conv shape of the B=32 forward it times hn_conv2d_nhwc_bf16 with the 4-wave kernels (HN_BF16_W8=0)
-and each legal 8-wave tile (1: 256x256, 2: 256x128, 3: 128x256; 4 / 5: the four-phase 256x256 kernel with LDS-DMA in flight
-across barriers, MFMAs pinned per phase / free), HIP events around `iters` back-to-back launches, and prints TF/s + the winner
--- the data behind the dispatch heuristic in conv_igemm_bf16.hip.  SWEEP_VARIANTS / SWEEP_ONLY select columns / layers.
+and each legal 8-wave tile (1: 256x256, 2: 256x128, 3: 128x256), HIP events around `iters` back-to-back launches, and prints
+TF/s + the winner -- the data behind the dispatch heuristic in conv_igemm_bf16.hip.  SWEEP_VARIANTS / SWEEP_ONLY select
+columns / layers.  (Variants 4-7 of profiles/r2_conv_tile_sweep.txt were the phased kernels of commit 053652b, since removed.)
 """
 import os
 import sys
@@ -78,7 +78,7 @@ def run(shape, variant, iters=10):
 
 
 def main():
-    print("# bf16 conv tile sweep, B=%d; columns = HN_BF16_W8 variants %s (0: 4-wave kernels, 1: 256x256, 2: 256x128, 3: 128x256, 4 / 5: phased 256x256 strict / free, 6 / 7: two-phase free / strict, -1: dispatch heuristic); ms, TF/s" % (B, os.environ.get("SWEEP_VARIANTS", "0,1,2,3,-1")))
+    print("# bf16 conv tile sweep, B=%d; columns = HN_BF16_W8 variants %s (0: 4-wave kernels, 1: 256x256, 2: 256x128, 3: 128x256, -1: dispatch heuristic); ms, TF/s" % (B, os.environ.get("SWEEP_VARIANTS", "0,1,2,3,-1")))
     tot = {0: 0.0, "best": 0.0, "auto": 0.0}
     only = [t for t in os.environ.get("SWEEP_ONLY", "").split(",") if t]
     variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "0,1,2,3,-1").split(",")]
@@ -88,7 +88,7 @@ def main():
             continue
         row, best, ref = [], None, None
         for v in variants:
-            legal = v in (0, -1) or (v in (1, 3, 4, 5, 6, 7) and cout % 256 == 0) or (v == 2 and cout % 128 == 0)
+            legal = v in (0, -1) or (v in (1, 3) and cout % 256 == 0) or (v == 2 and cout % 128 == 0)
             if not legal:
                 row.append("      -      ")
                 continue
