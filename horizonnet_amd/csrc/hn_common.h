@@ -36,6 +36,32 @@ constexpr int HN_STATUS_WORD = 512;
 
 constexpr size_t HN_HEAD_BWD_SCRATCH_FLOATS = 32 * 12 * 1024 + 32 * 12;   // hn_launch_head_bwd: row-slice partials behind dlin
 
+// The persistent LSTM kernels hand data between workgroups inside one launch: ALL workgroups of the grid must be resident at
+// once (a plain launch does not check that; on a partitioned GPU -- CPX mode, fewer CUs -- they would spin into their time-out
+// and report through the status word).  Checked once per kernel and device against the occupancy query, as a cooperative
+// launch would, without that launch's ~17 us of host time per call.
+template <class Kernel>
+static inline int hn_require_coresident(Kernel kern, int grid, int threads, const char* what)
+{
+    static const void* ok[64][4] = {};      // kernels already checked on a device (the template is per signature, not per kernel)
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    const void* id = reinterpret_cast<const void*>(kern);
+    if (dev >= 0 && dev < 64)
+        for (int i = 0; i < 4; ++i)
+            if (ok[dev][i] == id) return 0;
+    int per_cu = 0, cus = 0;
+    HN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
+    HN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HN_REQUIRE((long)per_cu * cus >= grid,
+               "%s: the persistent kernel needs its %d workgroups resident at once, this device offers %d compute units x %d workgroups "
+               "(partitioned GPU?)", what, grid, cus, per_cu);
+    if (dev >= 0 && dev < 64)
+        for (int i = 0; i < 4; ++i)
+            if (ok[dev][i] == nullptr) { ok[dev][i] = id; break; }
+    return 0;
+}
+
 static inline int hn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- internal launchers (defined in the .hip files, used by engine.hip) ----

@@ -35,7 +35,13 @@ static_assert(2 * CNT_SHARDS * CNT_STRIDE <= HN_STATUS_WORD && HN_STATUS_WORD < 
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate nonlinearities sit on every step's critical path (128 gate threads, nothing to overlap them with): hardware exp2 / rcp
+// (v_exp_f32, v_rcp_f32, ~1 ulp each) instead of libm's expf / tanhf and an IEEE division -- absolute error ~2e-7 per gate, the
+// size of the difference between two libm implementations (torch's CPU path uses a vectorised approximation as well); the
+// layer-output tap stays within 1e-5 of the reference's (tests/test_gpu_parity.py).  Saturation is exact (exp -> inf, rcp -> 0).
+__device__ __forceinline__ float fast_exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp_(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp_(2.0f * x)); }
 
 template <int BT>   // 16-row batch tiles per launch (1: <=16 panoramas, 2: <=32)
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ gx, const float* __restrict__ whh_f,
@@ -151,17 +157,17 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
             }
             const float ig = sigmoidf_(pre[0]);
             const float fg = sigmoidf_(pre[1]);
-            const float gg = tanhf(pre[2]);
+            const float gg = tanhf_(pre[2]);
             const float og = sigmoidf_(pre[3]);
             c_state = fg * c_state + ig * gg;
-            const float h = og * tanhf(c_state);
+            const float h = og * tanhf_(c_state);
+            if (gate_live)      // write-through (sc1) store: visible to every XCD once the wave's vmcnt drains
+                __hip_atomic_store(y + ((size_t)t * B + b0 + gb) * 1024 + dir * LSTM_H + u0 + gu, h, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             if (gate_live && save) {   // training: keep (i, f, g, o, c) for the adjoint pass -- [t][b][dir][5][512]
                 float* sv = save + ((((size_t)t * B + b0 + gb) * 2 + dir) * 5) * LSTM_H + u0 + gu;
                 sv[0] = ig; sv[LSTM_H] = fg; sv[2 * LSTM_H] = gg; sv[3 * LSTM_H] = og; sv[4 * LSTM_H] = c_state;
             }
-            if (gate_live)      // write-through (sc1) store: visible to every XCD once the wave's vmcnt drains
-                __hip_atomic_store(y + ((size_t)t * B + b0 + gb) * 1024 + dir * LSTM_H + u0 + gu, h, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
         }
 
         // publish h_t: every storing wave drains its write-through stores, then ONE lane arrives
@@ -252,6 +258,9 @@ int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int bc = (B - b0) < 32 ? (B - b0) : 32;
         HN_HIP(hipMemsetAsync(sync, 0, STATUS_WORD * sizeof(unsigned), s));   // counters only; status is sticky
+        if (int rc = bc <= 16 ? hn_require_coresident(lstm_layer_kernel<1>, 2 * LSTM_NB, 256, "LSTM recurrence")
+                              : hn_require_coresident(lstm_layer_kernel<2>, 2 * LSTM_NB, 256, "LSTM recurrence"))
+            return rc;
         if (bc <= 16)
             hipLaunchKernelGGL(lstm_layer_kernel<1>, dim3(2 * LSTM_NB), dim3(256), 0, s, gx, whh_f, whh_r, y, T, B, b0, bc, sync, save);
         else

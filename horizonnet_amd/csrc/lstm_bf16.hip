@@ -37,7 +37,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 typedef unsigned long long u64;
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate nonlinearities on the step's critical path (16 lanes per wave, nothing to overlap them with): hardware exp2 / rcp
+// (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of libm's expf / tanhf / IEEE division -- a few 1e-7 of difference on values that
+// are rounded to bf16 (2^-9) before they re-enter the recurrence.  Saturation is exact: exp -> inf gives rcp -> 0.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp(2.0f * x)); }
 __device__ __forceinline__ unsigned bf16_rn(float x)
 {
     unsigned r;
@@ -146,28 +151,33 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __res
 
         if (gate_lane) {
             unsigned packed = 0;
+            float hval[BPG], gsave[BPG][4];
 #pragma unroll
             for (int r = 0; r < BPG; ++r) {
                 const float ig = sigm(gxv[r][0] + acc[0][r]);
                 const float fg = sigm(gxv[r][1] + acc[1][r]);
-                const float gg = tanhf(gxv[r][2] + acc[2][r]);
+                const float gg = tanh_fast(gxv[r][2] + acc[2][r]);
                 const float og = sigm(gxv[r][3] + acc[3][r]);
                 c_state[r] = fg * c_state[r] + ig * gg;
-                const float h = og * tanhf(c_state[r]);
+                hval[r] = og * tanh_fast(c_state[r]);
+                gsave[r][0] = ig; gsave[r][1] = fg; gsave[r][2] = gg; gsave[r][3] = og;
+                if (r < nvalid) packed |= bf16_rn(hval[r]) << (16 * r);
+            }
+            // publish FIRST (the peers' next step waits for it): ONE write-through 8-byte store per unit, tag = step + 1 (never 0)
+            u64* dst = slots + (size_t)(step & 1) * NGRP * LH + u0 + col;
+            __hip_atomic_store(dst, ((u64)(unsigned)(step + 1) << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < BPG; ++r) {
                 if (r < nvalid) {
                     const size_t o = ((size_t)t * B + b0 + bfirst + r) * 1024 + dir * LH + u0 + col;
                     if (save) {      // training: post-activation gates + cell state for the adjoint, [t][b][dir][5][512]
                         float* sv = save + (((size_t)t * B + b0 + bfirst + r) * 2 + dir) * 5 * LH + u0 + col;
-                        sv[0] = ig; sv[LH] = fg; sv[2 * LH] = gg; sv[3 * LH] = og; sv[4 * LH] = c_state[r];
+                        sv[0] = gsave[r][0]; sv[LH] = gsave[r][1]; sv[2 * LH] = gsave[r][2]; sv[3 * LH] = gsave[r][3]; sv[4 * LH] = c_state[r];
                     }
-                    y[o] = h;
-                    if (y_h) y_h[o] = (u16)bf16_rn(h);
-                    packed |= bf16_rn(h) << (16 * r);
+                    y[o] = hval[r];
+                    if (y_h) y_h[o] = (u16)bf16_rn(hval[r]);
                 }
             }
-            // publish: ONE write-through 8-byte store per unit, tag = step + 1 (never 0)
-            u64* dst = slots + (size_t)(step & 1) * NGRP * LH + u0 + col;
-            __hip_atomic_store(dst, ((u64)(unsigned)(step + 1) << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -278,31 +288,36 @@ __global__ __launch_bounds__(256) void lstm_layer_bwd_bf16_kernel(const float* _
 
         if (gate_lane) {
             unsigned packed[4] = {0u, 0u, 0u, 0u};
+            float g[BPG][4];
 #pragma unroll
             for (int r = 0; r < BPG; ++r) {
                 const float ig = sv[r][0], fg = sv[r][1], gg = sv[r][2], og = sv[r][3];
                 const float dh = dyv[r] + acc[r];
-                const float tc = tanhf(sv[r][4]);
+                const float tc = tanh_fast(sv[r][4]);
                 const float dc = dc_rec[r] + dh * og * (1.f - tc * tc);
-                float g[4];
-                g[0] = dc * gg * ig * (1.f - ig);
-                g[1] = dc * cprev[r] * fg * (1.f - fg);
-                g[2] = dc * ig * (1.f - gg * gg);
-                g[3] = dh * tc * og * (1.f - og);
+                g[r][0] = dc * gg * ig * (1.f - ig);
+                g[r][1] = dc * cprev[r] * fg * (1.f - fg);
+                g[r][2] = dc * ig * (1.f - gg * gg);
+                g[r][3] = dh * tc * og * (1.f - og);
                 dc_rec[r] = dc * fg;
                 if (r < nvalid) {
-                    float* gp = dgx + ((size_t)t * B + b0 + bfirst + r) * 4096 + dir * GR + unit;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        gp[k * LH] = g[k];
-                        packed[k] |= bf16_rn(g[k]) << (16 * r);
-                    }
+                    for (int k = 0; k < 4; ++k) packed[k] |= bf16_rn(g[r][k]) << (16 * r);
                 }
             }
+            // publish FIRST (the peers' next step waits for these), then the float32 copies for the weight-gradient GEMMs
             u64* dst = slots + (size_t)(step & 1) * NGRP * GR + unit;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 __hip_atomic_store(dst + k * LH, ((u64)(unsigned)(step + 1) << 32) | packed[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < BPG; ++r) {
+                if (r < nvalid) {
+                    float* gp = dgx + ((size_t)t * B + b0 + bfirst + r) * 4096 + dir * GR + unit;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gp[k * LH] = g[r][k];
+                }
+            }
         }
     }
 }
@@ -321,6 +336,7 @@ int hn_launch_lstm_layer_bwd_bf16(const float* saved, const float* dy, const voi
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int bc = (B - b0) < 32 ? (B - b0) : 32;
         HN_HIP(hipMemsetAsync(xch, 0, hn_lstm_bwd_bf16_xch_bytes(), s));
+        if (int rc = hn_require_coresident(lstm_layer_bwd_bf16_kernel, NGRP * GRP, 256, "bf16 LSTM adjoint")) return rc;
         hipLaunchKernelGGL(lstm_layer_bwd_bf16_kernel, dim3(NGRP * GRP), dim3(256), 0, s, saved, dy, reinterpret_cast<const u16*>(whhT_f),
                            reinterpret_cast<const u16*>(whhT_r), dgx, reinterpret_cast<u64*>(xch), T, B, b0, bc,
                            reinterpret_cast<unsigned*>(sync_ws));
@@ -341,6 +357,7 @@ int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* wh
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int bc = (B - b0) < 32 ? (B - b0) : 32;
         HN_HIP(hipMemsetAsync(xch, 0, hn_lstm_bf16_xch_bytes(), s));       // every tag back to 0 before every launch
+        if (int rc = hn_require_coresident(lstm_layer_bf16_kernel, NGRP * GRP, 256, "bf16 LSTM recurrence")) return rc;
         hipLaunchKernelGGL(lstm_layer_bf16_kernel, dim3(NGRP * GRP), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
                            reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), reinterpret_cast<u64*>(xch), T, B, b0,
                            bc, reinterpret_cast<unsigned*>(sync_ws), save);
