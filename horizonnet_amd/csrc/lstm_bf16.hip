@@ -14,7 +14,8 @@
 //   * per step a member needs h_{t-1} of ITS TWO panoramas only: 2 x 512 bf16 = 2 KB, published by the 8 members as 512
 //     eight-byte {tag, value} granules (cdna guide G16 form R2: the data is the flag -- one write-through store per
 //     granule, no counter, no fence, no drain on the critical path; tag = step + 1, two slots by step parity).  One wave
-//     sweeps the 512 granules (8 coalesced 8-byte sc1 loads per lane) until every tag matches, spreads h into LDS, and all
+//     sweeps the 512 granules until every tag matches, spreads h into LDS (every wave a quarter: 2 coalesced 8-byte sc1 loads per
+//     lane), and all
 //     four waves run 64 MFMAs each (A = h rows, 2 of the 16 MFMA rows live).
 //   * gates, cell state (registers of the 16 lanes that own the live accumulator rows) and the float32 layer output y are
 //     float32; h is rounded to bf16 only where it re-enters the matrix cores (recurrence, next layer's input GEMM).
@@ -110,15 +111,16 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __res
 
         if (step > 0) {
             const int par = step & 1;
-            if (wave == 0) {
-                // sweep the group's 512 granules of step-1 (tag == step) until all have landed, then spread h into LDS
-                const u64* src = slots + (size_t)((step - 1) & 1) * NGRP * LH;
-                unsigned v[8];
+            {
+                // every wave sweeps ITS quarter of the group's 512 granules of step-1 (tag == step) until all have landed, then
+                // spreads that quarter of h into LDS: 2 coalesced 8-byte sc1 loads and 4 LDS stores per lane and sweep
+                const u64* src = slots + (size_t)((step - 1) & 1) * NGRP * LH + wave * 128;
+                unsigned v[2];
                 unsigned spins = 0;
                 for (;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < 2; ++k) {
                         const u64 x = __hip_atomic_load(src + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         v[k] = (unsigned)x;
                         ok = ok && (unsigned)(x >> 32) == (unsigned)step;
@@ -131,9 +133,9 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __res
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    hs[par][0][k * 64 + lane] = (u16)(v[k] & 0xffffu);
-                    hs[par][1][k * 64 + lane] = (u16)(v[k] >> 16);
+                for (int k = 0; k < 2; ++k) {
+                    hs[par][0][wave * 128 + k * 64 + lane] = (u16)(v[k] & 0xffffu);
+                    hs[par][1][wave * 128 + k * 64 + lane] = (u16)(v[k] >> 16);
                 }
             }
             __syncthreads();
