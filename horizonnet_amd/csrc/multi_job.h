@@ -52,8 +52,10 @@ inline MJob mj_make(int kind, const void* src, void* dst, long long total)
 // Engine-owned device copy of one job list.  `run` uploads the list only when it differs from the last one it ran (the
 // pointers are stable from step to step: bound parameters, one workspace, the caching allocator's gradient buffer).
 struct JobTable {
-    std::vector<MJob> last;
+    std::vector<MJob> last;  // what the device copy holds
     void* dev = nullptr;
+    void* host = nullptr;    // page-locked staging copy: the upload is a true asynchronous copy
+    hipEvent_t uploaded = nullptr;   // recorded behind the last upload; waited for before the staging copy is overwritten
     size_t cap = 0;          // jobs
     int run(std::vector<MJob>& jobs, hipStream_t s);
     void release();

@@ -129,16 +129,21 @@ int JobTable::run(std::vector<MJob>& jobs, hipStream_t s)
     const bool same = last.size() == jobs.size() && memcmp(last.data(), jobs.data(), jobs.size() * sizeof(MJob)) == 0;
     if (!same || dev == nullptr) {
         if (jobs.size() > cap) {
-            // (hipFree waits for the device: nothing can still be reading the old table)
+            // (hipFree waits for the device: nothing can still be reading the old table or the old staging copy)
             if (dev) HN_HIP(hipFree(dev));
-            dev = nullptr;
+            if (host) HN_HIP(hipHostFree(host));
+            dev = host = nullptr;
             cap = jobs.size() + 16;
             HN_HIP(hipMalloc(&dev, cap * sizeof(MJob)));
+            HN_HIP(hipHostMalloc(&host, cap * sizeof(MJob), hipHostMallocDefault));
         }
+        if (uploaded == nullptr) HN_HIP(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
+        else HN_HIP(hipEventSynchronize(uploaded));       // the previous upload has read the staging copy
+        memcpy(host, jobs.data(), jobs.size() * sizeof(MJob));
         last = jobs;
-        // stream-ordered behind any launch still reading the previous list; the source is pageable host memory, which the
-        // runtime stages before returning, so `last` may change afterwards
-        HN_HIP(hipMemcpyAsync(dev, last.data(), last.size() * sizeof(MJob), hipMemcpyHostToDevice, s));
+        // stream-ordered behind any launch still reading the previous list
+        HN_HIP(hipMemcpyAsync(dev, host, jobs.size() * sizeof(MJob), hipMemcpyHostToDevice, s));
+        HN_HIP(hipEventRecord(uploaded, s));
     }
     hipLaunchKernelGGL(multi_job_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const MJob*>(dev), (int)jobs.size());
     HN_LAUNCH_CHECK();
@@ -148,7 +153,10 @@ int JobTable::run(std::vector<MJob>& jobs, hipStream_t s)
 void JobTable::release()
 {
     if (dev) (void)hipFree(dev);
-    dev = nullptr;
+    if (host) (void)hipHostFree(host);
+    if (uploaded) (void)hipEventDestroy(uploaded);
+    dev = host = nullptr;
+    uploaded = nullptr;
     cap = 0;
     last.clear();
 }
