@@ -203,6 +203,29 @@ extern "C" int hn_destroy(hn_engine* e)
     return 0;
 }
 
+// Host step of the Manhattan fit (see the header): two-pointer form of the reference's span matrix, float64 throughout.
+extern "C" int hn_vote_scan(const double* v, int L, double tol, int32_t* best3)
+{
+    HN_REQUIRE(v != nullptr && best3 != nullptr && L >= 0, "hn_vote_scan: bad argument");
+    int best_span = -1, best_i = -1, best_j = -1;
+    int j = 0;
+    for (int i = 0; i < L; ++i) {
+        if (j < i) j = i;
+        while (j + 1 < L && !((v[j + 1] - v[i]) + 1e-9 > tol)) ++j;      // largest j with (v_j - v_i) + 1e-9 <= tol
+        if (j == i && 0.0 > tol) continue;
+        const int span = j - i + 1;
+        if (!((double)span < (double)L * 0.4) && span > best_span) {
+            best_span = span;
+            best_i = i;
+            best_j = j;
+        }
+    }
+    best3[0] = best_span;
+    best3[1] = best_i;
+    best3[2] = best_j;
+    return 0;
+}
+
 extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
 {
     HN_REQUIRE(e != nullptr && name != nullptr, "hn_set_option: null argument");

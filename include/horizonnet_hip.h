@@ -239,6 +239,15 @@ int hn_augment_batch(const unsigned char* data, int n_images, const int* index, 
 int hn_find_peaks(const float* signal, int B, int n, int r, float min_v, int apply_sigmoid,
                   uint8_t* mask, float* prob, void* stream);
 
+/* ---- host step of the Manhattan fit: misc/post_proc.py:75-98 (`vote`) ------------------- */
+
+/* HOST function (no device work, no stream): the decision loop of the reference's `vote` on an ascending float64 sample
+ * vector -- the longest run v[i..j] with (v[j] - v[i]) + 1e-9 <= tol that covers at least 40 % of the samples, first maximum in
+ * (i, j) row-major order as post_proc.py:78-90's N x N span matrix finds it.  best3 = {span, i, j} (span = -1: none).  The
+ * means / medians around it stay in numpy (horizonnet_amd/postproc.py) so that every rounding is the reference's; the loop is
+ * what took 2/3 of the host time of inference.py:89-141 per panorama. */
+int hn_vote_scan(const double* sorted_samples, int L, double tol, int32_t* best3);
+
 /* ---- per-stage entry points (used by the parity tests; the engine calls the same code) */
 
 /* OIHW -> packed [Cout][kh][kw][Cin] (stem 7x7: [64][7][8][4] zero padded). */

@@ -171,3 +171,36 @@ def test_product_never_imports_oracle_postproc():
     for name in ("horizonnet_amd.inference", "horizonnet_amd.postproc"):
         src = open(importlib.import_module(name).__file__).read()
         assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_native_vote_scan_equals_interpreted_loop():
+    """hn_vote_scan (host function of the native library) makes exactly the decisions of the interpreted two-pointer loop --
+    which test_vote_equals_dense_reference_formulation ties to the reference's N x N span matrix (post_proc.py:75-98) -- on
+    clustered / uniform / constant / tiny vectors and zero / negative / huge tolerances."""
+    import ctypes
+    from horizonnet_amd import _lib
+    rng = np.random.RandomState(3)
+    L = _lib.load()
+    best = (ctypes.c_int32 * 3)()
+    n = 0
+    for trial in range(400):
+        k = int(rng.choice([1, 2, 3, 5, 17, 64, 200]))
+        kind = trial % 4
+        if kind == 0:
+            v = rng.normal(0, 1, k)
+        elif kind == 1:
+            v = np.concatenate([rng.normal(5, 0.01, k), rng.uniform(-50, 50, max(1, k // 3))])
+        elif kind == 2:
+            v = np.full(k, 3.25)
+        else:
+            v = np.round(rng.uniform(0, 4, k), 1)                       # many exact ties
+        v = np.sort(v.astype(np.float64))
+        for tol in (0.0, -1.0, 1e-9, 0.05, 0.5, 3.0, 1e6, float(len(v)) + 0.5):
+            want = pp._vote_scan_py(v, tol)
+            _lib.check(L.hn_vote_scan(v.ctypes.data, len(v), float(tol), ctypes.addressof(best)), "hn_vote_scan")
+            assert (int(best[0]), int(best[1]), int(best[2])) == want, (v, tol)
+            n += 1
+    assert n == 3200
+    # and the float32 route stays on the interpreted loop (numpy scalar arithmetic in the array's own type)
+    v32 = np.sort(rng.normal(0, 1, 50).astype(np.float32))
+    assert pp.vote(v32, 0.3)[1] == pp._vote_scan_py(v32, 0.3)[0] / 50 or pp.vote(v32, 0.3)[1] == 0
