@@ -164,12 +164,36 @@ def _usable_cores():
     return n
 
 
+_SHM = {"bon": None, "cor": None, "mask": None}      # process-shared signal buffers (created before the pool forks)
+_SHM_B, _SHM_W, _SHM_MASKS = 256, 1024, 2
+
+
+def _shared_signals():
+    """numpy views [B,2,W] f32, [B,W] f32, [masks,B,W] u8 over anonymous shared memory; the fit workers inherit them at fork."""
+    if _SHM["bon"] is None:
+        import ctypes
+        import multiprocessing as mp
+        _SHM["bon"] = np.frombuffer(mp.RawArray(ctypes.c_float, _SHM_B * 2 * _SHM_W), np.float32).reshape(_SHM_B, 2, _SHM_W)
+        _SHM["cor"] = np.frombuffer(mp.RawArray(ctypes.c_float, _SHM_B * _SHM_W), np.float32).reshape(_SHM_B, _SHM_W)
+        _SHM["mask"] = np.frombuffer(mp.RawArray(ctypes.c_uint8, _SHM_MASKS * _SHM_B * _SHM_W), np.uint8).reshape(_SHM_MASKS, _SHM_B, _SHM_W)
+    return _SHM["bon"], _SHM["cor"], _SHM["mask"]
+
+
+def _fit_shared(task):
+    """Worker side of the shared-memory hand-over: panorama b of the batch lying in the shared buffers."""
+    b, W, H, force_cuboid, force_raw, min_v, r, keys = task
+    bon, cor, mask = _shared_signals()
+    return layout_from_signals(bon[b, :, :W].copy(), cor[b, :W].copy(), H, W, force_cuboid, force_raw, min_v, r,
+                               _MaskPeaks({k: mask[i, b, :W].copy() for i, k in enumerate(keys)}))
+
+
 def _fit_pool(workers):
-    """Process pool for the host Manhattan fit (pure numpy; the workers never touch the GPU)."""
+    """Process pool for the host Manhattan fit (numpy + the native vote scan; the workers never touch the GPU)."""
     import multiprocessing as mp
     if _POOL["pool"] is None or _POOL["n"] != workers:
         if _POOL["pool"] is not None:
             _POOL["pool"].terminate()
+        _shared_signals()                    # must exist BEFORE the fork so that parent and workers map the same pages
         _POOL["pool"] = mp.get_context("fork").Pool(workers)
         _POOL["n"] = workers
     return _POOL["pool"]
@@ -237,22 +261,32 @@ def _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth):
     return {"event": ev, "bon": h_bon, "cor": h_cor, "mask": h_mask, "keys": keys, "B": B, "keep": (bon, prob)}
 
 
-def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers):
-    """Host half: wait for THIS batch's copies, then the Manhattan fits (worker processes for batches of 8 or more)."""
+def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals=False):
+    """Host half: wait for THIS batch's copies, then the Manhattan fits (worker processes for batches of 8 or more).
+    shared_signals: hand the batch to the workers through shared memory (three memcpys + one small tuple per panorama)
+    instead of pickling five arrays per panorama in the calling thread."""
     st["event"].synchronize()
     B = st["B"]
     y_bon, y_cor, masks = st["bon"].numpy(), st["cor"].numpy(), st["mask"].numpy()
-    jobs = [(y_bon[b].copy(), y_cor[b].copy(), H, W, force_cuboid, force_raw, min_v, r,
-             {k: masks[i, b].copy() for i, k in enumerate(st["keys"])}) for b in range(B)]
     if workers is None:
         workers = min(_usable_cores(), 32) if B >= 8 else 0
+    if shared_signals and workers > 1 and B <= _SHM_B and W <= _SHM_W and len(st["keys"]) <= _SHM_MASKS:
+        pool = _fit_pool(workers)            # (creates the shared buffers before forking)
+        sb, sc, sm = _shared_signals()
+        sb[:B, :, :W] = y_bon
+        sc[:B, :W] = y_cor
+        sm[:len(st["keys"]), :B, :W] = masks
+        tasks = [(b, W, H, force_cuboid, force_raw, min_v, r, tuple(st["keys"])) for b in range(B)]
+        return pool.map(_fit_shared, tasks, chunksize=max(1, -(-B // workers)))     # blocking: the buffers are free again on return
+    jobs = [(y_bon[b].copy(), y_cor[b].copy(), H, W, force_cuboid, force_raw, min_v, r,
+             {k: masks[i, b].copy() for i, k in enumerate(st["keys"])}) for b in range(B)]
     if workers <= 1:
         return [_fit_one(j) for j in jobs]
     return _fit_pool(workers).map(_fit_one, jobs, chunksize=max(1, B // (4 * workers)))
 
 
 def inference_batch(net, x, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
-                    peaks_fn=None, workers=None):
+                    peaks_fn=None, workers=None, shared_signals=False):
     """x [B,3,512,1024]: one engine forward for all B x augmentations, ONE peak-detection launch per threshold for the
     whole batch (hn_find_peaks), then the host Manhattan fit of the B panoramas spread over `workers` processes
     (default: the usable host cores, inline for small batches; 0 = inline).  -> list of (cor_id, z0, z1), identical to
@@ -263,16 +297,18 @@ def inference_batch(net, x, device, flip=False, rotate=[], force_cuboid=False, f
         _, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
         return [layout_from_signals(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn) for b in range(B)]
     st = _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth=1)
-    return _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers)
+    return _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals)
 
 
 def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
-                     workers=None, depth=2):
+                     workers=None, depth=2, shared_signals=False):
     """Pipelined ``inference_batch`` over an iterable of batches x [B,3,512,1024]: yields one list of (cor_id, z0, z1) per
     batch, in order, identical to ``inference_batch`` batch by batch.  The device half of the next `depth - 1` batches
     (forward, peaks, copies to pinned memory: all asynchronous) is enqueued BEFORE the host half of the current one (the
     Manhattan fits) runs, so the GPU works on batch i + 1 while the host cores fit batch i -- the per-batch loop of
-    inference.py:187-209 leaves each side idle while the other works."""
+    inference.py:187-209 leaves each side idle while the other works.  shared_signals=True hands the batch to the fit workers
+    through shared memory instead of pickles (same results, tests/test_postproc_cpu.py; off by default until it has been timed
+    on the target box)."""
     from collections import deque
     pending = deque()
     for x in batches:
@@ -280,7 +316,7 @@ def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=F
         pending.append((_stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth), H, W))
         if len(pending) >= depth:
             st, h, w = pending.popleft()
-            yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers)
+            yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals)
     while pending:
         st, h, w = pending.popleft()
-        yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers)
+        yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals)

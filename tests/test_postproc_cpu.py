@@ -204,3 +204,43 @@ def test_native_vote_scan_equals_interpreted_loop():
     # and the float32 route stays on the interpreted loop (numpy scalar arithmetic in the array's own type)
     v32 = np.sort(rng.normal(0, 1, 50).astype(np.float32))
     assert pp.vote(v32, 0.3)[1] == pp._vote_scan_py(v32, 0.3)[0] / 50 or pp.vote(v32, 0.3)[1] == 0
+
+
+def test_host_half_pooled_and_shared_memory_equal_inline(gold):
+    """_finish_host (the host half of inference_batch / inference_stream) on signals laid out as the device half leaves them:
+    inline, pooled with pickled jobs, and pooled with the shared-memory hand-over return the same layouts, bit for bit,
+    including ragged batch sizes and a second batch through the same shared buffers."""
+    from horizonnet_amd import inference as inf_mod
+    import importlib
+    inf_mod = importlib.import_module("horizonnet_amd.inference")
+    g, meta = gold
+    js = [m["case"] for m in meta][:40]
+    xs = torch.cat([image_of(g, j) for j in js], 0)
+    with torch.no_grad():
+        yb, yc = sr.SignalNet()(xs.float())
+    yc = torch.sigmoid(yc)[:, 0].contiguous()
+
+    class Done:
+        def synchronize(self):
+            pass
+
+    def staged(lo, hi):
+        keys = [0.05, 0.0]
+        mask = torch.zeros((2, hi - lo, 1024), dtype=torch.uint8)
+        for i, k in enumerate(keys):
+            for b in range(lo, hi):
+                mask[i, b - lo, peaks_ref.find_N_peaks(yc[b].numpy(), r=26, min_v=k, N=None)[0]] = 1
+        return {"event": Done(), "bon": yb[lo:hi].contiguous(), "cor": yc[lo:hi].contiguous(), "mask": mask, "keys": keys, "B": hi - lo}
+
+    for lo, hi in ((0, 33), (33, 40)):
+        st = staged(lo, hi)
+        inline = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 0)
+        pooled = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 4)
+        shared = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 4, shared_signals=True)
+        assert len(inline) == len(pooled) == len(shared) == hi - lo
+        for a, b, c in zip(inline, pooled, shared):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0]) and a[1:] == b[1:] == c[1:]
+    # and they are the layouts the single-panorama entry point produces from the same signals
+    one = inference(sr.SignalNet(), image_of(g, js[0]), "cpu", peaks_fn=peaks_ref.find_N_peaks)
+    st = staged(0, 1)
+    assert np.array_equal(inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 0)[0][0], one[0])
