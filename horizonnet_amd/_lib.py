@@ -34,6 +34,11 @@ SIGNATURES = {
     "hn_workspace_bf16_bytes": (_sz, [_i]),
     "hn_forward_bf16": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hn_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hn_workspace_bf16_pipelined_bytes": (_sz, [_i]),
+    "hn_forward_bf16_submit": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+    "hn_forward_bf16_collect": (_i, [_vp, _i, _vp]),
+    "hn_pipelined_status_offset": (_i, [_i, _i, _c.POINTER(_sz)]),
+    "hn_lstm_layer_bf16_wide": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "hn_lstm_bf16_exchange_bytes": (_sz, []),
     "hn_lstm_layer_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "hn_lstm_layer_bf16_train": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

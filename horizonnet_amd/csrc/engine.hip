@@ -194,6 +194,11 @@ extern "C" int hn_destroy(hn_engine* e)
             if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
         }
         if (e->branch_stream) (void)hipStreamDestroy(e->branch_stream);
+        for (int k = 0; k < 2; ++k) {
+            if (e->ev_trunk[k]) (void)hipEventDestroy(e->ev_trunk[k]);
+            if (e->ev_head[k]) (void)hipEventDestroy(e->ev_head[k]);
+        }
+        if (e->head_stream) (void)hipStreamDestroy(e->head_stream);
         DeviceGuard guard(e->device);
         e->jt_pack.release();
         e->jt_pack_h.release();
@@ -232,6 +237,8 @@ extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
     if (strcmp(name, "branch_stream") == 0) { e->use_branch_stream = value ? 1 : 0; return 0; }
     if (strcmp(name, "bf16_lstm") == 0) { e->bf16_lstm = value ? 1 : 0; return 0; }
     if (strcmp(name, "fuse_downsample") == 0) { e->fuse_downsample = value ? 1 : 0; return 0; }
+    if (strcmp(name, "lstm_wide_rows") == 0) { e->wide_rows = value == 8 ? 8 : 16; return 0; }
+    if (strcmp(name, "lstm_wide_xcds") == 0) { e->wide_xcds = value == 2 ? 2 : 1; return 0; }
     HN_REQUIRE(false, "hn_set_option: unknown option '%s'", name);
 }
 

@@ -167,26 +167,30 @@ extern "C" int hn_pack_weights_bf16(hn_engine* e, void* packed_h, size_t bytes, 
     return 0;
 }
 
-extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
-                               size_t workspace_bytes, void* stream)
+namespace {
+
+// Buffers of the recurrent head (bi-LSTM + Linear) of one in-flight batch: the plain forward has one set inside PlanH, the
+// pipelined entry two (the head of batch i runs beside the trunk of batch i+1).
+struct HeadBufs {
+    char* sync;      // HN_SYNC_WORDS uint32: arrival counters + sticky status word
+    char* seq;       // [T*B][1024] bf16 column features (written by the trunk's up-sample / flatten launches)
+    char* gx;        // [T*B][4096] float32 gate pre-activations
+    char* y1;        // [T*B][1024] float32 layer-0 output
+    char* y1h;       // bf16 copy of y1 (layer 1's GEMM operand)
+    char* y2;        // [T*B][1024] float32 layer-1 output
+    char* xch;       // hand-off granules of the narrow recurrence kernel (plain forward)
+    char* y2h;       // bf16 copy of y2: the wide recurrence kernel's exchange buffer for layer 1 (pipelined entry only)
+};
+
+// The convolutional trunk (model.py:73-81,123-179): stem, the four ResNet stages, the four height-compression chains, the
+// up-sample / flatten into `seq`.  Everything is enqueued on `s` (+ the engine's branch stream, joined back into `s`).
+int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const PlanH& pl, char* seq, hipStream_t s)
 {
-    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward_bf16: null argument");
-    HN_REQUIRE(e->packed != nullptr && e->packed_h != nullptr, "hn_forward_bf16: hn_pack_weights / hn_pack_weights_bf16 have not been called");
-    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward_bf16: bad B=%d / C_in=%d", B, C_in);
-    const PlanH pl = make_plan_h(B);
-    HN_REQUIRE(workspace_bytes >= pl.total, "hn_forward_bf16: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
-    DeviceGuard guard(e->device);
-    HN_REQUIRE(guard.ok, "hn_forward_bf16: cannot select device %d", e->device);
-    hipStream_t s = (hipStream_t)stream;
     const Arch& a = arch();
     const HOff& h = hoff();
     const float* P = e->packed;
     const u16* H = reinterpret_cast<const u16*>(e->packed_h);
-    char* W = reinterpret_cast<char*>(workspace);
     int rc;
-    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
-    e->prof.clear();
-    e->events_used = 0;
 
     {   // stem: normalise -> NHWC4 bf16, 7x7/2 conv + BN + ReLU, max-pool
         const ConvLayer& c = a.convs[a.stem];
@@ -266,47 +270,171 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
         }
         {
             ProfScope ps(e, sb, "upsample_flatten." + std::to_string(li), 0.0);
-            if ((rc = hn_launch_upsample_flatten_bf16(gin, W + pl.seq, B, gh, Wd, a.convs[a.ghc_first[li] + 3].cout, 256 * li, sb))) return rc;
+            if ((rc = hn_launch_upsample_flatten_bf16(gin, seq, B, gh, Wd, a.convs[a.ghc_first[li] + 3].cout, 256 * li, sb))) return rc;
         }
         if (fork) HN_HIP(hipEventRecord(e->ev_join[li], sb));
     }
     if (fork)
         for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
+    return 0;
+}
 
-    // bi-LSTM x2: bf16 input GEMMs with f32 gate pre-activations, f32 recurrence; f32 Linear head
+// The recurrent head (model.py:263-269): bi-LSTM x2 (bf16 input GEMMs with f32 gate pre-activations, then the recurrence)
+// and the f32 Linear head, all on `s`.  wide: the few-compute-unit recurrence kernel of the pipelined entry.
+int run_head_h(hn_engine* e, int B, const HeadBufs& hb, float* bon, float* cor, bool wide, hipStream_t s)
+{
+    const Arch& a = arch();
+    const HOff& h = hoff();
+    const float* P = e->packed;
+    const u16* H = reinterpret_cast<const u16*>(e->packed_h);
+    int rc;
+    HN_HIP(hipMemsetAsync(hb.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
     const long rows = (long)T_COLS * B;
-    if ((rc = e->tap("feature", W + pl.seq, (size_t)rows * 1024 * 2, s))) return rc;
-    const void* lin = W + pl.seq;
-    float* ybuf[2] = {reinterpret_cast<float*>(W + pl.y1), reinterpret_cast<float*>(W + pl.y2)};
+    if ((rc = e->tap("feature", hb.seq, (size_t)rows * 1024 * 2, s))) return rc;
+    const void* lin = hb.seq;
+    float* ybuf[2] = {reinterpret_cast<float*>(hb.y1), reinterpret_cast<float*>(hb.y2)};
     for (int l = 0; l < 2; ++l) {
         {
             ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".input_gemm", 2.0 * rows * 1024.0 * 4096);
             ConvDesc d;
             memset(&d, 0, sizeof(d));
             d.x = reinterpret_cast<const float*>(lin); d.w = reinterpret_cast<const float*>(H + h.wih[l]);
-            d.scale = P + a.ones_off; d.shift = P + a.lbias_off[l]; d.y = reinterpret_cast<float*>(W + pl.gx);
+            d.scale = P + a.ones_off; d.shift = P + a.lbias_off[l]; d.y = reinterpret_cast<float*>(hb.gx);
             d.B = 1; d.Hi = 1; d.Wi = (int)rows; d.Cin = 1024; d.Cout = 4096; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1;
             d.Ho = 1; d.Wo = (int)rows; d.relu = 0; d.ldy = 4096;
             if ((rc = hn_launch_conv_bf16(d, 1, s))) return rc;
         }
         {
             ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".recurrence", 2.0 * rows * 512.0 * 2048 * 2);
-            if (e->bf16_lstm) {      // recurrent matmul on the bf16 matrix cores, 8-workgroup groups, granule hand-off (lstm_bf16.hip)
-                if ((rc = hn_launch_lstm_layer_bf16(reinterpret_cast<float*>(W + pl.gx), H + h.whh[l][0], H + h.whh[l][1], ybuf[l],
-                                                    l == 0 ? W + pl.y1h : nullptr, T_COLS, B, W + pl.xch, W + pl.sync, s)))
+            if (wide) {              // 16 (8) panoramas per group: 32 (64) compute units per batch of 32 (lstm_bf16.hip, wide form)
+                if ((rc = hn_launch_lstm_layer_bf16_wide(reinterpret_cast<float*>(hb.gx), H + h.whh[l][0], H + h.whh[l][1], ybuf[l],
+                                                         l == 0 ? hb.y1h : hb.y2h, T_COLS, B, hb.sync, e->wide_rows, e->wide_xcds, s)))
                     return rc;
-            } else if ((rc = hn_launch_lstm_layer(reinterpret_cast<float*>(W + pl.gx), P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l],
-                                                  T_COLS, B, W + pl.sync, s)))
+            } else if (e->bf16_lstm) {      // recurrent matmul on the bf16 matrix cores, 8-workgroup groups, granule hand-off (lstm_bf16.hip)
+                if ((rc = hn_launch_lstm_layer_bf16(reinterpret_cast<float*>(hb.gx), H + h.whh[l][0], H + h.whh[l][1], ybuf[l],
+                                                    l == 0 ? hb.y1h : nullptr, T_COLS, B, hb.xch, hb.sync, s)))
+                    return rc;
+            } else if ((rc = hn_launch_lstm_layer(reinterpret_cast<float*>(hb.gx), P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l],
+                                                  T_COLS, B, hb.sync, s)))
                 return rc;
         }
         if (l == 0) {
-            if (!e->bf16_lstm && (rc = hn_launch_f32_to_bf16(ybuf[0], W + pl.y1h, rows * 1024, s))) return rc;
-            lin = W + pl.y1h;
+            if (!wide && !e->bf16_lstm && (rc = hn_launch_f32_to_bf16(ybuf[0], hb.y1h, rows * 1024, s))) return rc;
+            lin = hb.y1h;
         }
     }
     if ((rc = e->tap("lstm", ybuf[1], (size_t)rows * 1024 * sizeof(float), s))) return rc;
     ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
     return hn_launch_linear_head(ybuf[1], P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
+}
+
+// Second head buffer set + the wide kernel's exchange areas, laid out behind the plain plan.
+struct PlanP {
+    PlanH base;
+    size_t sync1, seq1, gx1, y11, y1h1, y21, y2h[2], total;
+};
+
+PlanP make_plan_p(int B)
+{
+    PlanP p;
+    p.base = make_plan_h(B);
+    size_t off = p.base.total;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t b = (size_t)B;
+    p.sync1 = take(HN_SYNC_WORDS * 4);
+    p.seq1 = take((size_t)T_COLS * b * 1024 * 2);
+    p.gx1 = take((size_t)T_COLS * b * 4096 * 4);
+    p.y11 = take((size_t)T_COLS * b * 1024 * 4);
+    p.y1h1 = take((size_t)T_COLS * b * 1024 * 2);
+    p.y21 = take((size_t)T_COLS * b * 1024 * 4);
+    for (int k = 0; k < 2; ++k) p.y2h[k] = take((size_t)T_COLS * b * 1024 * 2);
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                               size_t workspace_bytes, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward_bf16: null argument");
+    HN_REQUIRE(e->packed != nullptr && e->packed_h != nullptr, "hn_forward_bf16: hn_pack_weights / hn_pack_weights_bf16 have not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward_bf16: bad B=%d / C_in=%d", B, C_in);
+    const PlanH pl = make_plan_h(B);
+    HN_REQUIRE(workspace_bytes >= pl.total, "hn_forward_bf16: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward_bf16: cannot select device %d", e->device);
+    hipStream_t s = (hipStream_t)stream;
+    char* W = reinterpret_cast<char*>(workspace);
+    e->prof.clear();
+    e->events_used = 0;
+    if (int rc = run_trunk_h(e, x, B, C_in, W, pl, W + pl.seq, s)) return rc;
+    const HeadBufs hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y1h, W + pl.y2, W + pl.xch, nullptr};
+    return run_head_h(e, B, hb, bon, cor, false, s);
+}
+
+// ---- pipelined entry: trunk of batch i+1 beside the recurrent head of batch i ----------------------------------------------
+extern "C" size_t hn_workspace_bf16_pipelined_bytes(int B)
+{
+    if (B < 1) return 0;
+    return make_plan_p(B).total;
+}
+
+extern "C" int hn_forward_bf16_submit(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                                      size_t workspace_bytes, int slot, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward_bf16_submit: null argument");
+    HN_REQUIRE(e->packed != nullptr && e->packed_h != nullptr, "hn_forward_bf16_submit: hn_pack_weights / hn_pack_weights_bf16 have not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward_bf16_submit: bad B=%d / C_in=%d", B, C_in);
+    HN_REQUIRE(slot == 0 || slot == 1, "hn_forward_bf16_submit: slot must be 0 or 1 (got %d)", slot);
+    HN_REQUIRE(!e->profiling && e->taps.empty(), "hn_forward_bf16_submit: profiling / taps are served by hn_forward_bf16 only");
+    const PlanP pp = make_plan_p(B);
+    HN_REQUIRE(workspace_bytes >= pp.total, "hn_forward_bf16_submit: workspace too small (%zu < %zu; hn_workspace_bf16_pipelined_bytes)",
+               workspace_bytes, pp.total);
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward_bf16_submit: cannot select device %d", e->device);
+    if (e->head_stream == nullptr) {          // created on first use: highest priority, so that the few workgroups of the recurrence
+        int least = 0, greatest = 0;          // win the dispatcher's arbitration against the thousands of the next batch's convolutions
+        HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HN_HIP(hipStreamCreateWithPriority(&e->head_stream, hipStreamNonBlocking, greatest));
+        for (int k = 0; k < 2; ++k) {
+            HN_HIP(hipEventCreateWithFlags(&e->ev_trunk[k], hipEventDisableTiming));
+            HN_HIP(hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char* W = reinterpret_cast<char*>(workspace);
+    const PlanH& pl = pp.base;
+    HeadBufs hb;
+    if (slot == 0) hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y1h, W + pl.y2, nullptr, W + pp.y2h[0]};
+    else hb = {W + pp.sync1, W + pp.seq1, W + pp.gx1, W + pp.y11, W + pp.y1h1, W + pp.y21, nullptr, W + pp.y2h[1]};
+    // this slot's `seq` was last read by the head submitted two calls ago: the trunk's writes into it wait for that head
+    if (e->head_pending[slot]) HN_HIP(hipStreamWaitEvent(s, e->ev_head[slot], 0));
+    if (int rc = run_trunk_h(e, x, B, C_in, W, pl, hb.seq, s)) return rc;
+    HN_HIP(hipEventRecord(e->ev_trunk[slot], s));
+    HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_trunk[slot], 0));
+    if (int rc = run_head_h(e, B, hb, bon, cor, true, e->head_stream)) return rc;
+    HN_HIP(hipEventRecord(e->ev_head[slot], e->head_stream));
+    e->head_pending[slot] = true;
+    return 0;
+}
+
+extern "C" int hn_forward_bf16_collect(hn_engine* e, int slot, void* stream)
+{
+    HN_REQUIRE(e != nullptr && (slot == 0 || slot == 1), "hn_forward_bf16_collect: bad argument");
+    HN_REQUIRE(e->head_pending[slot], "hn_forward_bf16_collect: nothing was submitted on slot %d", slot);
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward_bf16_collect: cannot select device %d", e->device);
+    HN_HIP(hipStreamWaitEvent((hipStream_t)stream, e->ev_head[slot], 0));
+    return 0;
+}
+
+extern "C" int hn_pipelined_status_offset(int B, int slot, size_t* byte_offset)
+{
+    HN_REQUIRE(B >= 1 && (slot == 0 || slot == 1) && byte_offset, "hn_pipelined_status_offset: bad argument");
+    const PlanP pp = make_plan_p(B);
+    *byte_offset = (slot == 0 ? pp.base.sync : pp.sync1) + HN_STATUS_WORD * sizeof(unsigned);
+    return 0;
 }
 
 extern "C" size_t hn_lstm_bf16_exchange_bytes(void) { return hn_lstm_bf16_xch_bytes(); }
@@ -317,6 +445,14 @@ extern "C" int hn_lstm_layer_bf16(const float* gx, const void* whh_fwd_bf16, con
 {
     HN_REQUIRE(gx && whh_fwd_bf16 && whh_rev_bf16 && y && exchange && sync_ws, "hn_lstm_layer_bf16: null pointer");
     return hn_launch_lstm_layer_bf16(gx, whh_fwd_bf16, whh_rev_bf16, y, y_bf16, T, B, exchange, sync_ws, (hipStream_t)stream);
+}
+
+extern "C" int hn_lstm_layer_bf16_wide(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, void* y_bf16, int T,
+                                       int B, void* sync_ws, int rows_per_group, int xcds_per_group, void* stream)
+{
+    HN_REQUIRE(gx && whh_fwd_bf16 && whh_rev_bf16 && y && y_bf16 && sync_ws, "hn_lstm_layer_bf16_wide: null pointer");
+    return hn_launch_lstm_layer_bf16_wide(gx, whh_fwd_bf16, whh_rev_bf16, y, y_bf16, T, B, sync_ws, rows_per_group, xcds_per_group,
+                                          (hipStream_t)stream);
 }
 
 // per-stage entries (tests): the training step's forms of that layer -- forward also storing (i, f, g, o, c), and the adjoint

@@ -37,6 +37,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 typedef unsigned long long u64;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 // Gate nonlinearities on the step's critical path (16 lanes per wave, nothing to overlap them with): hardware exp2 / rcp
 // (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of libm's expf / tanhf / IEEE division -- a few 1e-7 of difference on values that
@@ -180,6 +183,180 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_kernel(const float* __res
                     if (y_h) y_h[o] = (u16)bf16_rn(hval[r]);
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// WIDE form of the same recurrence for the pipelined forward (hn_forward_bf16_submit, engine_bf16.hip): the kernel above keeps
+// 2 of the 16 MFMA rows live and therefore occupies all 256 compute units for a latency-bound chain of 256 steps.  Here a
+// group owns one direction of BW = 16 (or 8) panoramas, so every MFMA row is live and a batch of 32 needs 4 groups x 8
+// workgroups = 32 compute units (64 at BW = 8); the other 224 run the NEXT batch's HBM-bound stem / layer1 convolutions on the
+// caller's stream while the recurrence walks its 2 x 256 steps (the point of the pipelined entry; reference model.py:263-264
+// is a serial nn.LSTM call after the convolutions of the same batch).
+//   * the per-step exchange grows to BW x 512 bf16 = 16 KB per group; with 8-byte {tag, 2 x bf16} granules every wave swept
+//     8 KB in 16 loads per lane and the step took 6.8 us (measured, round 3).  The exchange buffer is therefore the layer's
+//     bf16 OUTPUT y_h itself, one slot per time step, pre-filled with the bf16 pattern 0xFFFF (a NaN no finite h rounds to):
+//     "every element differs from the sentinel" is the arrival test, there is no tag, no parity and no slot reuse.  A member
+//     publishes with ONE 8-byte write-through store per lane (4 consecutive units of one panorama, built from the lanes' four
+//     accumulator rows with two DPP quad swaps); a wave sweeps BW / 4 rows with one 16-byte sc1 load per lane and row.
+//     Element granularity makes torn 16-byte reads harmless.  Rows of absent panoramas are neither published nor swept.
+//   * all 64 lanes of a wave are gate lanes (4 accumulator rows each); the arithmetic is the narrow kernel's, so the two
+//     kernels agree bit for bit (tested).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int WIDE_MAX_GROUPS = 8;            // per launch: 2 directions x 4 sets (64 panoramas at BW = 16)
+constexpr int WIDE_HP = LH + 8;               // LDS row pitch (bf16): rows 4 banks apart -> conflict-free 16-byte fragment reads
+
+__device__ __forceinline__ unsigned quad_swap1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false); }   // lane ^ 1
+__device__ __forceinline__ unsigned quad_swap2(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false); }   // lane ^ 2
+
+template <int BW>
+__global__ __launch_bounds__(256) void lstm_layer_bf16_wide_kernel(const float* __restrict__ gx, const u16* __restrict__ whh_f,
+                                                                   const u16* __restrict__ whh_r, float* __restrict__ y, u16* y_h,
+                                                                   int T, int B, int b0, int bc, int ngroups, int xcds_per_group,
+                                                                   unsigned* sync)
+{
+    static_assert(BW == 8 || BW == 16, "rows per group");
+    constexpr int RPW = BW / 4;                                       // rows swept per wave
+    __shared__ __attribute__((aligned(16))) u16 hs[2][BW][WIDE_HP];   // h_{t-1} of the group's panoramas, by step parity
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // blockIdx b runs on XCD b % 8 (observed, speed only): a group's 8 members on ONE XCD (xcds_per_group 1: groups 0..7 on
+    // XCDs 0..7) or 4 + 4 on two neighbouring XCDs (xcds_per_group 2: 4 compute units of every XCD at 4 groups)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    int grp, mem;
+    if (xcds_per_group == 1) { grp = xcd + 8 * (slot >> 3); mem = slot & 7; }
+    else { grp = (xcd >> 1) + 4 * (slot >> 2); mem = ((xcd & 1) << 2) | (slot & 3); }
+    if (grp >= ngroups) return;
+    const int dir = grp & 1;
+    const int bfirst = (grp >> 1) * BW;
+    if (bfirst >= bc) return;                          // the whole group leaves together
+    const int nvalid = (bc - bfirst) < BW ? (bc - bfirst) : BW;
+    const u16* whh = dir ? whh_r : whh_f;
+    const int col = lane & 15;
+    const int kb = lane >> 4;
+    const int u0 = mem * UPC + wave * 16;
+    const size_t yh_bytes = (size_t)T * B * 1024 * sizeof(u16);
+    const __amdgpu_buffer_rsrc_t rsrc_h =              // h_{t-1} is read with sc1 (L1-bypassing) buffer loads: aux bit 4
+        __builtin_amdgcn_make_buffer_rsrc(y_h, 0, (unsigned)(yh_bytes > 0xfffffff0u ? 0xfffffff0u : yh_bytes), 0x00020000);
+
+
+    u32x4 wf[4][16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const u16* wr = whh + (size_t)(g * LH + u0 + col) * LH + kb * 8;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) wf[g][ks] = *reinterpret_cast<const u32x4*>(wr + ks * 32);
+    }
+
+    // accumulator rows of this lane: kb * 4 + r, r = 0..3 (unit u0 + col); after the two quad swaps the lane publishes 4
+    // consecutive units (the quad's) of row kb * 4 + pub_r
+    const int row0 = kb * 4;
+    const bool gate_lane = row0 < BW;
+    const int j = col & 3;
+    const int pub_row = row0 + ((j & 1) ? 2 : 0) + (j >> 1);
+    float c_state[4] = {0.f, 0.f, 0.f, 0.f};
+    bool failed = false;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+
+        float gxv[4][4];
+        if (gate_lane) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + r;
+                const int bb = b0 + bfirst + (row < nvalid ? row : nvalid - 1);
+                const float* gp = gx + ((size_t)t * B + bb) * 4096 + dir * 2048 + u0 + col;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gxv[r][g] = gp[g * LH];
+            }
+        }
+
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            const int par = step & 1;
+            {
+                const int tprev = dir ? t + 1 : t - 1;
+                u32x4 v[RPW];
+                unsigned voff[RPW];
+#pragma unroll
+                for (int k = 0; k < RPW; ++k) {          // a row of an absent panorama re-reads the group's row 0 (its MFMA row is dead)
+                    const int row = wave * RPW + k < nvalid ? wave * RPW + k : 0;
+                    voff[k] = (unsigned)((((size_t)tprev * B + b0 + bfirst + row) * 1024 + dir * LH) * sizeof(u16)) + lane * 16;
+                }
+                unsigned spins = 0;
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k)
+                        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, voff[k], 0, /*sc1*/ 16));
+                    u16x8 m8 = __builtin_bit_cast(u16x8, v[0]);      // running packed maximum: 0xFFFF somewhere <=> an element is still the sentinel
+#pragma unroll
+                    for (int k = 1; k < RPW; ++k) m8 = __builtin_elementwise_max(m8, __builtin_bit_cast(u16x8, v[k]));
+                    const u16x4 m4 = __builtin_elementwise_max(m8.lo, m8.hi);
+                    const u16x2 m2 = __builtin_elementwise_max(m4.lo, m4.hi);
+                    const bool ok = (m2[0] != 0xffff) & (m2[1] != 0xffff);
+                    if (__all(ok) || failed) break;
+                    asm volatile("" ::: "memory");                       // the next sweep re-reads memory
+                    if (++spins > SPIN_LIMIT_H) {
+                        __hip_atomic_store(sync + HN_STATUS_WORD, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        failed = true;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < RPW; ++k) *reinterpret_cast<u32x4*>(&hs[par][wave * RPW + k][lane * 8]) = v[k];
+            }
+            __syncthreads();
+            // A fragments: row = lane % 16 -> panorama (BW = 8: rows 8..15 are dead and read row 0), k = ks*32 + kb*8 .. +8
+            const u16* hrow = &hs[par][col < BW ? col : 0][kb * 8];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(hrow + ks * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wf[g][ks]),
+                                                                     acc[g], 0, 0, 0);
+            }
+        }
+
+        if (gate_lane) {
+            float hval[4];
+            unsigned hb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigm(gxv[r][0] + acc[0][r]);
+                const float fg = sigm(gxv[r][1] + acc[1][r]);
+                const float gg = tanh_fast(gxv[r][2] + acc[2][r]);
+                const float og = sigm(gxv[r][3] + acc[3][r]);
+                c_state[r] = fg * c_state[r] + ig * gg;
+                hval[r] = og * tanh_fast(c_state[r]);
+                hb[r] = bf16_rn(hval[r]);
+            }
+            // publish FIRST: 4 rows x 1 unit per lane -> 1 row x 4 units per lane (a 4 x 4 transpose inside the quad of unit lanes)
+            const unsigned lo = hb[0] | (hb[1] << 16), hi = hb[2] | (hb[3] << 16);
+            const bool odd = j & 1;
+            const unsigned mine = odd ? hi : lo;                              // even lanes keep rows 0,1; odd lanes rows 2,3
+            const unsigned recv = quad_swap1(odd ? lo : hi);
+            const unsigned ev = odd ? recv : mine, od = odd ? mine : recv;    // even / odd unit of the pair, two rows each
+            const unsigned p0 = (ev & 0xffffu) | (od << 16);                  // first of the lane's two rows, units (2p, 2p+1)
+            const unsigned p1 = (ev >> 16) | (od & 0xffff0000u);              // second row
+            const bool up = j >> 1;                                           // unit pair 1 of the quad keeps the second row
+            const unsigned recv2 = quad_swap2(up ? p0 : p1);
+            const u64 word = up ? ((u64)recv2 | ((u64)p1 << 32)) : ((u64)p0 | ((u64)recv2 << 32));
+            if (pub_row < nvalid)
+                __hip_atomic_store(reinterpret_cast<u64*>(y_h + ((size_t)t * B + b0 + bfirst + pub_row) * 1024 + dir * LH + u0 + (col & ~3)), word,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < nvalid) y[((size_t)t * B + b0 + bfirst + row0 + r) * 1024 + dir * LH + u0 + col] = hval[r];
         }
     }
 }
@@ -363,6 +540,36 @@ int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* wh
         hipLaunchKernelGGL(lstm_layer_bf16_kernel, dim3(NGRP * GRP), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
                            reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), reinterpret_cast<u64*>(xch), T, B, b0,
                            bc, reinterpret_cast<unsigned*>(sync_ws), save);
+        HN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// The wide form (see lstm_layer_bf16_wide_kernel): rows_per_group 16 (default) or 8, xcds_per_group 1 or 2; <= 0 picks the default.
+// y_h (bf16 [T*B][1024]) is REQUIRED: it is the kernel's exchange buffer as well as its bf16 output.
+int hn_launch_lstm_layer_bf16_wide(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B,
+                                   void* sync_ws, int rows_per_group, int xcds_per_group, hipStream_t s)
+{
+    HN_REQUIRE(T >= 1 && B >= 1 && T < 0x7fffffff && y_h != nullptr, "lstm bf16 wide: bad T/B or no y_h");
+    const int bw = rows_per_group == 8 ? 8 : 16;
+    const int xs = xcds_per_group == 2 ? 2 : 1;
+    const int chunk = bw * (WIDE_MAX_GROUPS / 2);
+    HN_HIP(hipMemsetAsync(y_h, 0xFF, (size_t)T * B * 1024 * sizeof(u16), s));       // every element = the "not yet written" sentinel
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int bc = (B - b0) < chunk ? (B - b0) : chunk;
+        const int ngroups = 2 * hn_cdiv(bc, bw);
+        const int grid = xs == 1 ? 64 * hn_cdiv(ngroups, 8) : 32 * hn_cdiv(ngroups, 4);
+        if (bw == 16) {
+            if (int rc = hn_require_coresident(lstm_layer_bf16_wide_kernel<16>, grid, 256, "bf16 LSTM recurrence (wide)")) return rc;
+            hipLaunchKernelGGL(lstm_layer_bf16_wide_kernel<16>, dim3(grid), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
+                               reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), T, B, b0, bc, ngroups, xs,
+                               reinterpret_cast<unsigned*>(sync_ws));
+        } else {
+            if (int rc = hn_require_coresident(lstm_layer_bf16_wide_kernel<8>, grid, 256, "bf16 LSTM recurrence (wide)")) return rc;
+            hipLaunchKernelGGL(lstm_layer_bf16_wide_kernel<8>, dim3(grid), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
+                               reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), T, B, b0, bc, ngroups, xs,
+                               reinterpret_cast<unsigned*>(sync_ws));
+        }
         HN_LAUNCH_CHECK();
     }
     return 0;

@@ -238,14 +238,21 @@ class _HostRing:
 _RING = _HostRing()
 
 
-def _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth):
-    """Device half of one batch, enqueued without any host synchronisation: forward of B x A views, augmentation undo + mean,
-    sigmoid, one hn_find_peaks launch per threshold, asynchronous copies into pinned host buffers, one event."""
-    from .peaks import find_peaks_batch
-    W = int(x.shape[-1])
-    B = int(x.shape[0])
+def _stage_submit(net, x, device, flip, rotate):
+    """First device stage of one batch: test-time augmentation + the engine forward, submitted asynchronously
+    (``forward_async``: in bf16 mode the recurrent head runs on the engine's own stream beside the NEXT batch's trunk)."""
     x_aug, tags = augment(x.to(device), flip, rotate)
-    y_bon, y_cor = net(x_aug)
+    fwd = net.forward_async(x_aug) if hasattr(net, "forward_async") else None
+    return {"pending": fwd, "out": None if fwd is not None else net(x_aug), "tags": tags, "B": int(x.shape[0]), "W": int(x.shape[-1]),
+            "net": net, "device": device}
+
+
+def _stage_post(sub, force_cuboid, min_v, r, depth):
+    """Second device stage, enqueued without any host synchronisation: wait (stream-side) for the forward's head, augmentation
+    undo + mean, sigmoid, one hn_find_peaks launch per threshold, asynchronous copies into pinned host buffers, one event."""
+    from .peaks import find_peaks_batch
+    W, B, tags, device = sub["W"], sub["B"], sub["tags"], sub["device"]
+    y_bon, y_cor = sub["pending"].result() if sub["pending"] is not None else sub["out"]
     bon = _undo_mean_device(y_bon, tags)
     prob = _undo_mean_device(torch.sigmoid(y_cor), tags)[:, 0].contiguous()
     mv = (0.0 if force_cuboid else 0.05) if min_v is None else float(min_v)
@@ -258,7 +265,25 @@ def _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth):
         h_mask[i].copy_(find_peaks_batch(prob, rr, k)[0], non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(torch.device(device)))
-    return {"event": ev, "bon": h_bon, "cor": h_cor, "mask": h_mask, "keys": keys, "B": B, "keep": (bon, prob)}
+    return {"event": ev, "bon": h_bon, "cor": h_cor, "mask": h_mask, "keys": keys, "B": B, "keep": (bon, prob), "net": sub["net"],
+            "device": device}
+
+
+def _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth):
+    """Both device stages of one batch back to back (the unpipelined form)."""
+    return _stage_post(_stage_submit(net, x, device, flip, rotate), force_cuboid, min_v, r, depth)
+
+
+def _raise_if_engine_failed(st):
+    """The forward posted an asynchronous read of the persistent LSTM's status word BEFORE the event this batch was just
+    synchronised on, so the word is on the host now: a timed-out recurrence means THIS batch's signals are garbage -- raise
+    here instead of on the next engine call (which, for the last batch of a stream, never comes)."""
+    net, device = st.get("net"), st.get("device")
+    states = getattr(net, "_hip_states", None)
+    if states:
+        ds = states.get(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+        if ds is not None:
+            ds.raise_if_failed()
 
 
 def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals=False):
@@ -266,6 +291,7 @@ def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_si
     shared_signals: hand the batch to the workers through shared memory (three memcpys + one small tuple per panorama)
     instead of pickling five arrays per panorama in the calling thread."""
     st["event"].synchronize()
+    _raise_if_engine_failed(st)
     B = st["B"]
     y_bon, y_cor, masks = st["bon"].numpy(), st["cor"].numpy(), st["mask"].numpy()
     if workers is None:
@@ -311,12 +337,18 @@ def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=F
     on the target box)."""
     from collections import deque
     pending = deque()
-    for x in batches:
+    sub = None                         # the batch whose forward is submitted but whose second device stage is not yet enqueued:
+    for x in batches:                  # batch i+1's trunk goes onto the stream BEFORE batch i's wait for its recurrent head
         H, W = tuple(x.shape[2:])
-        pending.append((_stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth), H, W))
+        nxt = (_stage_submit(net, x, device, flip, rotate), H, W)
+        if sub is not None:
+            pending.append((_stage_post(sub[0], force_cuboid, min_v, r, depth + 1), sub[1], sub[2]))
+        sub = nxt
         if len(pending) >= depth:
             st, h, w = pending.popleft()
             yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals)
+    if sub is not None:
+        pending.append((_stage_post(sub[0], force_cuboid, min_v, r, depth + 1), sub[1], sub[2]))
     while pending:
         st, h, w = pending.popleft()
         yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals)

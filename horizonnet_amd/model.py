@@ -190,6 +190,9 @@ class _DeviceState:
         self.workspaces.pop(kind, None)      # one batch size resident per kind; the other kinds stay (a validation forward
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)      # between a train forward and its backward is fine)
         ws[:_SYNC_BYTES].zero_()             # arrival counters + the STICKY status word of the persistent LSTM
+        if kind == "bf16p":                  # the second head slot's sync area lies behind the plain plan
+            off = self.pipelined_status_bytes(B)[1] - _STATUS_BYTE
+            ws[off:off + _SYNC_BYTES].zero_()
         self.workspaces[kind] = (B, ws)
         return ws
 
@@ -202,9 +205,21 @@ class _DeviceState:
     def train_workspace(self, B):
         return self._workspace("train", B, self.lib.hn_train_workspace_bytes(B))
 
-    def post_status_read(self, ws):
+    def workspace_bf16_pipelined(self, B):
+        return self._workspace("bf16p", B, self.lib.hn_workspace_bf16_pipelined_bytes(B))
+
+    def pipelined_status_bytes(self, B):
+        """Byte offsets of the two head slots' sticky status words inside the pipelined workspace."""
+        offs = []
+        for slot in (0, 1):
+            o = ctypes.c_size_t()
+            _lib.check(self.lib.hn_pipelined_status_offset(B, slot, ctypes.byref(o)), "hn_pipelined_status_offset")
+            offs.append(int(o.value))
+        return offs
+
+    def post_status_read(self, ws, byte_off=_STATUS_BYTE):
         """Asynchronous copy of the workspace's sticky LSTM status word to pinned host memory (no synchronisation)."""
-        self.status_host.copy_(ws[_STATUS_BYTE:_STATUS_BYTE + 4].view(torch.int32), non_blocking=True)
+        self.status_host.copy_(ws[byte_off:byte_off + 4].view(torch.int32), non_blocking=True)
         if self.status_event is None:
             self.status_event = torch.cuda.Event()
         self.status_event.record(torch.cuda.current_stream(self.device))
@@ -224,6 +239,25 @@ class _DeviceState:
             self.lib.hn_destroy(self.handle)
         except Exception:
             pass
+
+
+class PendingForward:
+    """Handle of one ``HorizonNet.forward_async`` call.  ``result()`` makes the CURRENT stream wait for the call's recurrent
+    head (a stream-side wait, the host does not block) and returns (bon, cor) -- the reference's ``net(x)`` outputs."""
+
+    def __init__(self, st, slot, bon, cor, ws, status_off, check):
+        self._st, self._slot, self._bon, self._cor, self._ws = st, slot, bon, cor, ws
+        self._status_off, self._check, self._done = status_off, check, slot is None
+
+    def result(self):
+        if not self._done:
+            dev = self._bon.device
+            with torch.cuda.device(dev):
+                _lib.check(self._st.lib.hn_forward_bf16_collect(self._st.handle, self._slot, _lib.stream_ptr(dev)), "hn_forward_bf16_collect")
+                if self._check:
+                    self._st.post_status_read(self._ws, self._status_off)
+            self._done = True
+        return self._bon, self._cor
 
 
 class _HipTrainStep(torch.autograd.Function):
@@ -470,6 +504,43 @@ class HorizonNet(nn.Module):
                 st.post_status_read(ws)
         return bon, cor
 
+    def forward_async(self, x):
+        """Two-stage form of ``forward`` for back-to-back batches (serving loops, ``inference_stream``): enqueues the
+        convolutional trunk on the current stream and the recurrent head (bi-LSTM + Linear, reference model.py:263-269) on an
+        engine-owned stream behind it, and returns a ``PendingForward`` at once.  The head's recurrence kernel needs 32 of the
+        256 compute units for 32 panoramas, so the trunk of the NEXT ``forward_async`` call runs beside it: call
+        ``forward_async(x[i+1])`` BEFORE ``pending[i].result()``.  Outputs are bit-identical to ``forward``.  Pipelined for
+        eval mode with ``precision == "bf16"``; every other mode runs ``forward`` and returns a completed handle."""
+        if self.training or self.precision != "bf16":
+            bon, cor = self.forward(x)
+            return PendingForward(None, None, bon, cor, None, 0, False)
+        if x.shape[2] != 512 or x.shape[3] != 1024:
+            raise NotImplementedError()
+        if not x.is_cuda:
+            raise RuntimeError("horizonnet_amd.HorizonNet runs on the MI355X HIP engine only: move the input "
+                               "(and the module) to a cuda/ROCm device; there is no CPU fallback")
+        B, C_in = int(x.shape[0]), int(x.shape[1])
+        if C_in < 3:
+            raise RuntimeError("expected at least 3 input channels")
+        xin = x.detach()
+        if xin.dtype != torch.float32 or not xin.is_contiguous():
+            xin = xin.float().contiguous()
+        with torch.cuda.device(x.device):
+            st = self._hip_state(x.device)
+            st.raise_if_failed()
+            bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
+            cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
+            self._pack_bf16(st, x.device)
+            ws = st.workspace_bf16_pipelined(B)
+            slot = st.pipe_slot = 1 - getattr(st, "pipe_slot", 1)
+            _lib.check(st.lib.hn_forward_bf16_submit(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
+                                                     ws.numel(), slot, _lib.stream_ptr(x.device)), "hn_forward_bf16_submit")
+            # bon / cor are written on the engine's head stream: the handle keeps them (and the input the trunk reads on this
+            # stream) alive until result() has ordered them on the caller's stream
+            pend = PendingForward(st, slot, bon, cor, ws, st.pipelined_status_bytes(B)[slot], self.check_status_async)
+            pend._keep = xin
+        return pend
+
     _TAP_SHAPES = {"stem": (256, 512, 64), "pool": (128, 256, 64), "c1": (128, 256, 256), "c2": (64, 128, 512),
                    "c3": (32, 64, 1024), "c4": (16, 32, 2048)}
 
@@ -534,8 +605,11 @@ class HorizonNet(nn.Module):
         if st is None or not st.workspaces:
             return 0
         worst = 0
-        for _, ws in st.workspaces.values():         # the status word is sticky per workspace
+        for kind, (B, ws) in st.workspaces.items():  # the status word is sticky per workspace
             val = ctypes.c_int(0)
             _lib.check(st.lib.hn_check_status(st.handle, _lib.ptr(ws), ctypes.byref(val)), "hn_check_status")
             worst = max(worst, val.value)
+            if kind == "bf16p":                      # second head slot of the pipelined workspace
+                off = st.pipelined_status_bytes(B)[1]
+                worst = max(worst, int(ws[off:off + 4].view(torch.int32).item()))
         return worst

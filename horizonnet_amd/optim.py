@@ -96,6 +96,9 @@ class FusedAdam:
         if base is None:
             return
         ptrs, active = self._tables()
+        st = getattr(self.net, "_hip_states", {}).get(self.device.index)
+        if st is not None:
+            st.raise_if_failed()     # an EARLIER step's recurrence timed out (its status word has arrived): stop before more updates
         self.step_count += 1
         with torch.cuda.device(self.device):
             _lib.check(self.lib.hn_adam_step(_lib.ptr(ptrs), _lib.ptr(self.offsets), _lib.ptr(self.ends), _lib.ptr(active), len(self.order),
@@ -109,8 +112,71 @@ class FusedAdam:
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.m.copy_(sd["m"].to(self.device))
-        self.v.copy_(sd["v"].to(self.device))
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        """Own layout {'step', 'm', 'v', 'param_groups'}, or ``torch.optim.Adam``'s {'state', 'param_groups'} -- what the
+        reference's ``checkpoint.pth.tar`` holds (see ``torch_adam_state_to_flat``)."""
+        if "m" in sd and "v" in sd and "step" in sd:
+            self.step_count = int(sd["step"])
+            self.m.copy_(sd["m"].to(self.device))
+            self.v.copy_(sd["v"].to(self.device))
+            for g, s in zip(self.param_groups, sd["param_groups"]):
+                g.update({k: v for k, v in s.items() if k != "params"})
+            return
+        entries = [(int(self.lib.hn_grad_offset(k.encode())), k, tuple(p.shape), bool(p.requires_grad)) for k, p in self.named]
+        m, v, step, hyper = torch_adam_state_to_flat(sd, entries, self.total)
+        self.m.copy_(m.to(self.device))
+        self.v.copy_(v.to(self.device))
+        self.step_count = step
+        self.param_groups[0].update(hyper)
+
+
+def torch_adam_state_to_flat(sd, entries, total):
+    """``torch.optim.Adam.state_dict()`` -> (m, v, step, hyper-parameters) in the engine's flat layout.
+
+    The reference builds its optimiser over the parameters with ``requires_grad`` in ``net.parameters()`` order
+    (train.py:216-225) and stores ``optimizer.state_dict()`` in ``checkpoint.pth.tar`` (train.py:336-346): state index i is
+    the i-th such parameter.  `entries`: (flat offset, name, shape, requires_grad) per parameter in ``named_parameters()``
+    order.  ``exp_avg`` / ``exp_avg_sq`` are scattered to the offsets; parameters without state (never stepped) keep zero
+    moments; ``step`` is the largest per-parameter step.  A state that is not Adam's (SGD momentum buffers) cannot seed the
+    moments: they restart at zero with a warning, the hyper-parameters are still taken."""
+    if "state" not in sd or "param_groups" not in sd:
+        raise KeyError("FusedAdam.load_state_dict: neither FusedAdam's {'step','m','v','param_groups'} nor torch.optim's "
+                       "{'state','param_groups'} layout (keys: %s)" % sorted(sd.keys()))
+    ids = [i for g in sd["param_groups"] for i in g["params"]]
+    live = [e for e in entries if e[3]]
+    if len(ids) == len(live):
+        targets = live
+    elif len(ids) == len(entries):
+        targets = entries
+    else:
+        raise ValueError("FusedAdam.load_state_dict: the torch optimiser state covers %d parameters, this module has %d "
+                         "trainable of %d" % (len(ids), len(live), len(entries)))
+    m = torch.zeros(total, dtype=torch.float32)
+    v = torch.zeros(total, dtype=torch.float32)
+    steps, adam_like = [], True
+    for i, (o, k, shape, _) in zip(ids, targets):
+        st = sd["state"].get(i)
+        if st is None:
+            continue
+        if "exp_avg" not in st or "exp_avg_sq" not in st:
+            adam_like = False
+            break
+        if tuple(st["exp_avg"].shape) != tuple(shape):
+            raise ValueError("FusedAdam.load_state_dict: state %d has shape %s, parameter %s has %s"
+                             % (i, tuple(st["exp_avg"].shape), k, tuple(shape)))
+        n = st["exp_avg"].numel()
+        m[o:o + n] = st["exp_avg"].reshape(-1).to("cpu", torch.float32)
+        v[o:o + n] = st["exp_avg_sq"].reshape(-1).to("cpu", torch.float32)
+        steps.append(int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"]))
+    if not adam_like:
+        import warnings
+        warnings.warn("FusedAdam.load_state_dict: the checkpoint's optimiser state is not Adam's (no exp_avg / exp_avg_sq): "
+                      "moments and step counter restart at zero", RuntimeWarning, stacklevel=3)
+        m.zero_()
+        v.zero_()
+        steps = []
+    hyper = {}
+    g0 = sd["param_groups"][0]
+    for key in ("lr", "betas", "eps", "weight_decay"):
+        if key in g0:
+            hyper[key] = tuple(g0[key]) if key == "betas" else float(g0[key])
+    return m, v, (max(steps) if steps else 0), hyper

@@ -133,7 +133,10 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        import datetime
+        # generous collective time-out: a validation pass on rank 0 may outlast RCCL's default watchdog
+        dist.init_process_group(backend=os.environ.get("HN_DIST_BACKEND", "nccl"), device_id=device if os.environ.get("HN_DIST_BACKEND", "nccl") == "nccl" else None,
+                                timeout=datetime.timedelta(hours=2))
     np.random.seed(args.seed + rank)
     torch.manual_seed(args.seed + rank)
     ckpt_dir = os.path.join(args.ckpt, args.id)
@@ -178,7 +181,7 @@ def main(argv=None):
     first_epoch = 1
     ckpt_file = os.path.join(ckpt_dir, "checkpoint.pth.tar")
     if args.resume and os.path.isfile(ckpt_file):
-        first_epoch = utils.resume_checkpoint(ckpt_file, net, optimizer, args, device)
+        first_epoch = utils.resume_checkpoint(ckpt_file, net, optimizer, args, device, rank=rank, world=world)
         if rank == 0:
             print("resumed from %s: continuing with epoch %d (iteration %d)" % (ckpt_file, first_epoch, args.cur_iter))
 
@@ -210,6 +213,11 @@ def main(argv=None):
                     print("ep %d it %d lr %.3e bon %.4f cor %.4f" % (epoch, args.cur_iter, args.running_lr, row["bon"], row["cor"]),
                           flush=True)
         batches.close()
+        torch.cuda.synchronize(device)
+        if net.hip_status(device) != 0:                     # a timed-out persistent LSTM kernel produced garbage this epoch:
+            raise RuntimeError("horizonnet_amd.train: the engine's status word is non-zero after epoch %d; refusing to "
+                               "validate / checkpoint weights updated from invalid activations" % epoch)
+        rng_ranks = utils.gather_rng_states()               # collective: every rank's streams go into rank 0's checkpoint
         if dataset_valid is not None:
             scores = validate(net, dataset_valid, device)
             now = scores.get("3DIoU", 0.0)
@@ -217,12 +225,14 @@ def main(argv=None):
             is_best = now > args.best_valid_score
             if is_best:
                 args.best_valid_score = now
-            utils.save_checkpoint(utils.make_checkpoint(net, optimizer, epoch, args), is_best, ckpt_dir, epoch)
+            utils.save_checkpoint(utils.make_checkpoint(net, optimizer, epoch, args, rng_ranks), is_best, ckpt_dir, epoch)
             history.append({"epoch": epoch, "valid": scores})
         elif rank == 0:
-            utils.save_checkpoint(utils.make_checkpoint(net, optimizer, epoch, args), False, ckpt_dir, epoch)
+            utils.save_checkpoint(utils.make_checkpoint(net, optimizer, epoch, args, rng_ranks), False, ckpt_dir, epoch)
         if rank == 0 and epoch % args.save_every == 0:
             utils.save_model(net, os.path.join(ckpt_dir, "epoch_%d.pth" % epoch), args)
+        if dist is not None:
+            dist.barrier()                                  # nobody reads a checkpoint (or starts the next epoch's collectives) before rank 0 has written it
         if args.stop_after_epoch is not None and epoch >= args.stop_after_epoch:
             break
     if dist is not None:

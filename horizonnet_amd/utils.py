@@ -54,19 +54,69 @@ def save_checkpoint(state, is_best, checkpoint_dir, epoch):
         shutil.copyfile(final, os.path.join(checkpoint_dir, "best_model_%d.pth.tar" % epoch))
 
 
-def make_checkpoint(net, optimizer, epoch, args):
-    """The dictionary of train.py:336-346, plus what a bit-continuous resume needs (iteration counter, RNG states)."""
+def _rng_states():
+    import numpy as np
+    return {"torch": torch.get_rng_state(), "numpy": np.random.get_state()}
+
+
+def gather_rng_states():
+    """Every rank's host RNG streams (torch: dropout seeds of the training step; numpy: augmentation draws), rank-indexed.
+    A COLLECTIVE when torch.distributed is initialised with more than one rank: call it on every rank (train.py does, just
+    before rank 0 writes the checkpoint)."""
+    import torch.distributed as dist
+    mine = _rng_states()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        states = [None] * dist.get_world_size()
+        dist.all_gather_object(states, mine)
+        return states
+    return [mine]
+
+
+def make_checkpoint(net, optimizer, epoch, args, rng_ranks=None):
+    """The dictionary of train.py:336-346, plus what a bit-continuous resume needs (iteration counter, RNG states of EVERY
+    rank: `rng_ranks` from gather_rng_states(); default: this process only)."""
     core = unwrap(net)
+    rng_ranks = [_rng_states()] if rng_ranks is None else rng_ranks
     return {"epoch": epoch, "state_dict": core.state_dict(), "optimizer": optimizer.state_dict(),
             "best_valid_score": args.best_valid_score, "backbone": getattr(core, "backbone", None),
             "use_rnn": getattr(core, "use_rnn", True), "cur_iter": args.cur_iter,
-            "rng": {"torch": torch.get_rng_state(), "numpy": __import__("numpy").random.get_state()}}
+            "rng": rng_ranks[0], "rng_ranks": rng_ranks}
 
 
-def resume_checkpoint(path, net, optimizer, args, device):
+def _restore_rng(blob, rank, world):
+    """Each rank continues ITS OWN streams.  A checkpoint without per-rank states (older file, or written by a different
+    world size) cannot do that for ranks > 0: they are re-seeded with a deterministic function of (rank 0's saved state,
+    rank) so that replicas stay decorrelated instead of all replaying rank 0's draws."""
+    import numpy as np
+    ranks = blob.get("rng_ranks")
+    if ranks is not None and len(ranks) == world:
+        torch.set_rng_state(ranks[rank]["torch"])
+        np.random.set_state(ranks[rank]["numpy"])
+        return "own"
+    rng = blob.get("rng")
+    if rng is None:
+        return "none"
+    if rank == 0:
+        torch.set_rng_state(rng["torch"])
+        np.random.set_state(rng["numpy"])
+        return "own"
+    import zlib
+    base = zlib.crc32(rng["torch"].numpy().tobytes()) ^ zlib.crc32(np.asarray(rng["numpy"][1]).tobytes())
+    seed = (base + 0x9E3779B1 * rank) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return "reseeded"
+
+
+def resume_checkpoint(path, net, optimizer, args, device, rank=None, world=None):
     """Restore model, optimiser, epoch / iteration counters and RNG streams from ``checkpoint.pth.tar``; returns the
-    epoch to continue with.  Also accepts the reference's own checkpoints (no 'cur_iter' / 'rng': the iteration counter
-    is rebuilt from the epoch)."""
+    epoch to continue with.  Also accepts the reference's own checkpoints (torch.optim.Adam state, no 'cur_iter' / 'rng':
+    the iteration counter is rebuilt from the epoch)."""
+    if rank is None or world is None:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank() if on else 0
+        world = dist.get_world_size() if on else 1
     blob = torch.load(path, map_location="cpu", weights_only=False)
     unwrap(net).load_state_dict(blob["state_dict"])
     optimizer.load_state_dict(blob["optimizer"])
@@ -76,9 +126,5 @@ def resume_checkpoint(path, net, optimizer, args, device):
                 state[k] = v.to(device)
     args.best_valid_score = blob.get("best_valid_score", 0)
     args.cur_iter = blob.get("cur_iter", blob["epoch"] * getattr(args, "iters_per_epoch", 0))
-    rng = blob.get("rng")
-    if rng is not None:
-        import numpy as np
-        torch.set_rng_state(rng["torch"])
-        np.random.set_state(rng["numpy"])
+    args.rng_restore = _restore_rng(blob, rank, world)
     return int(blob["epoch"]) + 1

@@ -83,6 +83,8 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * (model.py:138-156), which depend only on C1..C4, on an engine-owned second HIP stream beside the following ResNet
  * stages (fork / join with events: the caller's stream still orders the whole call); 0 = everything on the caller's
  * stream.  Results are identical either way.
+ * "lstm_wide_rows" (16 | 8, default 16) / "lstm_wide_xcds" (1 | 2, default 1): geometry of the wide recurrence kernel of
+ * hn_forward_bf16_submit (speed only).
  * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores
  * (float32 accumulation, gates, cell state and outputs); 0 = the float32 recurrence kernel of hn_forward.
  * "fuse_downsample" (default 1): block 0 of a ResNet stage ends in ONE launch for
@@ -113,6 +115,19 @@ int hn_pack_weights_bf16(hn_engine* e, void* packed_bf16, size_t bytes, void* st
 size_t hn_workspace_bf16_bytes(int B);
 int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* Pipelined form of hn_forward_bf16 for back-to-back batches (inference.py:187-209 calls net(x) per panorama; a serving
+ * loop calls it per batch): hn_forward_bf16_submit enqueues the convolutional trunk (model.py:73-81,123-179) on `stream` and
+ * the recurrent head (bi-LSTM + Linear, model.py:263-269) on an engine-owned high-priority stream behind it, then returns;
+ * the head uses a recurrence kernel that occupies 32 of the 256 compute units for a batch of 32, so the NEXT submit's trunk
+ * runs beside it.  `slot` (0 | 1, alternate between consecutive submits) selects one of two head buffer sets in the
+ * workspace (hn_workspace_bf16_pipelined_bytes).  bon / cor are valid on `stream` after hn_forward_bf16_collect(slot, stream)
+ * (a stream-side wait, no host synchronisation).  Same arithmetic as hn_forward_bf16: bit-identical outputs.
+ * hn_pipelined_status_offset: byte offset of the slot's sticky LSTM status word inside the workspace. */
+size_t hn_workspace_bf16_pipelined_bytes(int B);
+int hn_forward_bf16_submit(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                           size_t workspace_bytes, int slot, void* stream);
+int hn_forward_bf16_collect(hn_engine* e, int slot, void* stream);
+int hn_pipelined_status_offset(int B, int slot, size_t* byte_offset);
 /* per-stage (tests): x / res / y bf16 NHWC (y f32 when out_f32), w_oihw f32, w_scratch Cout*KH*KW*Cin bf16
  * (w_oihw == NULL: w_scratch already holds the packed weights of an earlier call) */
 int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
@@ -123,6 +138,12 @@ int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, con
  * gx [T*B][4096] float32 gate pre-activations (fwd gates | rev gates), whh_*_bf16 [2048][512] bf16, y [T*B][1024] float32,
  * y_bf16 optional bf16 copy of y, exchange: hn_lstm_bf16_exchange_bytes() of scratch, sync_ws: 4096 zeroed bytes (status
  * word at uint32 index 512). */
+/* hn_lstm_layer_bf16_wide: the few-compute-unit form used by hn_forward_bf16_submit (a group = one direction of
+ * rows_per_group = 16 | 8 panoramas, its 8 workgroups on xcds_per_group = 1 | 2 XCDs; <= 0: defaults); same arithmetic,
+ * bit-identical y; y_bf16 is REQUIRED here: the bf16 output doubles as the kernel's exchange buffer (one slot per step,
+ * pre-filled with a NaN sentinel by the call). */
+int hn_lstm_layer_bf16_wide(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, void* y_bf16, int T, int B,
+                            void* sync_ws, int rows_per_group, int xcds_per_group, void* stream);
 size_t hn_lstm_bf16_exchange_bytes(void);
 int hn_lstm_layer_bf16(const float* gx, const void* whh_fwd_bf16, const void* whh_rev_bf16, float* y, void* y_bf16, int T, int B,
                        void* exchange, void* sync_ws, void* stream);

@@ -307,3 +307,77 @@ torch.save((b.cpu(), c.cpu()), sys.argv[1])
         os.remove(f)
     assert report("bf16 split-K vs unsplit: bon", outs[0][0].numpy(), outs[1][0].numpy(), 2e-4)
     assert report("bf16 split-K vs unsplit: cor", outs[0][1].numpy(), outs[1][1].numpy(), 2e-4)
+
+
+@pytest.mark.parametrize("B", [1, 3, 17, 32, 37, 70])
+def test_lstm_layer_bf16_wide_equals_narrow(B):
+    """The few-compute-unit recurrence kernel of the pipelined forward (a group = one direction of 16 or 8 panoramas, every
+    MFMA row live) runs the narrow kernel's arithmetic: y and its bf16 copy must be bit-identical to hn_lstm_layer_bf16 at
+    ragged batch sizes (rows of absent panoramas are neither published nor swept; B > 64 takes a second chunk launch), for
+    every geometry, twice."""
+    from hiputil import P, lib, sp
+    L = lib()
+    T = 256
+    gen = torch.Generator().manual_seed(500 + B)
+    gx = ((torch.rand(T * B, 4096, generator=gen) - 0.5) * 2.0).to(DEV)
+    wd = [((torch.rand(2048, 512, generator=gen) - 0.5) * 0.12).to(torch.bfloat16).to(DEV).contiguous() for _ in range(2)]
+    sync = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    y0 = torch.full((T * B, 1024), float("nan"), device=DEV)
+    yh0 = torch.zeros((T * B, 1024), dtype=torch.bfloat16, device=DEV)
+    xch = torch.empty(L.hn_lstm_bf16_exchange_bytes(), dtype=torch.uint8, device=DEV)
+    _lib.check(L.hn_lstm_layer_bf16(P(gx), P(wd[0]), P(wd[1]), P(y0), P(yh0), T, B, P(xch), P(sync), sp()), "hn_lstm_layer_bf16")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y0).all())
+    for rows, xcds in ((16, 1), (16, 2), (8, 1), (8, 2)):
+        for rep in range(2):
+            y = torch.full((T * B, 1024), float("nan"), device=DEV)
+            yh = torch.zeros((T * B, 1024), dtype=torch.bfloat16, device=DEV)
+            _lib.check(L.hn_lstm_layer_bf16_wide(P(gx), P(wd[0]), P(wd[1]), P(y), P(yh), T, B, P(sync), rows, xcds, sp()),
+                       "hn_lstm_layer_bf16_wide")
+            torch.cuda.synchronize()
+            assert int(sync.view(torch.int32)[512]) == 0, "wide bf16 LSTM kernel reported a spin time-out (%d, %d)" % (rows, xcds)
+            assert torch.equal(y, y0), "wide (%d rows, %d xcds) run %d differs from the narrow kernel: max %g" % (
+                rows, xcds, rep, float((y - y0).abs().max()))
+            assert torch.equal(yh, yh0)
+
+
+def test_forward_async_pipelined_bit_identical():
+    """hn_forward_bf16_submit / _collect (HorizonNet.forward_async): the recurrent head of batch i on the engine's head
+    stream beside the trunk of batch i+1 -- five different batches of 32 in flight two at a time must reproduce the plain
+    bf16 forward bit for bit (the hand-off of the wide recurrence kernel runs UNDER LOAD here: the other 224 compute units
+    stream the next batch's stem / layer1), in both slot orders and for every recurrence geometry."""
+    torch.manual_seed(7)
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(3, "random"))
+    net = net.to(DEV).eval()
+    net.precision = "bf16"
+    B = 32
+    gen = torch.Generator().manual_seed(77)
+    xs = [torch.rand(B, 3, 512, 1024, generator=gen).to(DEV) for _ in range(5)]
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in net(x)) for x in xs]
+        torch.cuda.synchronize()
+        for rows, xcds in ((16, 1), (16, 2), (8, 1)):
+            net.set_engine_option("lstm_wide_rows", rows)
+            net.set_engine_option("lstm_wide_xcds", xcds)
+            got, pend = [], None
+            for x in xs:
+                p = net.forward_async(x)
+                if pend is not None:
+                    got.append(pend.result())
+                pend = p
+            got.append(pend.result())
+            torch.cuda.synchronize()
+            assert net.hip_status(DEV) == 0
+            for i, ((b0, c0), (b1, c1)) in enumerate(zip(want, got)):
+                assert torch.equal(b0, b1) and torch.equal(c0, c1), "batch %d differs (rows %d, xcds %d): %g" % (
+                    i, rows, xcds, float(max((b0 - b1).abs().max(), (c0 - c1).abs().max())))
+        # a small ragged batch through the same path, and the f32 / train fall-back of forward_async (a completed handle)
+        x3 = xs[0][:3]
+        b_ref, c_ref = net(x3)
+        b_got, c_got = net.forward_async(x3).result()
+        assert torch.equal(b_ref, b_got) and torch.equal(c_ref, c_got)
+        net.precision = "f32"
+        b_ref, c_ref = net(x3)
+        b_got, c_got = net.forward_async(x3).result()
+        assert torch.equal(b_ref, b_got) and torch.equal(c_ref, c_got)

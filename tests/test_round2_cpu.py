@@ -221,3 +221,90 @@ def test_polygon_intersection_area_matches_exact_oracle():
         check(a, star(7))                                                        # Manhattan against general position
     assert nonzero >= 100
     print("[parity] polygon intersection vs exact rational oracle: worst relative error %.2e" % worst)
+
+
+def test_fused_adam_reads_torch_adam_state():
+    """the default optimiser of horizonnet_amd.train is FusedAdam, the reference's checkpoint.pth.tar holds
+    torch.optim.Adam's state (train.py:216-225,336-346: Adam over the parameters with requires_grad).  The conversion
+    scatters exp_avg / exp_avg_sq to the engine's flat offsets; SGD state restarts the moments with a warning."""
+    from horizonnet_amd import _lib
+    from horizonnet_amd.optim import torch_adam_state_to_flat
+    L = _lib.load()
+    torch.manual_seed(11)
+    net = HorizonNet("resnet50", True)
+    for blk in net.feature_extractor.list_blocks()[:2]:            # --freeze_earlier_blocks 1
+        for m in blk:
+            for p in m.parameters():
+                p.requires_grad = False
+    live = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(live, lr=3e-4, betas=(0.8, 0.99), eps=1e-7, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(12)
+    for _ in range(2):
+        for p in live:
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        opt.step()
+    sd = opt.state_dict()
+    entries = [(int(L.hn_grad_offset(k.encode())), k, tuple(p.shape), bool(p.requires_grad)) for k, p in net.named_parameters()]
+    total = int(L.hn_grad_floats())
+    m, v, step, hyper = torch_adam_state_to_flat(sd, entries, total)
+    assert step == 2 and hyper == {"lr": 3e-4, "betas": (0.8, 0.99), "eps": 1e-7, "weight_decay": 1e-3}
+    idx, covered = 0, torch.zeros(total, dtype=torch.bool)
+    for o, k, shape, req in entries:
+        n = int(np.prod(shape))
+        if req:
+            assert torch.equal(m[o:o + n].view(shape), sd["state"][idx]["exp_avg"]), k
+            assert torch.equal(v[o:o + n].view(shape), sd["state"][idx]["exp_avg_sq"]), k
+            covered[o:o + n] = True
+            idx += 1
+    assert idx == len(live) and float(m[~covered].abs().sum()) == 0.0        # frozen parameters and alignment gaps stay zero
+    # an optimiser over ALL parameters (no filter) maps one to one as well
+    opt_all = torch.optim.Adam(net.parameters(), lr=1e-4)
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 2e-3)
+    opt_all.step()
+    m2, _, step2, _ = torch_adam_state_to_flat(opt_all.state_dict(), entries, total)
+    o, k, shape, _ = entries[0]
+    assert step2 == 1 and torch.equal(m2[o:o + int(np.prod(shape))].view(shape), opt_all.state_dict()["state"][0]["exp_avg"])
+    # SGD state: hyper-parameters only, moments restart
+    sgd = torch.optim.SGD(live, lr=0.1, momentum=0.9)
+    sgd.step()
+    with pytest.warns(RuntimeWarning, match="not Adam"):
+        m3, v3, step3, hyper3 = torch_adam_state_to_flat(sgd.state_dict(), entries, total)
+    assert step3 == 0 and float(m3.abs().sum()) == 0.0 and hyper3["lr"] == 0.1
+    with pytest.raises(KeyError):
+        torch_adam_state_to_flat({"foo": 1}, entries, total)
+
+
+def test_resume_restores_each_ranks_own_rng_streams(tmp_path):
+    """only rank 0 writes the checkpoint; every rank must continue ITS OWN torch / numpy streams (dropout seeds,
+    augmentation draws), not rank 0's.  Without per-rank states (older checkpoint, other world size) ranks > 0 are
+    re-seeded deterministically and differently from rank 0."""
+    torch.manual_seed(1)
+    net = HorizonNet("resnet50", True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    args = argparse.Namespace(best_valid_score=0.0, cur_iter=7)
+    states, nxt = [], []
+    for r in range(2):
+        np.random.seed(100 + r)
+        torch.manual_seed(100 + r)
+        states.append({"torch": torch.get_rng_state(), "numpy": np.random.get_state()})
+        nxt.append((np.random.rand(), float(torch.rand(1))))
+    hutils.save_checkpoint(hutils.make_checkpoint(net, opt, 1, args, rng_ranks=states), False, str(tmp_path), 1)
+    path = str(tmp_path / "checkpoint.pth.tar")
+    for r in range(2):
+        a = argparse.Namespace(best_valid_score=0, cur_iter=0, iters_per_epoch=4)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        hutils.resume_checkpoint(path, net, opt, a, torch.device("cpu"), rank=r, world=2)
+        assert a.rng_restore == "own" and (np.random.rand(), float(torch.rand(1))) == nxt[r]
+    # world size changed: rank 0 continues its stream, the others get distinct deterministic seeds
+    draws = {}
+    for r in (0, 1, 2, 2):
+        a = argparse.Namespace(best_valid_score=0, cur_iter=0, iters_per_epoch=4)
+        hutils.resume_checkpoint(path, net, opt, a, torch.device("cpu"), rank=r, world=4)
+        d = (np.random.rand(), float(torch.rand(1)))
+        if r in draws:
+            assert draws[r] == d                                   # deterministic
+        draws[r] = d
+        assert a.rng_restore == ("own" if r == 0 else "reseeded")
+    assert draws[0] == nxt[0] and len({draws[0], draws[1], draws[2]}) == 3
