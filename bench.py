@@ -13,7 +13,11 @@ no data-path collective); RCCL is used only for the barrier and the max-over-ran
 
 Prints ONE JSON line (rank 0) with `roofline` (whole forward vs the fp32 MFMA roof, HIP events on the
 launch stream over the timed region; per-kernel-family breakdown from a separate profiled pass) and
-`cpu_baseline` (the oracle restatement of the reference forward timed on the host cores).
+`cpu_baseline` (the oracle restatement of the reference forward timed on the host cores).  At --gpus 1 the same line also
+carries the other BASELINE configs as extra keys (`--legs` selects them): `bf16_mode` (plain and pipelined bf16 forward,
+against the bf16 MFMA peak AND the per-layer mixed roofline), `latency_b1` (configs[0]: demo.png through inference()),
+`train_bf16` (configs[2]), `layout` (configs[4]: 1000 panoramas, 3D IoU vs the reference's own inference()),
+`pano_stretch`, `augment_pipeline`.
 """
 import argparse
 import json
@@ -31,6 +35,56 @@ if ROOT not in sys.path:
 FWD_FLOP_PER_PANO = 2.0 * 71_448_920_064          # BASELINE.md section 3 / SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: FP32 matrix peak (spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: BF16 dense MFMA peak (spec)
+
+
+_STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))
+
+
+def conv_table():
+    """Every convolution of the hot path as (name, Cin, Cout, k, Hin, Win, stride_h, stride_w) -- SURVEY.md appendix A."""
+    rows = [("stem", 3, 64, 7, 512, 1024, 2, 2)]
+    H, W, cin = 128, 256, 64
+    for li, (p, n) in enumerate(_STAGES):
+        for j in range(n):
+            s_ = 2 if (j == 0 and li > 0) else 1
+            rows.append(("layer%d.%d.conv1" % (li + 1, j), cin, p, 1, H, W, 1, 1))
+            rows.append(("layer%d.%d.conv2" % (li + 1, j), p, p, 3, H, W, s_, s_))
+            rows.append(("layer%d.%d.conv3" % (li + 1, j), p, 4 * p, 1, H // s_, W // s_, 1, 1))
+            if j == 0:
+                rows.append(("layer%d.0.downsample" % (li + 1), cin, 4 * p, 1, H, W, s_, s_))
+            cin, H, W = 4 * p, H // s_, W // s_
+        ch, gh = [4 * p, 2 * p, 2 * p, p, p // 2], H
+        for k in range(4):
+            rows.append(("ghc%d.%d" % (li, k), ch[k], ch[k + 1], 3, gh, W, 2, 1))
+            gh //= 2
+    return rows
+
+
+def bf16_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
+    """BASELINE.md section 3 / SURVEY.md 8(d): the bf16 forward's governing roofline is MIXED -- per layer
+    max(flops / MFMA peak, unfused bytes / HBM bandwidth), summed (stem / layer1 / layer2 are HBM-bound in bf16).
+    Bytes per conv = (input + output) x 2 B x batch + weights x 2 B; the LSTM's input GEMMs likewise (f32 gate
+    pre-activations), its recurrence at the MFMA peak.  -> (seconds per batch, flops, bytes, seconds of the HBM-bound layers)."""
+    t = fl = by = t_hbm = 0.0
+    for _, cin, cout, k, H, W, sh, sw in conv_table():
+        Ho, Wo = H // sh, W // sw
+        f = 2.0 * Ho * Wo * cout * cin * k * k * B
+        b = (H * W * cin + Ho * Wo * cout) * 2.0 * B + cout * cin * k * k * 2.0
+        t += max(f / peak_flops, b / hbm)
+        t_hbm += b / hbm if b / hbm > f / peak_flops else 0.0
+        fl += f
+        by += b
+    rows = 256.0 * B
+    for _ in range(2):
+        f = 2.0 * rows * 1024 * 4096
+        b = rows * 1024 * 2 + rows * 4096 * 4 + 4096 * 1024 * 2
+        t += max(f / peak_flops, b / hbm)
+        fl += f
+        by += b
+        f = 2.0 * rows * 512 * 2048 * 2
+        t += f / peak_flops
+        fl += f
+    return t, fl, by, t_hbm
 
 
 def shard_for_rank(global_units, world, rank):
@@ -224,21 +278,17 @@ def seeded_net_from_state(seed):
     return net
 
 
-def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
+def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with_curve=True):
     """BASELINE configs[2] (and configs[3] at world > 1): the loop of reference train.py:246-286 on the engine.  Every step
     draws its batch through the device data pipeline INSIDE the timed region -- DeviceBatcher: Pano-Stretch + flip + roll +
     gamma in one fused launch (dataset.py:70-105) plus the host label rasterisation (dataset.py:85,108-120) -- then
     train-mode forward, L1(bon) + BCE-with-logits(cor) (train.py:53-54), backward (all 241 gradients), the data-parallel
     all-reduce when world > 1, Adam (lr 1e-4, poly decay).  Data: synthetic PanoContext-shaped cuboid rooms rendered at
     start-up (no dataset offline), uint8 resident in HBM."""
-    import multiprocessing as mp
     import torch.nn.functional as F
     from horizonnet_amd import broadcast_module_
     from horizonnet_amd.dataset import DeviceBatcher
-    from tools import c5_common as c5
-    cores = max(1, c5.usable_cores() // max(1, world))
-    with mp.get_context("fork").Pool(cores) as pool:
-        imgs, cors = c5.make_rooms(rooms, 20_000 + 1000 * rank, pool, mix=[4])
+    imgs, cors = rooms                                    # rendered by main() BEFORE the first GPU call (fork pool, HIP-free)
     data = DeviceBatcher(images=imgs, corners=cors, device=dev, flip=True, rotate=True, gamma=True, stretch=True)
     net = seeded_net(0).to(dev).train()
     net.train_precision = dtype          # bf16: the three conv GEMMs on the bf16 matrix cores, rest f32
@@ -246,7 +296,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
     from horizonnet_amd.optim import FusedAdam
     opt = FusedAdam(net, lr=1e-4, betas=(0.9, 0.999))     # one hn_adam_step launch over the flat gradient buffer (train.py:216-225,279)
     rng = np.random.RandomState(2000 + rank)
-    total_iters = max(1, warmup + steps)
+    total_iters = max(1, warmup + steps + max(2, steps // 2) + 1)
     state = {"it": 0, "host_s": 0.0}
 
     def draws():                                          # the sampler: random indices, then that batch's augmentation draws
@@ -259,7 +309,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
 
     def step():
         for g_ in opt.param_groups:                       # misc/utils.py:35-46, power 0.9
-            g_["lr"] = 1e-4 * (1.0 - state["it"] / float(total_iters)) ** 0.9
+            g_["lr"] = 1e-4 * max(0.0, 1.0 - state["it"] / float(total_iters)) ** 0.9       # (the overlap block runs past total_iters)
         state["it"] += 1
         th = time.perf_counter()
         x, y_bon, y_cor = next(batches)
@@ -283,10 +333,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
             dist.barrier()
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), loss
+        return max_over_ranks(wall, dist, dev), loss
 
     for _ in range(warmup):
         step()
@@ -315,39 +362,190 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms=96):
                                   "augmentation and label rasterisation inside the timed step, L1 + BCE losses, Adam; %s"
                                   % (2 if world == 1 else 3, "float32 engine" if dtype == "f32" else
                                      "bf16 MFMA conv GEMMs (forward, data and weight gradients), f32 accumulation / BN / LSTM / master weights"),
-                      "batch_per_gpu": B, "global_batch": B * world, "rooms_per_gpu": rooms,
+                      "batch_per_gpu": B, "global_batch": B * world, "rooms_per_gpu": len(cors),
                       "parallelism": "dp%d (one process per GPU, RCCL all-reduce of the flat 326 MB gradient buffer overlapped with backward)" % world},
            "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flop: forward, data gradient, weight gradient GEMMs)",
                         "achieved": round(flop / wall / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(flop / wall / 1e12 / world / peak, 4), "traffic": None,
                         "note": "per GPU, against the dense MFMA peak of the GEMM dtype (%s)" % ("fp32 matrix 157.3 TF" if dtype == "f32" else "bf16 2.5 PF")},
            "host_data_pipeline_ms_per_step": round(host_s / steps * 1e3, 2),
-           "final_loss": float(loss)}
+           "final_loss": float(loss.detach())}
     if rccl is not None:
         out["rccl"] = rccl
     if overlap is not None:
         out["allreduce_overlap"] = overlap
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and with_curve:
         out["loss_curve_check"] = loss_curve_check(dev, dtype)
+    del net, opt, data
+    torch.cuda.empty_cache()
     return out
 
 
-def layout_leg(dev, n, batch):
-    """BASELINE configs[4]: inference.py general-layout path over n Structured3D-shaped synthetic panoramas, engine f32 and
-    bf16 vs the fixtures of the UNMODIFIED reference inference() (tools/c5_layout.py)."""
+def max_over_ranks(value, dist, dev):
+    """MAX over the ranks of a host scalar (the contract's max-over-ranks timing); device tensor for RCCL, host tensor for gloo."""
+    if dist is None:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def layout_leg(dev, n, batch, rooms, pool, dist=None, world=1, rank=0, precisions=("bf16", "f32")):
+    """BASELINE configs[4]: inference.py general-layout path over n Structured3D-shaped synthetic panoramas, engine bf16 (and
+    f32) vs the fixtures of the UNMODIFIED reference inference() (tools/c5_layout.py).  world > 1: the panoramas are
+    sharded over the ranks; rank 0 returns the merged line, the others None."""
     from tools.c5_layout import run_layout_eval
-    r = run_layout_eval(dev, n=n, batch=batch, timing_repeats=2)
+    r = run_layout_eval(dev, n=n, batch=batch, precisions=precisions, timing_repeats=1, rooms=rooms, pool=pool, dist=dist,
+                        world=world, rank=rank)
+    if r is None:
+        return None
     b = r["bf16"]
+    assert b["iou3d_failed"] == 0 and all(r[p_]["iou3d_failed"] == 0 for p_ in precisions), "layout_metrics failed on a predicted layout"
     return {"metric": "layout panoramas/s (inference.py general layout, end to end incl. post-processing) + 3D-IoU parity vs reference",
-            "value": b["panoramas_per_s_end_to_end"], "unit": "panoramas/s", "n_gpus": 1, "steps": 2, "warmup": 1,
-            "ms_per_step": round(b["seconds"] * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": b["panoramas_per_s_end_to_end"], "unit": "panoramas/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": round(b["seconds"] * 1e3, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: %d seeded synthetic Structured3D-shaped panoramas (corner mix 63/17/8/12 %% of 4/6/8/10), "
                                    "briefly-trained checkpoint tests/golden/config5/ckpt_q.npz, uint8 panoramas resident in HBM -> "
-                                   "inference() general layout (engine forward + device peaks + host Manhattan fit), batch %d" % (r["panoramas"], batch)},
-            "iou3d_parity_vs_reference_inference": {"bf16": b, "f32": r["f32"]},
+                                   "inference() general layout (engine forward + device peaks + host Manhattan fit), batch %d, "
+                                   "sharded over %d rank(s)" % (r["panoramas"], batch, world)},
+            "iou3d_parity_vs_reference_inference": {p_: r[p_] for p_ in precisions},
             "render_crc_mismatches": r["render_crc_mismatches"], "corner_mix_reference": r["corner_mix_reference"],
-            "host_cores": r["host_cores"]}
+            "host_cores": r["host_cores"], "host_cores_per_rank": r["host_cores_per_rank"]}
+
+
+def bf16_leg(net, x, dev, steps, f32_out):
+    """The engine's bf16 inference mode on the headline inputs: the plain forward (one stream-ordered call per batch) and the
+    pipelined entry (forward_async: recurrent head of batch i on 32 compute units beside the trunk of batch i+1); both
+    against the bf16 MFMA peak and against the per-layer MIXED roofline that governs this mode."""
+    B = int(x.shape[0])
+    net.precision = "bf16"
+    bon, cor = f32_out
+
+    def run_plain(n):
+        for _ in range(n):
+            out = net(x)
+        return out
+
+    def run_piped(n):
+        pend = None
+        for _ in range(n):
+            nxt = net.forward_async(x)
+            if pend is not None:
+                pend.result()
+            pend = nxt
+        return pend.result()                              # the last batch's head is INSIDE the timed region (pipeline drained)
+
+    res = {}
+    with torch.no_grad():
+        for name, fn in (("plain", run_plain), ("pipelined", run_piped)):
+            hb, hc = fn(2)
+            torch.cuda.synchronize(dev)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter()
+            ev0.record()
+            hb, hc = fn(steps)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t1) / steps
+            res[name] = {"value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "ms_per_step_hip_events": round(ev0.elapsed_time(ev1) / steps, 3),
+                         "max_abs_vs_f32_outputs": round(float(max((hb - bon).abs().max(), (hc - cor).abs().max())), 6)}
+            res[name + "_out"] = (hb, hc)
+    identical = bool(torch.equal(res["plain_out"][0], res["pipelined_out"][0]) and torch.equal(res["plain_out"][1], res["pipelined_out"][1]))
+    del res["plain_out"], res["pipelined_out"]
+    assert net.hip_status(dev) == 0, "persistent LSTM kernel reported a spin time-out (bf16 leg)"
+    net.precision = "f32"
+    t_mixed, fl, by, t_hbm = bf16_mixed_roofline(B)
+    best = max(res["plain"]["value"], res["pipelined"]["value"])
+    ms_best = B / best * 1e3
+    tf = FWD_FLOP_PER_PANO * B / (ms_best * 1e-3) / 1e12
+    return {"value": best, "unit": "panoramas/s", "ms_per_step": round(ms_best, 3),
+            "plain": res["plain"], "pipelined": res["pipelined"], "pipelined_equals_plain_bitwise": identical,
+            "f32_output_max_abs": round(float(max(bon.abs().max(), cor.abs().max())), 3),
+            "roofline": {"bound": "mixed (per layer max(flops / 2.5 PFLOP/s, unfused bytes / 8 TB/s), summed)",
+                         "achieved": best, "peak": round(B / t_mixed, 1), "unit": "panoramas/s", "frac": round(best / (B / t_mixed), 4),
+                         "mixed_roofline_ms_per_batch": round(t_mixed * 1e3, 3), "hbm_bound_layers_ms": round(t_hbm * 1e3, 3),
+                         "algorithmic_flop_per_batch": fl, "unfused_bytes_per_batch": by,
+                         "mfma_only": {"achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)}},
+            "note": "bf16 MFMA convs, f32 accumulate / gates / head; single GPU; NOT the fp32 configuration the headline value is quoted on. "
+                    "value = the faster of the two entries; `pipelined` times K submits AND K collects (the last head inside the region)"}
+
+
+def latency_leg(dev):
+    """BASELINE configs[0]: ONE panorama (assets/demo.png, committed as tests/golden/demo_input_u8.npz) through inference()
+    (inference.py:196-209: forward + general-layout post-processing, no test-time augmentation), latency in ms, beside the
+    CPU oracle's forward on the same input (bounded: 3 forwards).  Seeded random weights: the layout itself is meaningless,
+    the work is the same."""
+    from horizonnet_amd import inference
+    from oracle import horizonnet_ref
+    from oracle.weights import make_state_dict
+    img = np.load(os.path.join(ROOT, "tests", "golden", "demo_input_u8.npz"))["img"]
+    x = torch.from_numpy(img.transpose(2, 0, 1)[None].astype(np.float32) / 255.0)
+    net = seeded_net(0).to(dev).eval()
+    out = {}
+    with torch.no_grad():
+        for prec in ("f32", "bf16"):
+            net.precision = prec
+            times_fwd, times_e2e = [], []
+            for it in range(7):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                bon, cor = net(x.to(dev))
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                try:
+                    inference(net, x, dev, force_raw=False)
+                except Exception:                         # random weights may give < 4 peaks: the raw path has the same device work
+                    inference(net, x, dev, force_raw=True)
+                t2 = time.perf_counter()
+                if it >= 2:
+                    times_fwd.append(t1 - t0)
+                    times_e2e.append(t2 - t1)
+            out[prec] = {"forward_ms": round(1e3 * float(np.median(times_fwd)), 3), "inference_end_to_end_ms": round(1e3 * float(np.median(times_e2e)), 3)}
+    sd = make_state_dict(0, "random")
+    torch.set_num_threads(cpu_cores())
+    horizonnet_ref.forward(x, sd)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        horizonnet_ref.forward(x, sd)
+    cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+    del net
+    return {"workload": "BASELINE configs[0]: demo.png, B=1, host tensor in -> layout out (H2D copy included)", "engine": out,
+            "cpu_oracle_forward_ms": round(cpu_ms, 1), "cpu_cores": cpu_cores(),
+            "reference_cpu_note": "BASELINE.md section 4: unmodified reference inference() on 8 vCPU 0.55-1.11 s"}
+
+
+def cpu_cores():
+    from horizonnet_amd.hostcores import usable_cores
+    return usable_cores()
+
+
+def prepare_rooms(args, world, rank, legs):
+    """Host-side rendering of the synthetic rooms for the train / layout legs in a pool forked BEFORE the first GPU call
+    (forking a process that already holds a HIP runtime and helper threads is undefined behaviour).  The pool is
+    kept for the IoU evaluation of the layout leg (its workers never touch the GPU)."""
+    import multiprocessing as mp
+    from horizonnet_amd.hostcores import rank_cores
+    from tools import c5_common as c5
+    need_train = args.mode == "train" or (args.mode == "forward" and "train" in legs)
+    need_layout = args.mode == "layout" or (args.mode == "forward" and "layout" in legs)
+    if not (need_train or need_layout):
+        return None, {}
+    pool = mp.get_context("fork").Pool(rank_cores(world))
+    rooms = {}
+    t0 = time.perf_counter()
+    if need_train:
+        rooms["train"] = c5.make_rooms(args.rooms, 20_000 + 1000 * rank, pool, mix=[4])
+    if need_layout:
+        n = min(args.panoramas, 1000)
+        if world > 1:                                     # every rank renders only its own shard
+            lo, hi = shard_for_rank(n, world, rank)
+            imgs, gt = c5.make_rooms(hi - lo, c5.VAL_SEED0, pool, first=lo)
+            rooms["layout_shard"] = (lo, hi, imgs, gt)
+        else:
+            rooms["layout"] = c5.make_rooms(n, c5.VAL_SEED0, pool)
+    rooms["render_s"] = round(time.perf_counter() - t0, 1)
+    return pool, rooms
 
 
 def main():
@@ -355,17 +553,35 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="panoramas per GPU per step (configs[1]: 32)")
+    ap.add_argument("--batch", type=int, default=None, help="panoramas per GPU per step (forward: 32 = configs[1]; train: 64 = configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (default, the parity path); bf16 = the engine's bf16 inference mode")
     ap.add_argument("--force-rccl", action="store_true",
                     help="initialise the RCCL process group also at world size 1 (exercises the nccl branch on one GPU)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for --gpus N (nccl = RCCL, the product path; gloo only to exercise the N > 1 "
+                         "code path on a box with one GPU, together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--mode", choices=["forward", "train", "layout"], default="forward",
                     help="forward = the headline metric (default, configs[1]); train = configs[2]/[3]: one optimisation step per step "
                          "incl. the data pipeline; layout = configs[4]: inference.py general-layout path + 3D-IoU vs the reference")
-    ap.add_argument("--panoramas", type=int, default=1000, help="--mode layout: panoramas evaluated")
+    ap.add_argument("--legs", default="all",
+                    help="--mode forward, --gpus 1: extra legs carried by the same JSON line, comma separated out of "
+                         "bf16,latency,train,layout,stretch,augment,cpu ('all', 'none')")
+    ap.add_argument("--panoramas", type=int, default=1000, help="layout leg: panoramas evaluated")
+    ap.add_argument("--rooms", type=int, default=96, help="train leg: synthetic rooms rendered per rank")
+    ap.add_argument("--train-steps", type=int, default=6, help="train LEG of the default run: timed steps (B=64, bf16)")
     args = ap.parse_args()
+    all_legs = ["bf16", "latency", "train", "layout", "stretch", "augment", "cpu"]
+    legs = all_legs if args.legs == "all" else [] if args.legs == "none" else [l for l in args.legs.split(",") if l]
+    for l in legs:
+        if l not in all_legs:
+            raise SystemExit("unknown leg %r (choose from %s)" % (l, ",".join(all_legs)))
+    if args.no_cpu_baseline and "cpu" in legs:
+        legs.remove("cpu")
+    if args.batch is None:
+        args.batch = 64 if args.mode == "train" else 32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -384,22 +600,52 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus != world and not (args.gpus == 1 and world == 1):
         raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    if world > 1 or args.mode != "forward":
+        legs = [] if args.mode == "forward" else legs      # the extra legs belong to the single-GPU default run
+
+    from horizonnet_amd.hostcores import pin_rank_affinity, rank_cores
+    pin_rank_affinity(local_rank, world)                   # each rank's host threads / pools stay on its own slice of the CPUs
+    pool, rooms = prepare_rooms(args, world, rank, legs)   # fork pool + rendering BEFORE the first GPU call
+
+    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     rccl = None
     if world > 1 or args.force_rccl:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
-        rccl = rccl_report(dist, dev, world, rank)       # who is in the job + all-reduce bandwidth over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        rccl = rccl_report(dist, dev, world, rank, mbytes=326 if args.backend == "nccl" else 8)   # who is in the job + all-reduce bandwidth
 
     if args.mode == "layout":
-        print(json.dumps(layout_leg(dev, args.panoramas, args.batch)))
+        if world > 1:                                      # stitch the shards' images back into one index space for the evaluator
+            lo, hi, imgs, gt = rooms["layout_shard"]
+            n = min(args.panoramas, 1000)
+            full = np.zeros((n,) + imgs.shape[1:], np.uint8)
+            full[lo:hi] = imgs
+            parts = [None] * world
+            dist.all_gather_object(parts, (lo, gt))
+            gts = [g for _, gl in sorted(parts, key=lambda t_: t_[0]) for g in gl]
+            lay_rooms = (full, gts)
+        else:
+            lay_rooms = rooms["layout"]
+        out = layout_leg(dev, args.panoramas, args.batch, lay_rooms, pool, dist, world, rank)
+        if rank == 0:
+            out["render_s"] = rooms["render_s"]
+            if rccl is not None:
+                out["rccl"] = rccl
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if args.mode == "train":
-        out = train_leg(dev, world, rank, args.batch, args.steps, args.warmup, dist, args.dtype, rccl)
+        out = train_leg(dev, world, rank, args.batch, args.steps, args.warmup, dist, args.dtype, rccl, rooms["train"])
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:
@@ -422,28 +668,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def run(n):                                          # bf16 as the measured mode: the pipelined entry (forward_async)
+        if args.dtype == "bf16":
+            pend = None
+            for _ in range(n):
+                nxt = net.forward_async(x)
+                if pend is not None:
+                    pend.result()
+                pend = nxt
+            return pend.result()
+        for _ in range(n):
+            out_ = net(x)
+        return out_
+
     with torch.no_grad():
-        for _ in range(args.warmup):
-            net(x)
+        if args.warmup > 0:
+            run(args.warmup)
         barrier()
         stream = torch.cuda.current_stream(dev)
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)                              # HIP events on the stream the kernels are launched on
-        for _ in range(args.steps):
-            bon, cor = net(x)
+        bon, cor = run(args.steps)
         ev1.record(stream)
         barrier()
         wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     assert net.hip_status(dev) == 0, "persistent LSTM kernel reported a spin time-out"
     assert bool(torch.isfinite(bon).all()) and bool(torch.isfinite(cor).all())
-
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall_max = max_over_ranks(wall, dist, dev)
 
     if rank == 0:
         total_panos = B * world * args.steps
@@ -475,17 +729,21 @@ def main():
                          "share": round(v[0] / prof_total, 3)} for k, v in fam.items()}
         igemm_ms = sum(v[0] for k, v in fam.items() if "conv_igemm" in k)
         igemm_fl = sum(v[1] for k, v in fam.items() if "conv_igemm" in k)
-        traffic, traffic_note = None, None               # HBM-side bytes per forward from the committed PMC passes of THIS round's kernels
-        tpath = os.path.join(ROOT, "profiles", "r2_pmc_forward.json")
+        traffic, traffic_note = None, None               # HBM-side bytes per forward from the committed PMC passes of the newest round's kernels
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        if B == 32 and os.path.exists(tpath):
-            rec = json.load(open(tpath))["precisions"][args.dtype]
-            traffic = rec["total_bytes"]
-            traffic_note = ("bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes, profiles/r2_pmc_forward.json "
-                            "(tools/profile_forward.sh); Infinity-Cache hits included; algorithmic minimum %.1f GB -> counter / algorithmic = %.2f; "
-                            "matrix pipe busy %s %% of the conv kernels' cycles" % (
-                                rec["fetch_bytes"] / 1e9, rec["write_bytes"] / 1e9, rec["algorithmic_min_bytes"] / 1e9, rec["counter_over_algorithmic"],
-                                "/".join(str(v["mfma_busy_pct"]) for k, v in rec["by_kernel_family"].items() if k.startswith("conv") and "mfma_busy_pct" in v)))
+        for tname in ("r3_pmc_forward.json", "r2_pmc_forward.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if B == 32 and os.path.exists(tpath):
+                rec = json.load(open(tpath))["precisions"].get(args.dtype)
+                if rec is None:
+                    continue
+                traffic = rec["total_bytes"]
+                traffic_note = ("bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes, profiles/%s "
+                                "(tools/profile_forward.sh); Infinity-Cache hits included; algorithmic minimum %.1f GB -> counter / algorithmic = %.2f; "
+                                "matrix pipe busy %s %% of the conv kernels' cycles" % (
+                                    rec["fetch_bytes"] / 1e9, rec["write_bytes"] / 1e9, tname, rec["algorithmic_min_bytes"] / 1e9, rec["counter_over_algorithmic"],
+                                    "/".join(str(v["mfma_busy_pct"]) for k, v in rec["by_kernel_family"].items() if k.startswith("conv") and "mfma_busy_pct" in v)))
+                break
         out = {
             "metric": "panoramas/s (512x1024 fwd)",
             "value": round(value, 2),
@@ -500,11 +758,11 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch=32 random 512x1024 panos per GPU, ResNet-50 + height-compression + bi-LSTM forward, %s, seeded random-init weights"
-                                   % ("fp32" if args.dtype == "f32" else "bf16 MFMA convs (f32 accumulate, f32 LSTM/head) -- NOT the fp32 config"),
+                                   % ("fp32" if args.dtype == "f32" else "bf16 MFMA convs (f32 accumulate, f32 gates / head), pipelined entry -- NOT the fp32 config"),
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d (independent replicas, no data-path collective)" % world},
             "roofline": {"bound": "mfma", "kernel": "%s (all launches of one forward; implicit-GEMM conv family = %.0f%% of device time)" % (
-                             "hn_forward" if args.dtype == "f32" else "hn_forward_bf16", 100.0 * igemm_ms / prof_total),
+                             "hn_forward" if args.dtype == "f32" else "hn_forward_bf16_submit", 100.0 * igemm_ms / prof_total),
                          "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": traffic_note,
@@ -514,29 +772,40 @@ def main():
                                             "frac": round(igemm_fl / (igemm_ms * 1e-3) / 1e12 / peak, 4)},
                          "breakdown": breakdown},
         }
-        if args.dtype == "f32":
-            # informational: the engine's bf16 inference mode on the same inputs (NOT the headline: configs[1] is fp32)
-            net.precision = "bf16"
-            with torch.no_grad():
-                hb, hc = net(x)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    net(x)
-                torch.cuda.synchronize(dev)
-                dt = (time.perf_counter() - t1) / args.steps
-            net.precision = "f32"
-            out["bf16_mode"] = {"value": round(B / dt, 1), "unit": "panoramas/s", "ms_per_step": round(dt * 1e3, 3),
-                                "max_abs_vs_f32_outputs": round(float(max((hb - bon).abs().max(), (hc - cor).abs().max())), 6),
-                                "f32_output_max_abs": round(float(max(bon.abs().max(), cor.abs().max())), 3),
-                                "note": "bf16 MFMA convs, f32 accumulate/LSTM/head; single GPU; not the fp32 configuration the headline value is quoted on"}
+        if args.dtype == "bf16":
+            t_mixed = bf16_mixed_roofline(B)[0]
+            out["roofline"]["mixed_per_layer"] = {"peak_panoramas_per_s": round(B / t_mixed, 1), "frac": round(B / (ms_per_fwd * 1e-3) / (B / t_mixed), 4),
+                                                  "note": "the governing roofline of the bf16 mode (BASELINE.md section 3)"}
         if rccl is not None:
             out["rccl"] = rccl
-        if not args.no_cpu_baseline and world == 1:     # the CPU reference leg runs on rank 0 of the single-GPU job only
-            out["cpu_baseline"] = cpu_baseline()
-            out["pano_stretch"] = pano_stretch_leg(dev)
-            out["augment_pipeline"] = augment_leg(dev)
+        if world == 1:
+            leg_s = {}
+
+            def timed_leg(key, fn):
+                t_ = time.perf_counter()
+                out[key] = fn()
+                leg_s[key] = round(time.perf_counter() - t_, 1)
+
+            if args.dtype == "f32" and "bf16" in legs:    # informational: the engine's bf16 mode on the same inputs (configs[1] is fp32)
+                timed_leg("bf16_mode", lambda: bf16_leg(net, x, dev, args.steps, (bon, cor)))
+            del net
+            torch.cuda.empty_cache()
+            if "cpu" in legs:                             # the CPU reference leg runs on rank 0 of the single-GPU job only
+                timed_leg("cpu_baseline", cpu_baseline)
+            if "latency" in legs:
+                timed_leg("latency_b1", lambda: latency_leg(dev))
+            if "stretch" in legs:
+                timed_leg("pano_stretch", lambda: pano_stretch_leg(dev))
+            if "augment" in legs:
+                timed_leg("augment_pipeline", lambda: augment_leg(dev))
+            if "train" in legs:                           # configs[2]: B = 64, bf16, data pipeline inside the step
+                timed_leg("train_bf16", lambda: train_leg(dev, 1, 0, 64, args.train_steps, 2, None, "bf16", None, rooms["train"]))
+            if "layout" in legs:                          # configs[4]: 1000 panoramas, end to end, IoU vs the reference's inference()
+                timed_leg("layout", lambda: layout_leg(dev, args.panoramas, 32, rooms["layout"], pool))
+            out["leg_seconds"] = dict(leg_s, render_rooms=rooms.get("render_s"))
         print(json.dumps(out))
+    if pool is not None:
+        pool.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,20 +148,9 @@ _POOL = {"pool": None, "n": 0}
 
 
 def _usable_cores():
-    import math
-    import os
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(math.floor(int(quota) / int(period)))))
-    except (OSError, ValueError):
-        pass
-    return n
+    """Host cores THIS rank may use for the fit workers (hostcores.rank_cores: the cgroup grant divided by the ranks on the node)."""
+    from .hostcores import rank_cores
+    return rank_cores()
 
 
 _SHM = {"bon": None, "cor": None, "mask": None}      # process-shared signal buffers (created before the pool forks)

@@ -83,7 +83,7 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * (model.py:138-156), which depend only on C1..C4, on an engine-owned second HIP stream beside the following ResNet
  * stages (fork / join with events: the caller's stream still orders the whole call); 0 = everything on the caller's
  * stream.  Results are identical either way.
- * "lstm_wide_rows" (16 | 8, default 16) / "lstm_wide_xcds" (1 | 2, default 1): geometry of the wide recurrence kernel of
+ * "lstm_wide_rows" (16 | 8, default 16) / "lstm_wide_xcds" (1 | 2, default 2): geometry of the wide recurrence kernel of
  * hn_forward_bf16_submit (speed only).
  * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores
  * (float32 accumulation, gates, cell state and outputs); 0 = the float32 recurrence kernel of hn_forward.

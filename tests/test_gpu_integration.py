@@ -288,11 +288,50 @@ def test_bench_self_launch_under_rccl():
     """`python bench.py --gpus 1 --force-rccl` (the one-GPU form of what the driver runs at N = 2, 4, 8): prints one JSON
     line carrying the RCCL report."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-rccl", "--steps", "2", "--warmup", "1",
-                          "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                          "--batch", "4", "--legs", "none"], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, MASTER_PORT="29657"))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["rccl"]["backend"] == "nccl" and rec["rccl"]["world_size_seen_by_rccl"] == 1 and rec["value"] > 0
+
+
+def _bench_two_ranks(extra, timeout=1200):
+    """`python bench.py --gpus 2 ...` WITHOUT torchrun's environment: bench.py becomes the launcher (the re-exec branch the
+    driver's N = 2, 4, 8 runs go through), both ranks share the box's one GPU, gloo stands in for RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"] + extra,
+                         capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line (rank 0 only): %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_self_launch_forward():
+    """the self-launch branch of bench.py had never executed.  Forward mode, 2 ranks x B = 2: rendezvous on
+    127.0.0.1, the report of who is in the job, shard_for_rank, barrier + max-over-ranks timing, rank-0-only printing."""
+    rec = _bench_two_ranks(["--batch", "2", "--steps", "2", "--warmup", "1"])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["rccl"]["world_size_seen_by_rccl"] == 2 and len(rec["rccl"]["devices"]) == 2 and rec["rccl"]["backend"] == "gloo"
+    assert "bf16_mode" not in rec and "layout" not in rec                  # the extra legs belong to the single-GPU run
+
+
+def test_bench_two_rank_self_launch_train():
+    """configs[3] code path at 2 ranks: per-rank rooms, broadcast of rank 0's weights, segmented backward with the bucketed
+    all-reduce of every gradient range, the overlap block (step with / without the exchange)."""
+    rec = _bench_two_ranks(["--mode", "train", "--dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0 and np.isfinite(rec["final_loss"])
+    assert rec["allreduce_overlap"]["ms_per_step_with_allreduce"] > 0 and rec["rccl"]["world_size_seen_by_rccl"] == 2
+
+
+def test_bench_two_rank_self_launch_layout():
+    """configs[4] sharded over 2 ranks: every rank renders and infers its own contiguous shard, rank 0 merges the layouts
+    and evaluates all of them against the reference's -- same parity as the single-rank run on the same panoramas."""
+    rec = _bench_two_ranks(["--mode", "layout", "--panoramas", "96", "--batch", "16"])
+    assert rec["n_gpus"] == 2 and rec["render_crc_mismatches"] == 0 and rec["host_cores_per_rank"] >= 1
+    par = rec["iou3d_parity_vs_reference_inference"]
+    assert par["f32"]["iou3d_failed"] == 0 and par["f32"]["iou3d_mean"] > 0.9999 and par["f32"]["corner_count_mismatches"] == 0
+    assert par["bf16"]["iou3d_mean"] > 0.99
 
 
 # ---- inference.py:174-223 call sequence --------------------------------------------------------------------------
@@ -381,7 +420,12 @@ def test_config5_layouts_vs_reference_inference(golden_dir):
     print("[parity] config 5:", json.dumps({k: v for k, v in res.items() if k != "per_image"}))
     assert res["render_crc_mismatches"] == 0
     f32, bf16 = res["f32"], res["bf16"]
+    assert f32["iou3d_failed"] == 0 and bf16["iou3d_failed"] == 0         # layout_metrics evaluated EVERY predicted layout
     assert f32["signal_max_abs_vs_reference"] < 2e-5
+    # all 1000 panoramas' signals, through their float64 sums (reference_layouts.npz: signal_sum): 2048 / 1024 elements per
+    # sum, so 2e-5 per element bounds the sum's deviation by 0.04 / 0.02 -- measured far below
+    s32 = f32["signal_sum_max_abs_vs_reference"]
+    assert s32["panoramas"] == 1000 and s32["bon"] < 2048 * 2e-6 and s32["cor"] < 1024 * 2e-5, s32
     assert f32["corner_count_mismatches"] <= 1 and f32["iou3d_mean"] > 0.9999       # a 1e-7 signal difference may flip one vote in 1000
     assert bf16["iou3d_mean"] >= 0.999 and bf16["corner_count_mismatches"] <= 10
 

@@ -14,11 +14,25 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda:0")
 net = seeded_net(0).to(dev).eval()
-net.precision = prec
+piped = prec == "bf16p"          # bf16 through the pipelined entry (forward_async: head of batch i beside the trunk of batch i+1)
+net.precision = "bf16" if piped else prec
+if len(sys.argv) > 4:            # geometry of the wide recurrence kernel: rows,xcds
+    r_, x_ = sys.argv[4].split(",")
+    net.set_engine_option("lstm_wide_rows", int(r_))
+    net.set_engine_option("lstm_wide_xcds", int(x_))
 x = torch.rand(B, 3, 512, 1024, generator=torch.Generator().manual_seed(1000)).to(dev)
 with torch.no_grad():
+    pend = None
     for _ in range(N):
-        bon, cor = net(x)
+        if piped:
+            p_ = net.forward_async(x)
+            if pend is not None:
+                bon, cor = pend.result()
+            pend = p_
+        else:
+            bon, cor = net(x)
+    if piped:
+        bon, cor = pend.result()
 torch.cuda.synchronize()
 assert net.hip_status(dev) == 0
 print("PROF_TARGET precision=%s B=%d forwards=%d" % (prec, B, N))
