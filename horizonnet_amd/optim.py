@@ -44,6 +44,7 @@ class FusedAdam:
         self.m = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.net.defer_grad_mean = True       # data-parallel backward leaves the gradient SUM; step() applies 1/world in the same launch
         self._ptr_sig = None
         self._ptrs = None
         self._active = None
@@ -103,8 +104,10 @@ class FusedAdam:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.hn_adam_step(_lib.ptr(ptrs), _lib.ptr(self.offsets), _lib.ptr(self.ends), _lib.ptr(active), len(self.order),
                                              ctypes.c_void_p(base), _lib.ptr(self.m), _lib.ptr(self.v), self.total, g["lr"], g["betas"][0],
-                                             g["betas"][1], g["eps"], g["weight_decay"], self.step_count, float(grad_scale),
+                                             g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
+                                             float(grad_scale) * float(getattr(self.net, "_grad_mean_scale", 1.0)),
                                              _lib.stream_ptr(self.device)), "hn_adam_step")
+        self.net._grad_mean_scale = 1.0      # consumed: the next backward sets it again
         self.net._train_steps += 1           # parameters changed behind torch's version counters: the engine re-packs
 
     def state_dict(self):

@@ -555,10 +555,25 @@ g0 = grads(xs[0:1], wb[0:1], False)
 g1 = grads(xs[1:2], wb[1:2], False)
 want = 0.5 * (g0 + g1)
 err = float((g_dp - want).norm() / want.norm())
+# FusedAdam's form: backward leaves the SUM over the ranks, the 1 / world goes into hn_adam_step's grad_scale
+net.defer_grad_mean = True
+g_sum = grads(xs[rank:rank + 1], wb[rank:rank + 1], True)
+err_sum = float((g_sum - 2.0 * want).norm() / want.norm()) + abs(net._grad_mean_scale - 0.5)
+net.defer_grad_mean = False
+# bf16 on the wire (half the xGMI bytes): the mean of bf16-rounded sums
+net.allreduce_dtype = "bf16"
+try:
+    g_h = grads(xs[rank:rank + 1], wb[rank:rank + 1], True)
+    err_h = float((g_h - want).norm() / want.norm())
+except RuntimeError as e:          # gloo builds without bf16 reductions on device tensors: RCCL has them
+    err_h = -1.0
+net.allreduce_dtype = "f32"
 allr = [None] * world
-dist.all_gather_object(allr, err)
+dist.all_gather_object(allr, (err, err_sum, err_h))
 if rank == 0:
-    print("DPERR %%.3e %%.3e status %%d" %% (allr[0], allr[1], net.hip_status(dev)))
+    print("DPERR %%.3e %%.3e status %%d" %% (allr[0][0], allr[1][0], net.hip_status(dev)))
+    print("DPSUM %%.3e %%.3e" %% (allr[0][1], allr[1][1]))
+    print("DPBF16 %%.3e %%.3e" %% (allr[0][2], allr[1][2]))
 dist.destroy_process_group()
 """
 
@@ -580,3 +595,8 @@ def test_two_rank_data_parallel_gradients(tmp_path):
     print("[parity] data-parallel gradient vs mean of shard gradients:", line)
     e0, e1 = float(line.split()[1]), float(line.split()[2])
     assert e0 < 1e-5 and e1 < 1e-5 and line.endswith("status 0")
+    sums = [float(v) for v in [l for l in out.stdout.splitlines() if l.startswith("DPSUM")][0].split()[1:]]
+    halves = [float(v) for v in [l for l in out.stdout.splitlines() if l.startswith("DPBF16")][0].split()[1:]]
+    print("[parity] deferred mean (sum left for FusedAdam):", sums, " bf16 wire:", halves)
+    assert max(sums) < 1e-5
+    assert all(h < 0 or 1e-5 < h < 1e-2 for h in halves)          # bf16 rounding of the summed ranges: ~2^-9 relative; -1 = backend lacks bf16
