@@ -103,6 +103,115 @@ def layout_from_signals(y_bon, y_cor, H=512, W=1024, force_cuboid=False, force_r
     return cor_id, z0, z1
 
 
+_TABLES = {}
+
+
+def _trig_tables(W):
+    """np.sin / np.cos of the longitude of every image column (post_proc.py:22-23), plus entry W: of u = -1, the default the
+    reference's inferred walls carry (post_proc.py:251-262).  numpy's values, so that hn_layout_fit_batch reproduces them."""
+    if W not in _TABLES:
+        u = np.concatenate([postproc.col_to_u(np.arange(W), W), [-1.0]])
+        _TABLES[W] = (np.ascontiguousarray(np.sin(u)), np.ascontiguousarray(np.cos(u)))
+    return _TABLES[W]
+
+
+def layouts_from_signals_batch(y_bon, y_cor, mask_main, mask_zero=None, H=512, W=1024, force_cuboid=False, threads=1):
+    """The host half of inference.py:89-141 for a BATCH: y_bon [B,2,W] float32 latitudes (radians), y_cor [B,W] float32 corner
+    probability, mask_main / mask_zero [B,W] uint8 corner peaks at the caller's threshold / at 0 (the cuboid fallback's)
+    -> list of (cor_id, z0, z1), bit-identical to B calls of ``layout_from_signals``.
+
+    Every transcendental function is evaluated by numpy on whole [B, W] arrays (numpy's elementwise results do not depend on
+    the array shape), the data-dependent part -- votes, the wall state machine, the validity test, the cuboid fallback --
+    runs in the native library on `threads` threads (hn_layout_fit_batch), and the corner points go back through numpy."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    B = int(y_bon.shape[0])
+    if B == 0:
+        return []
+    assert W == 1024 and H == 512, "the reference's floor-plan constants are those of a 1024 x 512 panorama"
+    PI = postproc.PI
+    yb = (np.asarray(y_bon, np.float32) / np.pi + 0.5) * H - 0.5
+    yb[:, 0] = np.clip(yb[:, 0], 1, H / 2 - 1)
+    yb[:, 1] = np.clip(yb[:, 1], H / 2 + 1, H - 2)
+    z0 = 50
+    # np_refine_by_fix_z (post_proc.py:109-123), float32 like the per-panorama path: only z1 is used downstream
+    v0 = postproc.row_to_v(yb[:, 0], H)
+    v1 = postproc.row_to_v(yb[:, 1], H)
+    zz = (z0 / np.tan(v0)) * np.tan(v1)
+    lo = np.percentile(zz, 25, axis=1)              # (two calls: np.percentile(zz, [25, 75]) interpolates in float64 and differs)
+    hi = np.percentile(zz, 75, axis=1)
+    z1 = np.empty(B, np.float32)
+    for b in range(B):
+        z1[b] = zz[b][(lo[b] <= zz[b]) & (zz[b] <= hi[b])].mean()
+    tol = np.abs(0.16 * z1 / 1.6)                                           # inference.py:111, float32 arithmetic
+    # np_coor2xy of (column, ceiling row) (post_proc.py:29-43) in float64, all panoramas at once
+    sin_u, cos_u = _trig_tables(W)
+    v = postproc.row_to_v(yb[:, 0].astype(np.float64), H)
+    c = z0 / np.tan(v)
+    xs = np.ascontiguousarray(c * sin_u[None, :W] + W / 2 - 0.5)
+    ys = np.ascontiguousarray(-c * cos_u[None, :W] + H / 2 - 0.5)
+    prob = np.asarray(y_cor, np.float32)
+    tol64 = np.ascontiguousarray(tol, np.float64)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)                            # noqa: E731
+
+    def top4_mask(mask_row, p_row):
+        """inference.py:25-28 with N = 4: the four most probable peaks (numpy's argsort decides ties), as a mask."""
+        pk = np.where(mask_row != 0)[0]
+        pk = pk[np.argsort(-p_row[pk])[:4]]
+        m = np.zeros(W, np.uint8)
+        m[pk] = 1
+        return m
+
+    def run(idx, masks, cuboid):
+        n = len(idx)
+        pts_, npts_, flags_ = np.empty((n, 64, 2), np.float64), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        xs_, ys_, tol_ = (xs, ys, tol64) if n == B else (np.ascontiguousarray(xs[idx]), np.ascontiguousarray(ys[idx]), np.ascontiguousarray(tol64[idx]))
+        _lib.check(lib.hn_layout_fit_batch(vp(xs_), vp(ys_), vp(masks), vp(sin_u), vp(cos_u), vp(tol_), n, W, int(cuboid),
+                                           int(max(1, min(threads, n))), vp(pts_), vp(npts_), vp(flags_)), "hn_layout_fit_batch")
+        return pts_, npts_, flags_
+
+    everyone = np.arange(B)
+    if force_cuboid:
+        masks = np.ascontiguousarray(np.stack([top4_mask(mask_main[b], prob[b]) for b in range(B)]))
+        pts, npts, flags = run(everyone, masks, True)
+    else:
+        pts, npts, flags = run(everyone, np.ascontiguousarray(mask_main, np.uint8), False)
+        redo = np.nonzero(flags == 1)[0]
+        if len(redo):                                                        # inference.py:121-126: invalid general layout -> cuboid
+            mz = mask_main if mask_zero is None else mask_zero
+            for _ in redo:
+                print("Fail to generate valid general layout!! Generate cuboid as fallback.", file=sys.stderr)
+            p2, n2, f2 = run(redo, np.ascontiguousarray(np.stack([top4_mask(mz[b], prob[b]) for b in redo])), True)
+            pts[redo], npts[redo], flags[redo] = p2, n2, f2
+    if (flags == 2).any():
+        raise AssertionError("layout fit: panorama(s) %s of the batch hit an assertion of the reference's gen_ww / vote "
+                             "(too few corner peaks, degenerate vote)" % np.nonzero(flags == 2)[0].tolist())
+    # np_xy2coor + infer_coory (post_proc.py:46-66,126-131) on all corner points at once
+    off = np.concatenate([[0], np.cumsum(npts)])
+    P = np.concatenate([pts[b, :npts[b]] for b in range(B)], 0)
+    cor = postproc.plan_to_pano(P, z0, W, H, W, H)
+    zh = np.repeat((z0 + (z1 - z0)).astype(np.float64), npts)              # z0 + h with h = z1 - z0 in float32 (inference.py:128)
+    vv = postproc.row_to_v(cor[:, 1], H)
+    floor_rows = (-np.arctan2(zh, z0 / np.tan(vv)) / PI + 0.5) * H - 0.5
+    out = []
+    for b in range(B):
+        cb = cor[off[b]:off[b + 1]]
+        fb = floor_rows[off[b]:off[b + 1]]
+        k = (2 * int(cb[::2, 0].argmin())) % len(cb)                        # gen_ww's np.roll(cor, -2 * argmin, axis=0) (post_proc.py:357)
+        if k:
+            cb, fb = np.concatenate((cb[k:], cb[:k])), np.concatenate((fb[k:], fb[:k]))
+        cor_id = np.zeros((len(cb) * 2, 2), np.float32)
+        cor_id[0::2, 0] = cb[:, 0]
+        cor_id[0::2, 1] = cb[:, 1]
+        cor_id[1::2, 0] = cb[:, 0]
+        cor_id[1::2, 1] = fb
+        cor_id[:, 0] /= W
+        cor_id[:, 1] /= H
+        out.append((cor_id, z0, z1[b]))
+    return out
+
+
 def _forward_signals(net, x, device, flip, rotate):
     """-> (x_aug, y_bon [B,2,W] radians, y_cor [B,1,W] probability) numpy, augmentations undone and averaged."""
     B = x.shape[0]
@@ -177,7 +286,9 @@ def _fit_shared(task):
 
 
 def _fit_pool(workers):
-    """Process pool for the host Manhattan fit (numpy + the native vote scan; the workers never touch the GPU)."""
+    """Process pool of the NON-default per-panorama fit (native=False; numpy + hn_vote_scan, the workers never touch the GPU).
+    It forks lazily, i.e. possibly after the HIP runtime has been initialised in this process: call it once before the first
+    GPU use if you rely on this path.  The default path (hn_layout_fit_batch) needs no processes at all."""
     import multiprocessing as mp
     if _POOL["pool"] is None or _POOL["n"] != workers:
         if _POOL["pool"] is not None:
@@ -275,14 +386,19 @@ def _raise_if_engine_failed(st):
             ds.raise_if_failed()
 
 
-def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals=False):
-    """Host half: wait for THIS batch's copies, then the Manhattan fits (worker processes for batches of 8 or more).
-    shared_signals: hand the batch to the workers through shared memory (three memcpys + one small tuple per panorama)
-    instead of pickling five arrays per panorama in the calling thread."""
+def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals=False, native=True):
+    """Host half: wait for THIS batch's copies, then the Manhattan fits.  native (default): the batched fit -- numpy for the
+    transcendental arrays, hn_layout_fit_batch on `workers` THREADS inside the library for the decisions (no worker
+    processes, nothing pickled, no fork).  native=False: the per-panorama numpy restatement, inline or on a process pool
+    (shared_signals: shared-memory hand-over instead of pickles); kept as the cross-check of the native path."""
     st["event"].synchronize()
     _raise_if_engine_failed(st)
     B = st["B"]
     y_bon, y_cor, masks = st["bon"].numpy(), st["cor"].numpy(), st["mask"].numpy()
+    if native and not force_raw and W == 1024 and H == 512:
+        keys = list(st["keys"])
+        return layouts_from_signals_batch(y_bon[:B], y_cor[:B], masks[0][:B], masks[keys.index(0.0)][:B] if 0.0 in keys else None,
+                                          H, W, force_cuboid, threads=_usable_cores() if not workers else workers)
     if workers is None:
         workers = min(_usable_cores(), 32) if B >= 8 else 0
     if shared_signals and workers > 1 and B <= _SHM_B and W <= _SHM_W and len(st["keys"]) <= _SHM_MASKS:
@@ -301,22 +417,23 @@ def _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_si
 
 
 def inference_batch(net, x, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
-                    peaks_fn=None, workers=None, shared_signals=False):
+                    peaks_fn=None, workers=None, shared_signals=False, native=True):
     """x [B,3,512,1024]: one engine forward for all B x augmentations, ONE peak-detection launch per threshold for the
-    whole batch (hn_find_peaks), then the host Manhattan fit of the B panoramas spread over `workers` processes
-    (default: the usable host cores, inline for small batches; 0 = inline).  -> list of (cor_id, z0, z1), identical to
-    B calls of ``inference``."""
+    whole batch (hn_find_peaks), then the host Manhattan fit of the B panoramas as ONE batched call (numpy for the
+    transcendental arrays, hn_layout_fit_batch on `workers` threads inside the library; default: this rank's share of the
+    host cores).  native=False: the per-panorama numpy restatement on `workers` forked processes (0 = inline), kept as a
+    cross-check.  -> list of (cor_id, z0, z1), identical to B calls of ``inference``."""
     H, W = tuple(x.shape[2:])
     B = int(x.shape[0])
     if peaks_fn is not None:                     # caller-supplied peak finder: the per-panorama path
         _, y_bon, y_cor = _forward_signals(net, x, device, flip, rotate)
         return [layout_from_signals(y_bon[b], y_cor[b, 0], H, W, force_cuboid, force_raw, min_v, r, peaks_fn) for b in range(B)]
     st = _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth=1)
-    return _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals)
+    return _finish_host(st, H, W, force_cuboid, force_raw, min_v, r, workers, shared_signals, native)
 
 
 def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=False, force_raw=False, min_v=None, r=0.05,
-                     workers=None, depth=2, shared_signals=False):
+                     workers=None, depth=2, shared_signals=False, native=True):
     """Pipelined ``inference_batch`` over an iterable of batches x [B,3,512,1024]: yields one list of (cor_id, z0, z1) per
     batch, in order, identical to ``inference_batch`` batch by batch.  The device half of the next `depth - 1` batches
     (forward, peaks, copies to pinned memory: all asynchronous) is enqueued BEFORE the host half of the current one (the
@@ -335,9 +452,9 @@ def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=F
         sub = nxt
         if len(pending) >= depth:
             st, h, w = pending.popleft()
-            yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals)
+            yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals, native)
     if sub is not None:
         pending.append((_stage_post(sub[0], force_cuboid, min_v, r, depth + 1), sub[1], sub[2]))
     while pending:
         st, h, w = pending.popleft()
-        yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals)
+        yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals, native)

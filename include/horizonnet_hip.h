@@ -262,6 +262,27 @@ int hn_find_peaks(const float* signal, int B, int n, int r, float min_v, int app
 
 /* ---- host step of the Manhattan fit: misc/post_proc.py:75-98 (`vote`) ------------------- */
 
+/* Host function (no device work): the decision half of the Manhattan fit for a BATCH of panoramas on a thread pool inside
+ * the library -- misc/post_proc.py gen_ww (:337-359) with gen_ww_general (:243-334) / gen_ww_cuboid (:205-240) / vote (:75-98),
+ * and the validity test + cuboid fallback of inference.py:113-126.  All pointers are HOST pointers.
+ *   xs, ys      [B][W] float64: floor-plan coordinates of the ceiling boundary per image column = np_coor2xy of (column,
+ *               ceiling row) (post_proc.py:29-43), computed by the caller WITH NUMPY: every transcendental value stays numpy's,
+ *               this function performs only IEEE +, -, *, /, comparisons, sorting and numpy's pairwise summation, so its
+ *               results are bit-identical to the reference's
+ *   peak_mask   [B][W] uint8: the corner columns the fit starts from (hn_find_peaks; for the cuboid fits the caller has
+ *               already reduced them to the 4 most probable, inference.py:25-28 -- ties there follow numpy's argsort)
+ *   sin_u,cos_u [W+1] float64: np.sin / np.cos of np_coorx2u(column); entry W: of u = -1 (the reference's default for
+ *               inferred walls)
+ *   tol         [B] float64 (inference.py:111: abs(0.16 * z1 / 1.6))
+ *   pts         [B][HN_FIT_MAX_CORNERS][2] float64 out: floor-plan corner points, in wall order (the input of np_xy2coor)
+ *   npts, flags [B] int32 out: corner count; 0 = layout fitted, 1 = the general layout is not a valid polygon (the caller
+ *               re-fits that panorama as a cuboid: force_cuboid with its 4 most probable peaks at threshold 0), 2 = one of the
+ *               reference's assertions would have fired (no layout)
+ * W must be 1024 (the reference's floor-plan constants). */
+#define HN_FIT_MAX_CORNERS 64
+int hn_layout_fit_batch(const double* xs, const double* ys, const unsigned char* peak_mask, const double* sin_u, const double* cos_u,
+                        const double* tol, int B, int W, int force_cuboid, int threads, double* pts, int32_t* npts, int32_t* flags);
+
 /* HOST function (no device work, no stream): the decision loop of the reference's `vote` on an ascending float64 sample
  * vector -- the longest run v[i..j] with (v[j] - v[i]) + 1e-9 <= tol that covers at least 40 % of the samples, first maximum in
  * (i, j) row-major order as post_proc.py:78-90's N x N span matrix finds it.  best3 = {span, i, j} (span = -1: none).  The

@@ -234,13 +234,98 @@ def test_host_half_pooled_and_shared_memory_equal_inline(gold):
 
     for lo, hi in ((0, 33), (33, 40)):
         st = staged(lo, hi)
-        inline = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 0)
-        pooled = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 4)
-        shared = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 4, shared_signals=True)
-        assert len(inline) == len(pooled) == len(shared) == hi - lo
-        for a, b, c in zip(inline, pooled, shared):
+        inline = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 0, native=False)
+        pooled = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 4, native=False)
+        shared = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 4, shared_signals=True, native=False)
+        native = inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 3)          # the default: hn_layout_fit_batch
+        assert len(inline) == len(pooled) == len(shared) == len(native) == hi - lo
+        for a, b, c, d in zip(inline, pooled, shared, native):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0]) and a[1:] == b[1:] == c[1:]
+            assert np.array_equal(a[0], d[0]) and d[0].dtype == np.float32 and a[1:] == d[1:]
     # and they are the layouts the single-panorama entry point produces from the same signals
     one = inference(sr.SignalNet(), image_of(g, js[0]), "cpu", peaks_fn=peaks_ref.find_N_peaks)
     st = staged(0, 1)
+    assert np.array_equal(inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 0, native=False)[0][0], one[0])
     assert np.array_equal(inf_mod._finish_host(st, 512, 1024, False, False, None, 0.05, 0)[0][0], one[0])
+
+
+def _signals(g, meta, kinds=None):
+    js = [m["case"] for m in meta if kinds is None or m["kind"] in kinds]
+    xs = torch.cat([image_of(g, j) for j in js], 0)
+    with torch.no_grad():
+        yb, yc = sr.SignalNet()(xs.float())
+    return js, yb.numpy(), torch.sigmoid(yc)[:, 0].contiguous().numpy()
+
+
+def _peak_masks(yc, keys, r=26):
+    mask = np.zeros((len(keys),) + yc.shape, np.uint8)
+    for i, k in enumerate(keys):
+        for b in range(yc.shape[0]):
+            mask[i, b, peaks_ref.find_N_peaks(yc[b], r=r, min_v=k, N=None)[0]] = 1
+    return mask
+
+
+def _per_panorama(yb, yc, mask_main, mask_zero, cuboid):
+    from horizonnet_amd.inference import _MaskPeaks
+    out = []
+    for b in range(yb.shape[0]):
+        keys = {(0.0 if cuboid else 0.05): mask_main[b], 0.0: mask_zero[b] if not cuboid else mask_main[b]}
+        try:
+            out.append(layout_from_signals(yb[b].copy(), yc[b].copy(), 512, 1024, cuboid, False, None, 0.05, _MaskPeaks(keys)))
+        except AssertionError:
+            out.append(None)
+    return out
+
+
+@pytest.mark.parametrize("cuboid", [False, True])
+def test_native_batched_fit_is_bit_identical_to_the_reference_pinned_path(gold, cuboid):
+    """hn_layout_fit_batch + the batched numpy stages (inference.layouts_from_signals_batch) against the per-panorama
+    restatement, which test_inference_end_to_end_bit_exact pins to the UNMODIFIED reference: all 102 fixture rooms -- the
+    three branches of the general-layout state machine, the self-intersection -> cuboid fallbacks, the 'hard' rooms with
+    tied corner probabilities -- as ONE batch, as ragged sub-batches, on 1 and 5 threads: same cor_id bits, same z1."""
+    from horizonnet_amd.inference import layouts_from_signals_batch
+    g, meta = gold
+    js, yb, yc = _signals(g, meta)
+    keys = [0.0] if cuboid else [0.05, 0.0]
+    masks = _peak_masks(yc, keys)
+    want = _per_panorama(yb, yc, masks[0], masks[-1], cuboid)
+    assert all(w is not None for w in want)
+    for lo, hi, threads in ((0, len(js), 5), (0, 1, 1), (1, 34, 1), (34, len(js), 3)):
+        got = layouts_from_signals_batch(yb[lo:hi], yc[lo:hi], masks[0][lo:hi], masks[-1][lo:hi], 512, 1024, cuboid, threads)
+        assert len(got) == hi - lo
+        for a, b in zip(got, want[lo:hi]):
+            assert a[0].dtype == np.float32 and np.array_equal(a[0], b[0]) and a[1] == b[1] == 50
+            assert a[2] == b[2] and type(a[2]) is type(b[2])
+
+
+def test_native_batched_fit_on_perturbed_signals_and_failures(gold):
+    """Decisions away from the fixtures: boundary noise, dropped and spurious corner peaks (300 perturbed rooms).  Wherever
+    the per-panorama path produces a layout the batched path produces the same bits; where the reference's own assertions
+    fire (too few peaks, degenerate votes) the batched path raises too, naming the panorama."""
+    from horizonnet_amd.inference import layouts_from_signals_batch
+    g, meta = gold
+    js, yb, yc = _signals(g, meta)
+    rng = np.random.RandomState(7)
+    n_ok = n_bad = n_fallback_like = 0
+    for rep in range(3):
+        yb2 = yb + rng.normal(0, 0.01 * (rep + 1), yb.shape).astype(np.float32)
+        masks = _peak_masks(yc, [0.05, 0.0])
+        for b in range(len(js)):                                           # drop / add peaks
+            pk = np.nonzero(masks[0, b])[0]
+            if len(pk) > 4 and rng.rand() < 0.5:
+                masks[0, b, rng.choice(pk)] = 0
+            if rng.rand() < 0.3:
+                masks[0, b, rng.randint(1024)] = 1
+        want = _per_panorama(yb2, yc, masks[0], masks[1], False)
+        good = [b for b in range(len(js)) if want[b] is not None]
+        bad = [b for b in range(len(js)) if want[b] is None]
+        got = layouts_from_signals_batch(yb2[good], yc[good], masks[0][good], masks[1][good], 512, 1024, False, 4)
+        for a, b in zip(got, [want[b] for b in good]):
+            assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+        n_ok += len(good)
+        for b in bad:
+            with pytest.raises(AssertionError):
+                layouts_from_signals_batch(yb2[b:b + 1], yc[b:b + 1], masks[0][b:b + 1], masks[1][b:b + 1], 512, 1024, False, 1)
+            n_bad += 1
+    print("perturbed rooms: %d fitted identically, %d rejected by both paths" % (n_ok, n_bad))
+    assert n_ok >= 250
