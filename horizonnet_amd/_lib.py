@@ -23,6 +23,11 @@ SIGNATURES = {
     "hn_pack_weights": (_i, [_vp, _vp, _sz, _vp]),
     "hn_workspace_bytes": (_sz, [_i]),
     "hn_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hn_workspace_pipelined_bytes": (_sz, [_i]),
+    "hn_forward_submit": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+    "hn_forward_collect": (_i, [_vp, _i, _vp]),
+    "hn_pipelined_status_offset_f32": (_i, [_i, _i, _c.POINTER(_sz)]),
+    "hn_lstm_layer_wide": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "hn_check_status": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "hn_set_option": (_i, [_vp, _c.c_char_p, _i]),
     "hn_set_forward_tap": (_i, [_vp, _c.c_char_p, _vp]),

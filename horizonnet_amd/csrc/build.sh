@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libhorizonnet_hip.so
-SRCS="engine.hip engine_bf16.hip train.hip conv_igemm_f32.hip conv_wgrad_f32.hip conv_wgrad_bf16.hip conv_igemm_bf16.hip elementwise.hip train_ops.hip lstm.hip lstm_bf16.hip panostretch.hip augment.hip peaks.hip multi_job.hip layout_fit.hip"
+SRCS="engine.hip engine_bf16.hip train.hip conv_igemm_f32.hip conv_wgrad_f32.hip conv_wgrad_bf16.hip conv_igemm_bf16.hip elementwise.hip train_ops.hip lstm.hip lstm_wide_f32.hip lstm_bf16.hip panostretch.hip augment.hip peaks.hip multi_job.hip layout_fit.hip"
 mkdir -p ../../build/obj
 OBJS=""
 for f in $SRCS; do

@@ -372,34 +372,30 @@ int run_gemm_rows(const float* x, const float* w, const float* scale, const floa
 
 }  // namespace
 
-extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
-                          size_t workspace_bytes, void* stream)
+namespace {
+
+// Buffers of the recurrent head of one in-flight batch (see engine_bf16.hip): the plain forward has one set in Plan, the
+// pipelined entry (hn_forward_submit) two.
+struct HeadBufsF {
+    float* sync;     // HN_SYNC_WORDS uint32
+    float* seq;      // [T*B][1024] column features
+    float* gx;       // [T*B][4096] gate pre-activations
+    float* y1;       // [T*B][1024] layer-0 output
+    float* y2;       // [T*B][1024] layer-1 output
+};
+
+// The convolutional trunk of hn_forward (model.py:248-252,73-81,123-179) on stream s, writing the column features to `seq`.
+int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const Plan& pl, float* seq, hipStream_t s)
 {
-    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward: null argument");
-    HN_REQUIRE(e->packed != nullptr, "hn_forward: hn_pack_weights has not been called");
-    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward: bad B=%d / C_in=%d", B, C_in);
-    HN_REQUIRE((size_t)B * 128 * 256 <= 0x7fffffffull / 2, "hn_forward: batch %d too large for 32-bit row indices", B);
-    const Plan pl = make_plan(B);
-    HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_forward: workspace too small (%zu < %zu)", workspace_bytes,
-               pl.total * sizeof(float));
-    DeviceGuard guard(e->device);
-    HN_REQUIRE(guard.ok, "hn_forward: cannot select device %d", e->device);
-    hipStream_t s = (hipStream_t)stream;
     const Arch& a = arch();
     const float* P = e->packed;
-    float* W = reinterpret_cast<float*>(workspace);
     int rc;
-
-    HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
-    e->prof.clear();
-    e->events_used = 0;
-
     // stem: normalise + 7x7/2 conv + BN + ReLU, then 3x3/2 max-pool  (model.py:248-252,73-76)
     {
         const ConvLayer& c = a.convs[a.stem];
         ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
         if ((rc = hn_stem(x, B, C_in, IMG_H, IMG_W, P + c.w_off, P + c.scale_off, P + c.shift_off, W + pl.xn, W + pl.stem,
-                          W + pl.pool, stream)))
+                          W + pl.pool, (void*)s)))
             return rc;
     }
     if ((rc = e->tap("stem", W + pl.stem, (size_t)B * 256 * 512 * 64 * sizeof(float), s))) return rc;
@@ -459,30 +455,163 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
         const int cq = a.convs[a.ghc_first[li] + 3].cout;
         {
             ProfScope ps(e, s, "upsample_flatten." + std::to_string(li), 0.0);
-            if ((rc = hn_launch_upsample_flatten(gin, W + pl.seq, B, gh, Wd, cq, 256 * li, s))) return rc;
+            if ((rc = hn_launch_upsample_flatten(gin, seq, B, gh, Wd, cq, 256 * li, s))) return rc;
         }
     }
 
-    // bi-LSTM x2 + Linear head (model.py:263-269)
+    return 0;
+}
+
+// The recurrent head (model.py:263-269): bi-LSTM x2 + Linear, on stream s.  wide: the 64-compute-unit recurrence kernel of the
+// pipelined entry (lstm_wide_f32.hip) instead of the 256-workgroup one (lstm.hip).
+int run_head_f(hn_engine* e, int B, const HeadBufsF& hb, float* bon, float* cor, bool wide, hipStream_t s)
+{
+    const Arch& a = arch();
+    const float* P = e->packed;
+    int rc;
+    HN_HIP(hipMemsetAsync(hb.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
     const long rows = (long)T_COLS * B;
-    if ((rc = e->tap("feature", W + pl.seq, (size_t)rows * 1024 * sizeof(float), s))) return rc;
-    const float* lin = W + pl.seq;
-    float* ybuf[2] = {W + pl.y1, W + pl.y2};
+    if ((rc = e->tap("feature", hb.seq, (size_t)rows * 1024 * sizeof(float), s))) return rc;
+    const float* lin = hb.seq;
+    float* ybuf[2] = {hb.y1, hb.y2};
     for (int l = 0; l < 2; ++l) {
         {
             ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".input_gemm", 2.0 * rows * 1024.0 * 4096);
-            if ((rc = run_gemm_rows(lin, P + a.wih_off[l], P + a.ones_off, P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
+            if ((rc = run_gemm_rows(lin, P + a.wih_off[l], P + a.ones_off, P + a.lbias_off[l], hb.gx, rows, 1024, 4096, s))) return rc;
         }
         {
             ProfScope ps(e, s, "bi_rnn.l" + std::to_string(l) + ".recurrence", 2.0 * rows * 512.0 * 2048 * 2);
-            if ((rc = hn_launch_lstm_layer(W + pl.gx, P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l], T_COLS, B, W + pl.sync, s)))
+            if (wide) {
+                if ((rc = hn_launch_lstm_layer_f32_wide(hb.gx, P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l], T_COLS, B, hb.sync, s))) return rc;
+            } else if ((rc = hn_launch_lstm_layer(hb.gx, P + a.whh_off[l][0], P + a.whh_off[l][1], ybuf[l], T_COLS, B, hb.sync, s)))
                 return rc;
         }
         lin = ybuf[l];
     }
-    if ((rc = e->tap("lstm", W + pl.y2, (size_t)rows * 1024 * sizeof(float), s))) return rc;
+    if ((rc = e->tap("lstm", hb.y2, (size_t)rows * 1024 * sizeof(float), s))) return rc;
     ProfScope ps(e, s, "linear", 2.0 * rows * 1024.0 * 12);
-    return hn_launch_linear_head(W + pl.y2, P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
+    return hn_launch_linear_head(hb.y2, P + a.linw_off, P + a.linb_off, bon, cor, T_COLS, B, s);
+}
+
+struct PlanPF {
+    Plan base;
+    size_t sync1, seq1, gx1, y11, y21, total;      // float offsets of the second head buffer set
+};
+
+PlanPF make_plan_pf(int B)
+{
+    PlanPF p;
+    p.base = make_plan(B);
+    size_t off = p.base.total;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    const size_t b = (size_t)B;
+    p.sync1 = take(HN_SYNC_WORDS);
+    p.seq1 = take((size_t)T_COLS * b * 1024);
+    p.gx1 = take((size_t)T_COLS * b * 4096);
+    p.y11 = take((size_t)T_COLS * b * 1024);
+    p.y21 = take((size_t)T_COLS * b * 1024);
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                          size_t workspace_bytes, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward: null argument");
+    HN_REQUIRE(e->packed != nullptr, "hn_forward: hn_pack_weights has not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward: bad B=%d / C_in=%d", B, C_in);
+    HN_REQUIRE((size_t)B * 128 * 256 <= 0x7fffffffull / 2, "hn_forward: batch %d too large for 32-bit row indices", B);
+    const Plan pl = make_plan(B);
+    HN_REQUIRE(workspace_bytes >= pl.total * sizeof(float), "hn_forward: workspace too small (%zu < %zu)", workspace_bytes,
+               pl.total * sizeof(float));
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward: cannot select device %d", e->device);
+    hipStream_t s = (hipStream_t)stream;
+    float* W = reinterpret_cast<float*>(workspace);
+    e->prof.clear();
+    e->events_used = 0;
+    if (int rc = run_trunk_f(e, x, B, C_in, W, pl, W + pl.seq, s)) return rc;
+    const HeadBufsF hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y2};
+    return run_head_f(e, B, hb, bon, cor, false, s);
+}
+
+// ---- pipelined entry (float32): trunk of batch i+1 beside the recurrent head of batch i; see hn_forward_bf16_submit ----------
+extern "C" size_t hn_workspace_pipelined_bytes(int B)
+{
+    if (B < 1) return 0;
+    return make_plan_pf(B).total * sizeof(float);
+}
+
+int hn_ensure_head_stream(hn_engine* e)
+{
+    if (e->head_stream != nullptr) return 0;
+    int least = 0, greatest = 0;          // highest priority: the few workgroups of the recurrence must win the dispatcher's
+    HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));       // arbitration against the thousands of the next batch's convolutions
+    HN_HIP(hipStreamCreateWithPriority(&e->head_stream, hipStreamNonBlocking, greatest));
+    for (int k = 0; k < 2; ++k) {
+        HN_HIP(hipEventCreateWithFlags(&e->ev_trunk[k], hipEventDisableTiming));
+        HN_HIP(hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+extern "C" int hn_forward_submit(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace,
+                                 size_t workspace_bytes, int slot, void* stream)
+{
+    HN_REQUIRE(e && x && bon && cor && workspace, "hn_forward_submit: null argument");
+    HN_REQUIRE(e->packed != nullptr, "hn_forward_submit: hn_pack_weights has not been called");
+    HN_REQUIRE(B >= 1 && C_in >= 3, "hn_forward_submit: bad B=%d / C_in=%d", B, C_in);
+    HN_REQUIRE((size_t)B * 128 * 256 <= 0x7fffffffull / 2, "hn_forward_submit: batch %d too large for 32-bit row indices", B);
+    HN_REQUIRE(slot == 0 || slot == 1, "hn_forward_submit: slot must be 0 or 1 (got %d)", slot);
+    HN_REQUIRE(!e->profiling && e->taps.empty(), "hn_forward_submit: profiling / taps are served by hn_forward only");
+    const PlanPF pp = make_plan_pf(B);
+    HN_REQUIRE(workspace_bytes >= pp.total * sizeof(float), "hn_forward_submit: workspace too small (%zu < %zu; hn_workspace_pipelined_bytes)",
+               workspace_bytes, pp.total * sizeof(float));
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward_submit: cannot select device %d", e->device);
+    if (int rc = hn_ensure_head_stream(e)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    float* W = reinterpret_cast<float*>(workspace);
+    const Plan& pl = pp.base;
+    HeadBufsF hb;
+    if (slot == 0) hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y2};
+    else hb = {W + pp.sync1, W + pp.seq1, W + pp.gx1, W + pp.y11, W + pp.y21};
+    if (e->head_pending[slot]) HN_HIP(hipStreamWaitEvent(s, e->ev_head[slot], 0));   // this slot's seq was last read by the head of two submits ago
+    if (int rc = run_trunk_f(e, x, B, C_in, W, pl, hb.seq, s)) return rc;
+    HN_HIP(hipEventRecord(e->ev_trunk[slot], s));
+    HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_trunk[slot], 0));
+    if (int rc = run_head_f(e, B, hb, bon, cor, true, e->head_stream)) return rc;
+    HN_HIP(hipEventRecord(e->ev_head[slot], e->head_stream));
+    e->head_pending[slot] = true;
+    return 0;
+}
+
+extern "C" int hn_forward_collect(hn_engine* e, int slot, void* stream)
+{
+    HN_REQUIRE(e != nullptr && (slot == 0 || slot == 1), "hn_forward_collect: bad argument");
+    HN_REQUIRE(e->head_pending[slot], "hn_forward_collect: nothing was submitted on slot %d", slot);
+    DeviceGuard guard(e->device);
+    HN_REQUIRE(guard.ok, "hn_forward_collect: cannot select device %d", e->device);
+    HN_HIP(hipStreamWaitEvent((hipStream_t)stream, e->ev_head[slot], 0));
+    return 0;
+}
+
+extern "C" int hn_pipelined_status_offset_f32(int B, int slot, size_t* byte_offset)
+{
+    HN_REQUIRE(B >= 1 && (slot == 0 || slot == 1) && byte_offset, "hn_pipelined_status_offset_f32: bad argument");
+    const PlanPF pp = make_plan_pf(B);
+    *byte_offset = ((slot == 0 ? pp.base.sync : pp.sync1) + HN_STATUS_WORD) * sizeof(float);
+    return 0;
+}
+
+// per-stage entry (tests): one bi-LSTM layer with the wide float32 recurrence kernel of hn_forward_submit
+extern "C" int hn_lstm_layer_wide(const float* gx, const float* whh_fwd, const float* whh_rev, float* y, int T, int B, void* sync_ws,
+                                  void* stream)
+{
+    HN_REQUIRE(gx && whh_fwd && whh_rev && y && sync_ws, "hn_lstm_layer_wide: null pointer");
+    return hn_launch_lstm_layer_f32_wide(gx, whh_fwd, whh_rev, y, T, B, sync_ws, (hipStream_t)stream);
 }
 
 extern "C" int hn_check_status(hn_engine* e, void* workspace, int* status_out)

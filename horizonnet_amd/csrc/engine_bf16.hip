@@ -393,15 +393,7 @@ extern "C" int hn_forward_bf16_submit(hn_engine* e, const float* x, int B, int C
                workspace_bytes, pp.total);
     DeviceGuard guard(e->device);
     HN_REQUIRE(guard.ok, "hn_forward_bf16_submit: cannot select device %d", e->device);
-    if (e->head_stream == nullptr) {          // created on first use: highest priority, so that the few workgroups of the recurrence
-        int least = 0, greatest = 0;          // win the dispatcher's arbitration against the thousands of the next batch's convolutions
-        HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HN_HIP(hipStreamCreateWithPriority(&e->head_stream, hipStreamNonBlocking, greatest));
-        for (int k = 0; k < 2; ++k) {
-            HN_HIP(hipEventCreateWithFlags(&e->ev_trunk[k], hipEventDisableTiming));
-            HN_HIP(hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
-        }
-    }
+    if (int rc = hn_ensure_head_stream(e)) return rc;
     hipStream_t s = (hipStream_t)stream;
     char* W = reinterpret_cast<char*>(workspace);
     const PlanH& pl = pp.base;

@@ -128,6 +128,8 @@ struct ProfScope {
     }
 };
 
+// creates the engine's head stream + its events on first use (hn_forward_submit / hn_forward_bf16_submit)
+int hn_ensure_head_stream(hn_engine* e);
 // element offset of conv `ci`'s packed bf16 weights inside the hn_pack_weights_bf16 buffer (engine_bf16.hip)
 size_t hn_bf16_conv_offset(int ci);
 // ... and of its per-class data-gradient packing (classes in (row parity, column parity) order, as hn_launch_conv_dgrad_bf16

@@ -93,6 +93,8 @@ int hn_launch_maxpool(const float* in, float* out, int B, int Hi, int Wi, int C,
 int hn_launch_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
 int hn_launch_lstm_layer(const float* gx, const float* whh_f, const float* whh_r, float* y, int T, int B,
                          void* sync_ws, hipStream_t s, float* save = nullptr);
+int hn_launch_lstm_layer_f32_wide(const float* gx, const float* whh_f, const float* whh_r, float* y, int T, int B, void* sync_ws,
+                                  hipStream_t s);
 int hn_launch_lstm_bwd_dh(const float* dg_f, const float* dg_r, const float* whh_f, const float* whh_r, float* dh, int B, hipStream_t s);
 int hn_launch_transpose(const float* in, float* out, int R, int C, hipStream_t s);
 int hn_launch_col_stats(const float* a, double* sum, double* sumsq, long M, int C, int lda, hipStream_t s);

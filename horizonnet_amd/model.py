@@ -190,8 +190,8 @@ class _DeviceState:
         self.workspaces.pop(kind, None)      # one batch size resident per kind; the other kinds stay (a validation forward
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)      # between a train forward and its backward is fine)
         ws[:_SYNC_BYTES].zero_()             # arrival counters + the STICKY status word of the persistent LSTM
-        if kind == "bf16p":                  # the second head slot's sync area lies behind the plain plan
-            off = self.pipelined_status_bytes(B)[1] - _STATUS_BYTE
+        if kind in ("bf16p", "f32p"):        # the second head slot's sync area lies behind the plain plan
+            off = self.pipelined_status_bytes(B, kind == "bf16p")[1] - _STATUS_BYTE
             ws[off:off + _SYNC_BYTES].zero_()
         self.workspaces[kind] = (B, ws)
         return ws
@@ -205,15 +205,18 @@ class _DeviceState:
     def train_workspace(self, B):
         return self._workspace("train", B, self.lib.hn_train_workspace_bytes(B))
 
-    def workspace_bf16_pipelined(self, B):
-        return self._workspace("bf16p", B, self.lib.hn_workspace_bf16_pipelined_bytes(B))
+    def workspace_pipelined(self, B, bf16):
+        if bf16:
+            return self._workspace("bf16p", B, self.lib.hn_workspace_bf16_pipelined_bytes(B))
+        return self._workspace("f32p", B, self.lib.hn_workspace_pipelined_bytes(B))
 
-    def pipelined_status_bytes(self, B):
+    def pipelined_status_bytes(self, B, bf16=True):
         """Byte offsets of the two head slots' sticky status words inside the pipelined workspace."""
+        fn = self.lib.hn_pipelined_status_offset if bf16 else self.lib.hn_pipelined_status_offset_f32
         offs = []
         for slot in (0, 1):
             o = ctypes.c_size_t()
-            _lib.check(self.lib.hn_pipelined_status_offset(B, slot, ctypes.byref(o)), "hn_pipelined_status_offset")
+            _lib.check(fn(B, slot, ctypes.byref(o)), "hn_pipelined_status_offset")
             offs.append(int(o.value))
         return offs
 
@@ -245,15 +248,16 @@ class PendingForward:
     """Handle of one ``HorizonNet.forward_async`` call.  ``result()`` makes the CURRENT stream wait for the call's recurrent
     head (a stream-side wait, the host does not block) and returns (bon, cor) -- the reference's ``net(x)`` outputs."""
 
-    def __init__(self, st, slot, bon, cor, ws, status_off, check):
+    def __init__(self, st, slot, bon, cor, ws, status_off, check, bf16=True):
         self._st, self._slot, self._bon, self._cor, self._ws = st, slot, bon, cor, ws
-        self._status_off, self._check, self._done = status_off, check, slot is None
+        self._status_off, self._check, self._done, self._bf16 = status_off, check, slot is None, bf16
 
     def result(self):
         if not self._done:
             dev = self._bon.device
             with torch.cuda.device(dev):
-                _lib.check(self._st.lib.hn_forward_bf16_collect(self._st.handle, self._slot, _lib.stream_ptr(dev)), "hn_forward_bf16_collect")
+                collect = self._st.lib.hn_forward_bf16_collect if self._bf16 else self._st.lib.hn_forward_collect
+                _lib.check(collect(self._st.handle, self._slot, _lib.stream_ptr(dev)), "hn_forward_collect")
                 if self._check:
                     self._st.post_status_read(self._ws, self._status_off)
             self._done = True
@@ -522,13 +526,17 @@ class HorizonNet(nn.Module):
     def forward_async(self, x):
         """Two-stage form of ``forward`` for back-to-back batches (serving loops, ``inference_stream``): enqueues the
         convolutional trunk on the current stream and the recurrent head (bi-LSTM + Linear, reference model.py:263-269) on an
-        engine-owned stream behind it, and returns a ``PendingForward`` at once.  The head's recurrence kernel needs 32 of the
-        256 compute units for 32 panoramas, so the trunk of the NEXT ``forward_async`` call runs beside it: call
-        ``forward_async(x[i+1])`` BEFORE ``pending[i].result()``.  Outputs are bit-identical to ``forward``.  Pipelined for
-        eval mode with ``precision == "bf16"``; every other mode runs ``forward`` and returns a completed handle."""
-        if self.training or self.precision != "bf16":
+        engine-owned stream behind it, and returns a ``PendingForward`` at once.  The head's recurrence kernel needs 32 (bf16)
+        / 64 (f32) of the 256 compute units for 32 panoramas, so the trunk of the NEXT ``forward_async`` call runs beside it:
+        call ``forward_async(x[i+1])`` BEFORE ``pending[i].result()``.  bf16: bit-identical to ``forward``; f32: exact float32
+        with a different summation order in the recurrence (agrees with ``forward`` to ~1e-6).  Train mode runs ``forward``
+        and returns a completed handle."""
+        if self.training:
             bon, cor = self.forward(x)
             return PendingForward(None, None, bon, cor, None, 0, False)
+        if self.precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        bf16 = self.precision == "bf16"
         if x.shape[2] != 512 or x.shape[3] != 1024:
             raise NotImplementedError()
         if not x.is_cuda:
@@ -545,14 +553,16 @@ class HorizonNet(nn.Module):
             st.raise_if_failed()
             bon = torch.empty((B, 2, 1024), dtype=torch.float32, device=x.device)
             cor = torch.empty((B, 1, 1024), dtype=torch.float32, device=x.device)
-            self._pack_bf16(st, x.device)
-            ws = st.workspace_bf16_pipelined(B)
+            if bf16:
+                self._pack_bf16(st, x.device)
+            ws = st.workspace_pipelined(B, bf16)
             slot = st.pipe_slot = 1 - getattr(st, "pipe_slot", 1)
-            _lib.check(st.lib.hn_forward_bf16_submit(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws),
-                                                     ws.numel(), slot, _lib.stream_ptr(x.device)), "hn_forward_bf16_submit")
+            submit = st.lib.hn_forward_bf16_submit if bf16 else st.lib.hn_forward_submit
+            _lib.check(submit(st.handle, _lib.ptr(xin), B, C_in, _lib.ptr(bon), _lib.ptr(cor), _lib.ptr(ws), ws.numel(), slot,
+                              _lib.stream_ptr(x.device)), "hn_forward_submit")
             # bon / cor are written on the engine's head stream: the handle keeps them (and the input the trunk reads on this
             # stream) alive until result() has ordered them on the caller's stream
-            pend = PendingForward(st, slot, bon, cor, ws, st.pipelined_status_bytes(B)[slot], self.check_status_async)
+            pend = PendingForward(st, slot, bon, cor, ws, st.pipelined_status_bytes(B, bf16)[slot], self.check_status_async, bf16)
             pend._keep = xin
         return pend
 
@@ -624,7 +634,7 @@ class HorizonNet(nn.Module):
             val = ctypes.c_int(0)
             _lib.check(st.lib.hn_check_status(st.handle, _lib.ptr(ws), ctypes.byref(val)), "hn_check_status")
             worst = max(worst, val.value)
-            if kind == "bf16p":                      # second head slot of the pipelined workspace
-                off = st.pipelined_status_bytes(B)[1]
+            if kind in ("bf16p", "f32p"):            # second head slot of the pipelined workspace
+                off = st.pipelined_status_bytes(B, kind == "bf16p")[1]
                 worst = max(worst, int(ws[off:off + 4].view(torch.int32).item()))
         return worst

@@ -75,6 +75,22 @@ size_t hn_workspace_bytes(int B);
 int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Pipelined form of hn_forward for back-to-back batches (a serving loop; inference.py:187-209 calls net(x) per panorama):
+ * hn_forward_submit enqueues the convolutional trunk (model.py:73-81,123-179) on `stream` and the recurrent head (bi-LSTM +
+ * Linear, model.py:263-269) on an engine-owned high-priority stream behind it, then returns; the head's recurrence kernel
+ * occupies 64 of the 256 compute units for a batch of 32 (lstm_wide_f32.hip), so the NEXT submit's trunk runs beside it.
+ * `slot` (0 | 1, alternate between consecutive submits) selects one of two head buffer sets in the workspace
+ * (hn_workspace_pipelined_bytes).  bon / cor are valid on `stream` after hn_forward_collect(slot, stream) (a stream-side
+ * wait, no host synchronisation).  Exact float32 like hn_forward; the recurrence sums over k in a different order, so the
+ * outputs agree with hn_forward's to rounding (1e-6), not bit for bit.  hn_pipelined_status_offset_f32: byte offset of the
+ * slot's sticky LSTM status word inside the workspace.  hn_lstm_layer_wide: that recurrence kernel alone (tests). */
+size_t hn_workspace_pipelined_bytes(int B);
+int hn_forward_submit(hn_engine* e, const float* x, int B, int C_in, float* bon, float* cor, void* workspace, size_t workspace_bytes,
+                      int slot, void* stream);
+int hn_forward_collect(hn_engine* e, int slot, void* stream);
+int hn_pipelined_status_offset_f32(int B, int slot, size_t* byte_offset);
+int hn_lstm_layer_wide(const float* gx, const float* whh_fwd, const float* whh_rev, float* y, int T, int B, void* sync_ws, void* stream);
+
 /* Blocking: reads back the device-side status word of the last hn_forward / hn_lstm_layer
  * on this workspace (non-zero = the persistent LSTM kernel's bounded spin gave up). */
 int hn_check_status(hn_engine* e, void* workspace, int* status_out);

@@ -511,3 +511,75 @@ def test_inference_batch_pooled_equals_per_panorama_and_reference(golden_dir):
         flat = [t for p_ in parts for t in p_]
         for a, b in zip(flat, out):
             assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+
+
+@pytest.mark.parametrize("B", [1, 3, 16, 17, 32, 37, 70])
+def test_lstm_layer_wide_f32_stage(B):
+    """The 64-compute-unit float32 recurrence kernel of the pipelined forward (a group = one direction of 16 panoramas,
+    16 members, the layer output as sentinel-filled exchange buffer) against a float64 recurrence and against
+    lstm_layer_kernel (same exact-f32 products, another summation order): ragged batches, B > 64 (second chunk), twice."""
+    from hiputil import P, lib, sp
+    L = lib()
+    T = 256
+    gen = torch.Generator().manual_seed(700 + B)
+    gx = (torch.rand(T * B, 4096, generator=gen) - 0.5) * 2.0
+    whh = [(torch.rand(2048, 512, generator=gen) - 0.5) * 0.12 for _ in range(2)]
+    want = torch.zeros(T, B, 1024, dtype=torch.float64)
+    g3 = gx.view(T, B, 4096).double()
+    for d in range(2):
+        w = whh[d].double()
+        h = torch.zeros(B, 512, dtype=torch.float64)
+        c = torch.zeros(B, 512, dtype=torch.float64)
+        for stp in range(T):
+            t = T - 1 - stp if d else stp
+            i_, f_, gg, o_ = (g3[t, :, d * 2048:(d + 1) * 2048] + h @ w.t()).chunk(4, dim=1)
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
+            h = torch.sigmoid(o_) * torch.tanh(c)
+            want[t, :, d * 512:(d + 1) * 512] = h
+    gxd = gx.to(DEV)
+    wd = [w.to(DEV).contiguous() for w in whh]
+    sync = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    y0 = torch.full((T * B, 1024), float("nan"), device=DEV)
+    _lib.check(L.hn_lstm_layer(P(gxd), P(wd[0]), P(wd[1]), P(y0), T, B, P(sync), sp()), "hn_lstm_layer")
+    first = None
+    for rep in range(2):
+        y = torch.full((T * B, 1024), float("nan"), device=DEV)
+        _lib.check(L.hn_lstm_layer_wide(P(gxd), P(wd[0]), P(wd[1]), P(y), T, B, P(sync), sp()), "hn_lstm_layer_wide")
+        torch.cuda.synchronize()
+        assert int(sync.view(torch.int32)[512]) == 0, "wide f32 LSTM kernel reported a spin time-out"
+        assert report("wide f32 LSTM layer B=%d (run %d) vs float64 recurrence" % (B, rep), y.view(T, B, 1024).cpu().numpy(), want.numpy(), 2e-5)
+        assert float((y - y0).abs().max()) < 1e-5          # vs the 256-workgroup kernel: rounding only
+        if first is None:
+            first = y.clone()
+    assert torch.equal(first, y)                          # deterministic
+
+
+def test_forward_async_f32_pipelined_matches_forward_and_golden(golden_dir):
+    """hn_forward_submit / _collect in float32: four different batches in flight two at a time (the wide recurrence under the
+    load of the next batch's convolutions) agree with the plain forward to recurrence rounding, and the demo panorama still
+    sits on the reference's golden outputs."""
+    net = HorizonNet("resnet50", True)
+    g = np.load(os.path.join(golden_dir, "forward_demo_seed0_bnrandom.npz"))
+    net.load_state_dict(make_state_dict(int(g["seed"]), str(g["bn"])))
+    net = net.to(DEV).eval()
+    gen = torch.Generator().manual_seed(78)
+    xs = [torch.rand(32, 3, 512, 1024, generator=gen).to(DEV) for _ in range(4)]
+    img = np.load(os.path.join(golden_dir, "demo_input_u8.npz"))["img"]
+    xd = torch.from_numpy(img.transpose(2, 0, 1)[None].astype(np.float32) / 255.0).to(DEV)
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in net(x)) for x in xs]
+        got, pend = [], None
+        for x in xs:
+            p = net.forward_async(x)
+            if pend is not None:
+                got.append(pend.result())
+            pend = p
+        got.append(pend.result())
+        torch.cuda.synchronize()
+        assert net.hip_status(DEV) == 0
+        for (b0, c0), (b1, c1) in zip(want, got):
+            assert float((b0 - b1).abs().max()) < 1e-5 and float((c0 - c1).abs().max()) < 1e-5
+        bon, cor = net.forward_async(xd).result()
+        torch.cuda.synchronize()
+    assert report("pipelined f32 forward vs reference golden (bon)", bon.cpu().numpy(), g["bon"], 2e-5)
+    assert report("pipelined f32 forward vs reference golden (cor)", cor.cpu().numpy(), g["cor"], 2e-5)

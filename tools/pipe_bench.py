@@ -52,6 +52,16 @@ with torch.no_grad():
         ms = min(timed(piped, K), timed(piped, K))
         print("pipelined rows=%2d xcds=%d       : %.3f ms  %.1f panoramas/s  status %d" % (rows, xcds, ms, B / ms * 1e3, net.hip_status(dev)))
 
+net.precision = "f32"
+with torch.no_grad():
+    plain(2)
+    ms = timed(plain, 8)
+    print("plain f32 forward             : %.3f ms  %.1f panoramas/s" % (ms, B / ms * 1e3))
+    piped(2)
+    ms = min(timed(piped, 8), timed(piped, 8))
+    print("pipelined f32 forward         : %.3f ms  %.1f panoramas/s  status %d" % (ms, B / ms * 1e3, net.hip_status(dev)))
+net.precision = "bf16"
+
 # the recurrence kernels alone (one layer, B = 32)
 L = _lib.load()
 T = 256
@@ -78,3 +88,21 @@ for rows, xcds in ((16, 1), (16, 2), (8, 1), (8, 2)):
     wide(2)
     print("wide rows=%2d xcds=%d (%3d CUs)  : %.3f ms per layer  status %d" % (rows, xcds, 2 * (B // rows) * 8, timed(wide, 10),
                                                                              int(sync.view(torch.int32)[512])))
+
+wf = [((torch.rand(2048, 512) - 0.5) * 0.12).to(dev) for _ in range(2)]
+
+
+def n32(n):
+    for _ in range(n):
+        _lib.check(L.hn_lstm_layer(P(gx), P(wf[0]), P(wf[1]), P(y), T, B, P(sync), sp(dev)), "f32")
+
+
+def w32(n):
+    for _ in range(n):
+        _lib.check(L.hn_lstm_layer_wide(P(gx), P(wf[0]), P(wf[1]), P(y), T, B, P(sync), sp(dev)), "f32 wide")
+
+
+n32(2)
+print("f32 recurrence (256 CUs)      : %.3f ms per layer" % timed(n32, 10))
+w32(2)
+print("f32 wide recurrence (64 CUs)  : %.3f ms per layer  status %d" % (timed(w32, 10), int(sync.view(torch.int32)[512])))
