@@ -571,6 +571,7 @@ def main():
                          "bf16,latency,train,layout,stretch,augment,cpu ('all', 'none')")
     ap.add_argument("--panoramas", type=int, default=1000, help="layout leg: panoramas evaluated")
     ap.add_argument("--rooms", type=int, default=96, help="train leg: synthetic rooms rendered per rank")
+    ap.add_argument("--plain", action="store_true", help="forward mode: time the plain stream-ordered forward instead of the pipelined entry")
     ap.add_argument("--train-steps", type=int, default=6, help="train LEG of the default run: timed steps (B=64, bf16)")
     args = ap.parse_args()
     all_legs = ["bf16", "latency", "train", "layout", "stretch", "augment", "cpu"]
@@ -668,18 +669,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(n):                                          # bf16 as the measured mode: the pipelined entry (forward_async)
-        if args.dtype == "bf16":
-            pend = None
-            for _ in range(n):
-                nxt = net.forward_async(x)
-                if pend is not None:
-                    pend.result()
-                pend = nxt
-            return pend.result()
+    def run_plain(n):
         for _ in range(n):
             out_ = net(x)
         return out_
+
+    def run(n):
+        """n steps through the pipelined entry (forward_async): the recurrent head of step i runs on 64 (f32) / 32 (bf16)
+        compute units beside the convolutional trunk of step i+1; EVERY step's head, the last one included, completes inside
+        the caller's timed region (result() of the last handle + the synchronisation that ends the region)."""
+        if args.plain:
+            return run_plain(n)
+        pend = None
+        for _ in range(n):
+            nxt = net.forward_async(x)
+            if pend is not None:
+                pend.result()
+            pend = nxt
+        return pend.result()
 
     with torch.no_grad():
         if args.warmup > 0:
@@ -699,6 +706,17 @@ def main():
     assert bool(torch.isfinite(bon).all()) and bool(torch.isfinite(cor).all())
     wall_max = max_over_ranks(wall, dist, dev)
 
+    plain_rec = None
+    if not args.plain:                                   # the plain (one stream-ordered call per batch) forward beside it
+        with torch.no_grad():
+            run_plain(2)
+            barrier()
+            t0 = time.perf_counter()
+            pb, pc = run_plain(args.steps)
+            barrier()
+            pw = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        plain_rec = {"value": round(B * world * args.steps / pw, 2), "ms_per_step": round(pw / args.steps * 1e3, 3),
+                     "max_abs_diff_pipelined_vs_plain_outputs": float(max((pb - bon).abs().max(), (pc - cor).abs().max()))}
     if rank == 0:
         total_panos = B * world * args.steps
         value = total_panos / wall_max
@@ -758,11 +776,13 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch=32 random 512x1024 panos per GPU, ResNet-50 + height-compression + bi-LSTM forward, %s, seeded random-init weights"
-                                   % ("fp32" if args.dtype == "f32" else "bf16 MFMA convs (f32 accumulate, f32 gates / head), pipelined entry -- NOT the fp32 config"),
+                                   % ("fp32" if args.dtype == "f32" else "bf16 MFMA convs (f32 accumulate, f32 gates / head) -- NOT the fp32 config"),
+                       "entry": "plain forward (one stream-ordered call per step)" if args.plain else
+                                "pipelined forward (forward_async: the recurrent head of step i beside the trunk of step i+1; all K heads complete inside the timed region)",
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d (independent replicas, no data-path collective)" % world},
             "roofline": {"bound": "mfma", "kernel": "%s (all launches of one forward; implicit-GEMM conv family = %.0f%% of device time)" % (
-                             "hn_forward" if args.dtype == "f32" else "hn_forward_bf16_submit", 100.0 * igemm_ms / prof_total),
+                             ("hn_forward" if args.plain else "hn_forward_submit") if args.dtype == "f32" else ("hn_forward_bf16" if args.plain else "hn_forward_bf16_submit"), 100.0 * igemm_ms / prof_total),
                          "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": traffic_note,
@@ -776,6 +796,8 @@ def main():
             t_mixed = bf16_mixed_roofline(B)[0]
             out["roofline"]["mixed_per_layer"] = {"peak_panoramas_per_s": round(B / t_mixed, 1), "frac": round(B / (ms_per_fwd * 1e-3) / (B / t_mixed), 4),
                                                   "note": "the governing roofline of the bf16 mode (BASELINE.md section 3)"}
+        if plain_rec is not None:
+            out["plain_forward"] = plain_rec
         if rccl is not None:
             out["rccl"] = rccl
         if world == 1:

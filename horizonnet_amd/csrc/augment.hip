@@ -12,6 +12,8 @@
 // once to f32: correctly rounded except in ~3e-6 of the cases, <= 1 ulp from numpy (tested).
 #include "hn_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int AG_ROWS = 8;
@@ -178,6 +180,167 @@ __global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __res
     }
 }
 
+// The 3 bytes of source pixel `pix` with ONE (unaligned) dword load instead of three byte loads: the load window is shifted back
+// by one byte when it would end behind the dataset (the very last pixel).
+__device__ __forceinline__ unsigned rgb_of(const unsigned char* base, size_t pix, size_t total_bytes)
+{
+    size_t o = pix * 3;
+    unsigned sh = 0;
+    if (o + 4 > total_bytes) { o -= 1; sh = 8; }
+    unsigned v;
+    __builtin_memcpy(&v, base + o, 4);
+    return v >> sh;
+}
+
+// ---- symmetric form (power-of-two H and W): one arctangent per FOUR output pixels, see pano_stretch_sym3_kernel ------------
+// The thread owns the STRETCHED-image column pair (xs, W-1-xs) and the block's row pairs (y, H-1-y); the flip / roll index maps
+// are applied on the way out (out column of stretched column xs: undo the flip, then add the roll).  Bit-identical to
+// augment_kernel (tested).
+constexpr int AG_SYM_R = 4;
+
+struct ColA {
+    int x0, x1;
+    double w0, w1;
+};
+
+__device__ __forceinline__ ColA col_of_a(double refx, int W)
+{
+#pragma clang fp contract(off)
+    const double cx = wrap_legacy(refx, (double)(W - 1));
+    const double fx = floor(cx);
+    ColA c;
+    int x0 = (int)fx;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0);
+    c.x0 = x0;
+    c.x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+    c.w1 = cx - fx;
+    c.w0 = 1.0 - c.w1;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void augment_sym_kernel(const unsigned char* __restrict__ data, float* __restrict__ dst, AugParams p,
+                                                          int H, int W, size_t data_bytes)
+{
+#pragma clang fp contract(off)
+    __shared__ double tan_v[AG_SYM_R];
+    __shared__ double pow_tab[48];
+    __shared__ float u8_tab[256];
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * AG_SYM_R;
+    const int xs = blockIdx.x * 256 + threadIdx.x;       // stretched column of the left half; its mirror is W-1-xs
+    const double PI = 3.141592653589793;
+    if (threadIdx.x < AG_SYM_R) tan_v[threadIdx.x] = tan((((double)(y0 + threadIdx.x) + 0.5) / (double)H - 0.5) * PI);
+    u8_tab[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) pow_tab[threadIdx.x - 64] = POW_TAB[threadIdx.x - 64];
+    __syncthreads();
+    if (xs >= W / 2) return;
+    const int xsb = W - 1 - xs;
+    // output columns of the two stretched columns: xs = flip ? W-1-(x - roll) : x - roll  =>  x = (flip ? W-1-xs : xs) + roll
+    int xoa = (p.flip[b] ? xsb : xs) + p.roll[b];
+    int xob = (p.flip[b] ? xs : xsb) + p.roll[b];
+    xoa = xoa >= W ? xoa - W : xoa;
+    xob = xob >= W ? xob - W : xob;
+
+    const unsigned char* img = data + (size_t)p.index[b] * H * W * 3;
+    float* out = dst + (size_t)b * 3 * H * W;
+    const bool gam = p.use_gamma[b] != 0;
+    const double ge = (double)p.gamma[b];
+
+    if (!p.stretch[b]) {
+#pragma unroll
+        for (int r = 0; r < AG_SYM_R; ++r) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int y = h ? H - 1 - (y0 + r) : y0 + r;
+                const size_t ip = (size_t)p.index[b] * H * W + (size_t)y * W;
+                const unsigned qa = rgb_of(data, ip + xs, data_bytes), qb = rgb_of(data, ip + xsb, data_bytes);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float va = u8_tab[(qa >> (8 * c)) & 0xffu], vb = u8_tab[(qb >> (8 * c)) & 0xffu];
+                    if (gam) { va = pow_01(va, ge, pow_tab); vb = pow_01(vb, ge, pow_tab); }
+                    out[((size_t)c * H + y) * W + xoa] = va;
+                    out[((size_t)c * H + y) * W + xob] = vb;
+                }
+            }
+        }
+        return;
+    }
+
+    const double kx = p.kx[b], ky = p.ky[b];
+    const double u = (((double)xs + 0.5) / (double)W - 0.5) * 2 * PI;
+    const double sin_u = sin(u), cos_u = cos(u);
+    const double u0 = atan2(sin_u * kx / ky, cos_u);
+    const double sin_u0 = sin(u0);
+    const double q0 = u0 / (2 * PI);
+    const ColA ca = col_of_a((q0 + 0.5) * (double)W - 0.5, W);
+    const ColA cb = col_of_a((-q0 + 0.5) * (double)W - 0.5, W);
+
+    // Phase 1: AG_SYM_R independent arctangent chains; phase 2 (per row half): all gathers in flight; phase 3: blend, gamma, stores.
+    int ra0[2][AG_SYM_R], ra1[2][AG_SYM_R];
+    double wy1[2][AG_SYM_R];
+#pragma unroll
+    for (int r = 0; r < AG_SYM_R; ++r) {
+        const double v0 = atan(tan_v[r] * sin_u0 / sin_u * ky);
+        const double qv = v0 / PI;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double refy = ((h ? -qv : qv) + 0.5) * (double)H - 0.5;
+            const double cy = wrap_legacy(refy, (double)(H - 1));
+            const double fy = floor(cy);
+            int yy0 = (int)fy;
+            yy0 = yy0 < 0 ? 0 : (yy0 > H - 1 ? H - 1 : yy0);
+            const int yy1 = yy0 + 1 < H ? yy0 + 1 : H - 1;
+            ra0[h][r] = yy0 * W;
+            ra1[h][r] = yy1 * W;
+            wy1[h][r] = cy - fy;
+        }
+    }
+    const size_t ipix = (size_t)p.index[b] * H * W;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned ta[AG_SYM_R][4], tb[AG_SYM_R][4];
+#pragma unroll
+        for (int r = 0; r < AG_SYM_R; ++r) {
+            ta[r][0] = rgb_of(data, ipix + ra0[h][r] + ca.x0, data_bytes);
+            ta[r][1] = rgb_of(data, ipix + ra0[h][r] + ca.x1, data_bytes);
+            ta[r][2] = rgb_of(data, ipix + ra1[h][r] + ca.x0, data_bytes);
+            ta[r][3] = rgb_of(data, ipix + ra1[h][r] + ca.x1, data_bytes);
+            tb[r][0] = rgb_of(data, ipix + ra0[h][r] + cb.x0, data_bytes);
+            tb[r][1] = rgb_of(data, ipix + ra0[h][r] + cb.x1, data_bytes);
+            tb[r][2] = rgb_of(data, ipix + ra1[h][r] + cb.x0, data_bytes);
+            tb[r][3] = rgb_of(data, ipix + ra1[h][r] + cb.x1, data_bytes);
+        }
+        asm volatile("" ::: "memory");       // every gather of this half is issued before the first store
+#pragma unroll
+        for (int r = 0; r < AG_SYM_R; ++r) {
+            const int y = h ? H - 1 - (y0 + r) : y0 + r;
+            const double w1 = wy1[h][r], w0 = 1.0 - w1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a0 = u8_tab[(ta[r][0] >> (8 * c)) & 0xffu], a1 = u8_tab[(ta[r][1] >> (8 * c)) & 0xffu];
+                const float a2 = u8_tab[(ta[r][2] >> (8 * c)) & 0xffu], a3 = u8_tab[(ta[r][3] >> (8 * c)) & 0xffu];
+                const float b0_ = u8_tab[(tb[r][0] >> (8 * c)) & 0xffu], b1_ = u8_tab[(tb[r][1] >> (8 * c)) & 0xffu];
+                const float b2_ = u8_tab[(tb[r][2] >> (8 * c)) & 0xffu], b3_ = u8_tab[(tb[r][3] >> (8 * c)) & 0xffu];
+                double t1 = 0.0, t2 = 0.0;                   // SciPy's term order, double accumulate, one rounding to f32
+                t1 += (double)a0 * w0 * ca.w0;
+                t1 += (double)a1 * w0 * ca.w1;
+                t1 += (double)a2 * w1 * ca.w0;
+                t1 += (double)a3 * w1 * ca.w1;
+                t2 += (double)b0_ * w0 * cb.w0;
+                t2 += (double)b1_ * w0 * cb.w1;
+                t2 += (double)b2_ * w1 * cb.w0;
+                t2 += (double)b3_ * w1 * cb.w1;
+                float va = (float)t1, vb = (float)t2;
+                if (gam) { va = pow_01(va, ge, pow_tab); vb = pow_01(vb, ge, pow_tab); }
+                out[((size_t)c * H + y) * W + xoa] = va;
+                out[((size_t)c * H + y) * W + xob] = vb;
+            }
+        }
+    }
+}
+
+static bool ag_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
 }  // namespace
 
 extern "C" int hn_augment_batch(const unsigned char* data, int n_images, const int* index, float* dst,
@@ -205,8 +368,14 @@ extern "C" int hn_augment_batch(const unsigned char* data, int n_images, const i
             p.gamma[i] = gamma ? (float)gamma[j] : 1.0f;
             HN_REQUIRE(!p.use_gamma[i] || (p.gamma[i] >= 0.25f && p.gamma[i] <= 4.0f), "augment_batch: gamma %g outside [0.25, 4]", (double)p.gamma[i]);
         }
-        dim3 grid((W + 255) / 256, (H + AG_ROWS - 1) / AG_ROWS, nb);
-        hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, s, data, dst + (size_t)b0 * 3 * H * W, p, H, W);
+        const char* env = getenv("HN_STRETCH_SYM");            // "0": the per-pixel kernel everywhere (A/B measurements, the bit-equality test)
+        if (ag_pow2(H) && ag_pow2(W) && H >= 2 * AG_SYM_R && !(env && env[0] == '0')) {
+            hipLaunchKernelGGL(augment_sym_kernel, dim3((W / 2 + 255) / 256, H / 2 / AG_SYM_R, nb), dim3(256), 0, s, data,
+                               dst + (size_t)b0 * 3 * H * W, p, H, W, (size_t)n_images * H * W * 3);
+        } else {
+            dim3 grid((W + 255) / 256, (H + AG_ROWS - 1) / AG_ROWS, nb);
+            hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, s, data, dst + (size_t)b0 * 3 * H * W, p, H, W);
+        }
         HN_LAUNCH_CHECK();
     }
     return 0;

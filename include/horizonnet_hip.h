@@ -252,6 +252,16 @@ int64_t hn_grad_offset(const char* name);
 int hn_pano_stretch(const float* src, float* dst, const double* kx, const double* ky,
                     int B, int H, int W, int C, void* stream);
 
+/* The same warp with the column and row terms supplied by the caller (DEVICE arrays of float64): col_tables [B][3][W] =
+ * refx, sin(u0), sin(u) per image column (misc/panostretch.py:92,95), tan_v [H] = tan(v) per row (:17-24).  The Python host
+ * computes them with numpy -- the reference's own arithmetic -- so every coordinate term except the per-pixel arctangent is
+ * bit-identical to the reference's, including the case kx == ky, where refx of column 0 sits on SciPy's wrap discontinuity
+ * (0 -+ 1e-13 decides between source column 0 and W-1).  tables_mirror_symmetric: the caller has verified
+ * refx[W-1-x] / sin values mirror those of x exactly, which lets the symmetric kernel share one arctangent between four
+ * pixels.  kx, ky: HOST arrays (ky enters the per-pixel term). */
+int hn_pano_stretch_tables(const float* src, float* dst, const double* kx, const double* ky, const double* col_tables,
+                           const double* tan_v, int tables_mirror_symmetric, int B, int H, int W, int C, void* stream);
+
 /* ---- training-input pipeline: dataset.py:52,82,88-89,95-96,100-104,123 ---------------- */
 
 /* One fused gather for a batch of B training inputs.  data: the dataset resident in HBM,

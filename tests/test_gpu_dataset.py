@@ -83,6 +83,34 @@ def test_augment_batch_vs_oracle_full_images():
             assert u.max() <= 1, (b, a, int(u.max()))
 
 
+def test_augment_symmetric_kernel_equals_per_pixel_kernel():
+    """augment_sym_kernel (one arctangent per four mirror-image pixels; flip / roll applied on the way out) against the
+    per-pixel kernel: identical bits for every augmentation combination."""
+    batcher = ds.DeviceBatcher(ROOT, device=DEV)
+    rng = np.random.RandomState(13)
+    index, augs = [], []
+    for b in range(16):
+        a = {"kx": 1.0, "ky": 1.0, "flip": 0, "rotate": False, "roll": 0, "gamma": 1.0}
+        if b & 1:
+            a["kx"], a["ky"] = float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2))
+        if b & 2:
+            a["flip"] = 1
+        if b & 4:
+            a["rotate"], a["roll"] = True, int(rng.randint(1024))
+        if b & 8:
+            a["gamma"] = float(rng.uniform(0.5, 2))
+        index.append(int(rng.randint(len(batcher))))
+        augs.append(a)
+    os.environ["HN_STRETCH_SYM"] = "0"
+    try:
+        want = ds.augment_images(batcher.data, index, augs).clone()
+    finally:
+        os.environ.pop("HN_STRETCH_SYM", None)
+    got = ds.augment_images(batcher.data, index, augs)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), "symmetric augment kernel differs in %d values" % int((got != want).sum())
+
+
 def test_device_batcher_equals_per_sample_path():
     kw = dict(flip=True, rotate=True, gamma=True, stretch=True)
     batcher = ds.DeviceBatcher(ROOT, device=DEV, **kw)

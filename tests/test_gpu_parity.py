@@ -375,17 +375,12 @@ def test_pano_stretch_demo_golden(golden_dir):
         o = out[i]
         rows = np.concatenate([o[0:4], o[254:258], o[508:512]], 0)
         cols = np.concatenate([o[:, 0:4], o[:, 1020:1024]], 1)
-        if kx == ky:
-            # reference coordinates sit exactly ON SciPy's wrap discontinuity in column 0 (refx = 0 -+ 1e-13):
-            # compare everything except that column (SURVEY.md section 7 "Pano-Stretch coordinate precision")
-            sel = np.ones(1024, bool)
-            sel[0] = False
-            ok &= report("pano_stretch demo kx=ky=%.2f rows (col 0 excluded)" % kx, rows[:, sel], g["rows_%d" % i][:, sel], 1e-6)
-            ok &= report("pano_stretch demo kx=ky=%.2f grid (col 0 excluded)" % kx, o[::8, 8::8], g["grid_%d" % i][:, 1:], 1e-6)
-        else:
-            ok &= report("pano_stretch demo kx=%.2f ky=%.2f rows" % (kx, ky), rows, g["rows_%d" % i], 1e-6)
-            ok &= report("pano_stretch demo kx=%.2f ky=%.2f cols" % (kx, ky), cols, g["cols_%d" % i], 1e-6)
-            ok &= report("pano_stretch demo kx=%.2f ky=%.2f grid" % (kx, ky), o[::8, ::8], g["grid_%d" % i], 1e-6)
+        # kx == ky puts the reference's refx of column 0 exactly ON SciPy's wrap discontinuity (0 -+ 1e-13 decides between
+        # source column 0 and W-1): the column terms come from numpy (hn_pano_stretch_tables), so that column is compared too
+        ok &= report("pano_stretch demo kx=%.2f ky=%.2f rows" % (kx, ky), rows, g["rows_%d" % i], 0.0)
+        if "cols_%d" % i in g.files:
+            ok &= report("pano_stretch demo kx=%.2f ky=%.2f cols" % (kx, ky), cols, g["cols_%d" % i], 0.0)
+        ok &= report("pano_stretch demo kx=%.2f ky=%.2f grid" % (kx, ky), o[::8, ::8], g["grid_%d" % i], 0.0)
         _, cor = pano_stretch(img[:8, :16], g["corners_in"], kx, ky)   # corner half: host closed form
     assert ok
 
@@ -583,3 +578,27 @@ def test_forward_async_f32_pipelined_matches_forward_and_golden(golden_dir):
         torch.cuda.synchronize()
     assert report("pipelined f32 forward vs reference golden (bon)", bon.cpu().numpy(), g["bon"], 2e-5)
     assert report("pipelined f32 forward vs reference golden (cor)", cor.cpu().numpy(), g["cor"], 2e-5)
+
+
+def test_pano_stretch_symmetric_kernel_equals_per_pixel_kernel():
+    """pano_stretch_sym3_kernel (one arctangent per four mirror-image pixels, power-of-two H x W x 3) against the per-pixel
+    kernel: same bits for every pixel, with the kernel's own column terms and with numpy's tables, for random stretch factors
+    including kx == ky and the identity."""
+    rng = np.random.RandomState(11)
+    imgs = torch.from_numpy(rng.rand(6, 512, 1024, 3).astype(np.float32)).to(DEV)
+    kx = [1.37, 0.6, 1.9, 1.25, 1.0, 0.83]
+    ky = [0.71, 1.7, 1.9, 1.25, 1.0, 1.21]
+    for tables in (False, True):
+        os.environ["HN_STRETCH_SYM"] = "0"
+        try:
+            want = pano_stretch_batch(imgs, kx, ky, host_tables=tables).clone()
+        finally:
+            os.environ.pop("HN_STRETCH_SYM", None)
+        got = pano_stretch_batch(imgs, kx, ky, host_tables=tables)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), "symmetric kernel differs (tables=%s): %d pixels" % (tables, int((got != want).sum()))
+    # and the table path against the oracle on the wrap column of a kx == ky warp (numpy decides the side, not device libm)
+    img = imgs[2].cpu().numpy()
+    want, _ = panostretch_ref.pano_stretch(img, np.zeros((1, 2), np.float32), 1.9, 1.9)
+    got = pano_stretch_batch(imgs[2:3], [1.9], [1.9])[0].cpu().numpy()
+    assert report("pano_stretch kx == ky, every column incl. the wrap column", got, want, 0.0)
