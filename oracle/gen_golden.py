@@ -556,11 +556,44 @@ def gen_traincurve():
                         max_iters=np.int64(args.max_iters))
 
 
+def gen_trained():
+    """Full taps on TRAINED weights (the forward goldens above use seeded random weights only): the config-5
+    checkpoint (tests/golden/config5/ckpt_q.npz, trained on synthetic Structured3D-shaped rooms) through the UNMODIFIED
+    reference on two of the config-5 panoramas -- outputs, strided stem / pool / C1..C4, feature and bi-LSTM taps."""
+    import model as ref_model
+    from tools import c5_common as c5
+    net = ref_model.HorizonNet("resnet50", True).eval()
+    sd = c5.decode_state_dict()
+    net.load_state_dict(sd, strict=True)
+    rooms = [0, 7]
+    imgs = np.stack([c5.make_room(c5.room_jobs(1, c5.VAL_SEED0, i)[0])[0] for i in rooms])
+    x = torch.FloatTensor(imgs.transpose(0, 3, 1, 2) / 255)                      # inference.py:199-200
+    with torch.no_grad():
+        bon, cor = net(x)
+        xn = net._prepare_x(x)
+        c = net.feature_extractor(xn)
+        feature = net.reduce_height_module(c, 256)
+        lstm_out, _ = net.bi_rnn(feature.permute(2, 0, 1))
+    taps = {}
+    obon, ocor = horizonnet_ref.forward(x, sd, taps)
+    d_bon, d_cor = (obon - bon).abs().max().item(), (ocor - cor).abs().max().item()
+    print("trained_c5 oracle-vs-reference: bon %.2e cor %.2e |bon|max %.3f |cor|max %.3f" % (d_bon, d_cor, bon.abs().max().item(), cor.abs().max().item()))
+    assert d_bon < 2e-5 and d_cor < 2e-5
+    out = {"bon": bon.numpy(), "cor": cor.numpy(), "feature": feature.numpy()[:, ::8], "lstm": lstm_out.numpy()[::8],
+           "rooms": np.array(rooms), "crc": np.array([c5.image_crc(im) for im in imgs], np.uint32)}
+    for k, st in TAP_STEPS.items():
+        src = taps[k] if k in ("stem", "pool") else c[int(k[1]) - 1]
+        out["tap_" + k] = sample(src, st)
+    np.savez_compressed(os.path.join(GOLD, "forward_trained_c5.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from oracle.hostinfo import usable_cores
     torch.set_num_threads(usable_cores())
     which = sys.argv[1:] or ["model", "panostretch", "peaks", "stretch", "postproc", "dataset", "train"]
+    if "trained" in which:
+        gen_trained()
     if "train" in which:
         gen_train()
     if "train_frozen" in which:

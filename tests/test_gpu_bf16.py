@@ -381,3 +381,33 @@ def test_forward_async_pipelined_bit_identical():
         b_ref, c_ref = net(x3)
         b_got, c_got = net.forward_async(x3).result()
         assert torch.equal(b_ref, b_got) and torch.equal(c_ref, c_got)
+
+
+def test_bf16_forward_trained_checkpoint_vs_emulation_and_reference(golden_dir):
+    """The bf16 mode on TRAINED weights (config-5 checkpoint, two config-5 panoramas): against the CPU emulation of the
+    engine's rounding points (<= 5e-4 of the output scale -- the signals are O(1) here, |cor| up to 7) and, as the precision
+    cost, against the unmodified reference's f32 outputs / taps (printed; bound 5 % of each tap's scale)."""
+    from tools import c5_common as c5
+    g = np.load(os.path.join(golden_dir, "forward_trained_c5.npz"))
+    imgs = np.stack([c5.make_room(c5.room_jobs(1, c5.VAL_SEED0, int(i))[0])[0] for i in g["rooms"]])
+    assert [c5.image_crc(im) for im in imgs] == [int(v) for v in g["crc"]]
+    x = torch.FloatTensor(imgs.transpose(0, 3, 1, 2) / 255)
+    sd = c5.decode_state_dict()
+    ebon, ecor = horizonnet_ref.forward_bf16_emulated(x, sd)
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    net.precision = "bf16"
+    with torch.no_grad():
+        bon, cor, taps = net.forward_with_taps(x.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    s_bon, s_cor = float(np.abs(g["bon"]).max()), float(np.abs(g["cor"]).max())
+    ok = report("bf16 trained c5 vs CPU emulation: bon", bon.cpu().numpy(), ebon.numpy(), 5e-4 * max(1.0, s_bon))
+    ok &= report("bf16 trained c5 vs CPU emulation: cor", cor.cpu().numpy(), ecor.numpy(), 5e-4 * max(1.0, s_cor))
+    ok &= report("bf16 trained c5 vs reference f32: bon (precision cost)", bon.cpu().numpy(), g["bon"], 5e-2 * s_bon)
+    ok &= report("bf16 trained c5 vs reference f32: cor (precision cost)", cor.cpu().numpy(), g["cor"], 5e-2 * s_cor)
+    for k, stp in TAP_STEPS.items():
+        got = taps[k].float()[:, ::stp[0], ::stp[1], ::stp[2]].cpu().numpy()
+        ok &= report("bf16 trained tap %s vs reference f32" % k, got, g["tap_" + k], 5e-2 * float(np.abs(g["tap_" + k]).max()))
+    assert ok

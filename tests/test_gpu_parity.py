@@ -602,3 +602,36 @@ def test_pano_stretch_symmetric_kernel_equals_per_pixel_kernel():
     want, _ = panostretch_ref.pano_stretch(img, np.zeros((1, 2), np.float32), 1.9, 1.9)
     got = pano_stretch_batch(imgs[2:3], [1.9], [1.9])[0].cpu().numpy()
     assert report("pano_stretch kx == ky, every column incl. the wrap column", got, want, 0.0)
+
+
+def _trained_c5_inputs(golden_dir):
+    from tools import c5_common as c5
+    g = np.load(os.path.join(golden_dir, "forward_trained_c5.npz"))
+    imgs = np.stack([c5.make_room(c5.room_jobs(1, c5.VAL_SEED0, int(i))[0])[0] for i in g["rooms"]])
+    assert [c5.image_crc(im) for im in imgs] == [int(v) for v in g["crc"]], "the box rendered different pixels than the build container"
+    return g, torch.FloatTensor(imgs.transpose(0, 3, 1, 2) / 255), c5.decode_state_dict()
+
+
+def test_forward_trained_checkpoint_matches_reference_taps(golden_dir):
+    """the forward goldens pinned intermediates on seeded RANDOM weights only.  The trained config-5 checkpoint
+    through the UNMODIFIED reference on two of the config-5 panoramas (oracle/gen_golden.py gen_trained): outputs within 2e-5
+    (the structured signals are O(1): |bon| 0.75, |cor| 7.1), every tap within 1e-5 of its scale -- plain and pipelined entry."""
+    g, x, sd = _trained_c5_inputs(golden_dir)
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        bon, cor, taps = net.forward_with_taps(x.to(DEV))
+        pb, pc = net.forward_async(x.to(DEV)).result()
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    ok = report("trained c5 forward bon", bon.cpu().numpy(), g["bon"], 2e-5)
+    ok &= report("trained c5 forward cor", cor.cpu().numpy(), g["cor"], 2e-5)
+    ok &= report("trained c5 pipelined forward bon", pb.cpu().numpy(), g["bon"], 2e-5)
+    ok &= report("trained c5 pipelined forward cor", pc.cpu().numpy(), g["cor"], 2e-5)
+    ok &= _check_taps("trained_c5", taps, g, 1e-5)
+    assert ok
+    for b in range(x.shape[0]):          # corner indices (inference.py:105-110) identical on engine and reference outputs
+        a = peaks_ref.find_N_peaks(torch.sigmoid(cor[b, 0]).cpu().numpy(), 26, 0.05, None)[0]
+        r = peaks_ref.find_N_peaks(torch.sigmoid(torch.from_numpy(g["cor"][b, 0])).numpy(), 26, 0.05, None)[0]
+        assert np.array_equal(a, r) and len(a) >= 4
