@@ -372,15 +372,17 @@ def test_forward_async_pipelined_bit_identical():
             for i, ((b0, c0), (b1, c1)) in enumerate(zip(want, got)):
                 assert torch.equal(b0, b1) and torch.equal(c0, c1), "batch %d differs (rows %d, xcds %d): %g" % (
                     i, rows, xcds, float(max((b0 - b1).abs().max(), (c0 - c1).abs().max())))
-        # a small ragged batch through the same path, and the f32 / train fall-back of forward_async (a completed handle)
+        # a small ragged batch through the same path; the f32 entry; the train-mode fall-back
         x3 = xs[0][:3]
         b_ref, c_ref = net(x3)
         b_got, c_got = net.forward_async(x3).result()
         assert torch.equal(b_ref, b_got) and torch.equal(c_ref, c_got)
-        net.precision = "f32"
+        net.precision = "f32"        # f32: exact float32 too, but the wide recurrence sums over k in another order
         b_ref, c_ref = net(x3)
         b_got, c_got = net.forward_async(x3).result()
-        assert torch.equal(b_ref, b_got) and torch.equal(c_ref, c_got)
+        assert float((b_ref - b_got).abs().max()) < 1e-5 and float((c_ref - c_got).abs().max()) < 1e-5
+        net.train()                   # train mode: forward_async is the plain forward, returned as a completed handle
+        assert net.forward_async(x3)._done
 
 
 def test_bf16_forward_trained_checkpoint_vs_emulation_and_reference(golden_dir):

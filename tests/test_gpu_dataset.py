@@ -166,3 +166,14 @@ def test_augment_batch_contract_errors():
     big = ds.augment_images(batcher.data, [i % 4 for i in range(70)], [dict(a, roll=i, rotate=True) for i in range(70)])
     want = dataset_ref.augment_image(batcher.data[1].cpu().numpy(), roll=69)
     assert np.array_equal(big[69].cpu().numpy(), want)                   # second chunk of a > 64 batch
+
+
+def test_images_to_input_equals_reference_conversion():
+    """dataset.images_to_input (the augmentation kernel with every augmentation off) == reference inference.py:196-200:
+    np.array(img)[..., :3].transpose(2, 0, 1) / 255 -> FloatTensor, bit for bit, for all 256 byte values."""
+    rng = np.random.RandomState(1)
+    imgs = rng.randint(0, 256, (3, 512, 1024, 3)).astype(np.uint8)
+    imgs[0, 0, :256, 0] = np.arange(256)
+    want = torch.FloatTensor(np.array([im.transpose(2, 0, 1) / 255 for im in imgs]))
+    got = ds.images_to_input(torch.from_numpy(imgs).to(DEV), [0, 1, 2, 1])
+    assert got.shape == (4, 3, 512, 1024) and torch.equal(got[:3].cpu(), want) and torch.equal(got[3].cpu(), want[1])

@@ -58,6 +58,7 @@ def run_layout_eval(dev, n=1000, batch=32, precisions=("f32", "bf16"), timing_re
     reports n / max-over-ranks time.  Ranks > 0 return None."""
     from horizonnet_amd import HorizonNet
     from horizonnet_amd.inference import inference_stream
+    from horizonnet_amd.dataset import images_to_input
     from horizonnet_amd.hostcores import rank_cores
     z, ref_cor = load_reference()
     n = min(n, int(z["n"]))
@@ -93,7 +94,9 @@ def run_layout_eval(dev, n=1000, batch=32, precisions=("f32", "bf16"), timing_re
                 barrier()
                 t0 = time.perf_counter()
                 out = []
-                feed = (lut[data[a:a + batch].long()].permute(0, 3, 1, 2).contiguous() for a in range(0, m, batch))
+                # inference.py:199-200 (img / 255 -> FloatTensor [B,3,H,W]) as one device pass per batch (dataset.images_to_input);
+                # the signal comparisons below use the torch LUT form of the same conversion, so both are exercised
+                feed = (images_to_input(data, list(range(a, min(a + batch, m)))) for a in range(0, m, batch))
                 for part in inference_stream(net, feed, dev, depth=3):    # GPU on batch i+1, i+2 while the host cores fit batch i
                     out += part
                 barrier()

@@ -14,8 +14,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda:0")
 net = seeded_net(0).to(dev).eval()
-piped = prec == "bf16p"          # bf16 through the pipelined entry (forward_async: head of batch i beside the trunk of batch i+1)
-net.precision = "bf16" if piped else prec
+piped = prec.endswith("p")       # "bf16p" / "f32p": the pipelined entry (forward_async: head of batch i beside the trunk of batch i+1)
+net.precision = prec[:-1] if piped else prec
 if len(sys.argv) > 4:            # geometry of the wide recurrence kernel: rows,xcds
     r_, x_ = sys.argv[4].split(",")
     net.set_engine_option("lstm_wide_rows", int(r_))
