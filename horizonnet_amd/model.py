@@ -412,9 +412,24 @@ class HorizonNet(nn.Module):
 
     # ---- engine plumbing --------------------------------------------------------------------
     def _state_tensors(self):
-        for k, v in self.state_dict(keep_vars=True).items():
-            if not k.endswith("num_batches_tracked"):
-                yield k, v
+        """(key, tensor) of every bound state tensor, in state_dict order.  The module tree is fixed after construction, so the
+        (owner module, kind, name, key) slots are resolved once; per call this is 379 dictionary look-ups instead of a
+        ``state_dict()`` walk (0.74 ms of host time per forward in round 2).  Tensors are looked up afresh every time:
+        ``.to()`` replaces buffers, ``load_state_dict`` / optimiser steps change them in place."""
+        slots = self.__dict__.get("_state_slots")
+        if slots is None:
+            slots = []
+            for prefix, mod in self.named_modules():
+                for name in mod._parameters:
+                    if mod._parameters[name] is not None:
+                        slots.append((mod, 0, name, (prefix + "." if prefix else "") + name))
+                for name in mod._buffers:
+                    if mod._buffers[name] is not None and name not in mod._non_persistent_buffers_set and name != "num_batches_tracked":
+                        slots.append((mod, 1, name, (prefix + "." if prefix else "") + name))
+            order = {k: i for i, k in enumerate(self.state_dict(keep_vars=True).keys())}
+            slots.sort(key=lambda s_: order[s_[3]])
+            self.__dict__["_state_slots"] = slots
+        return [(key, (mod._buffers if kind else mod._parameters)[name]) for mod, kind, name, key in slots]
 
     def _hip_state(self, device):
         st = self._hip_states.get(device.index)
@@ -471,6 +486,7 @@ class HorizonNet(nn.Module):
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_hip_states"] = {}                # (engine options are kept: they are plain ints)
+        d.pop("_state_slots", None)
         return d
 
     def forward(self, x):
