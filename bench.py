@@ -804,8 +804,18 @@ def main():
             leg_s = {}
 
             def timed_leg(key, fn):
+                """An extra leg must never cost the headline line: a failure is reported under the leg's key."""
                 t_ = time.perf_counter()
-                out[key] = fn()
+                try:
+                    out[key] = fn()
+                except Exception as exc:                  # noqa: BLE001  (reported, not swallowed: the key carries the error)
+                    import traceback
+                    out[key] = {"error": "%s: %s" % (type(exc).__name__, exc), "traceback_tail": traceback.format_exc()[-1500:]}
+                    try:
+                        torch.cuda.synchronize(dev)
+                        torch.cuda.empty_cache()
+                    except Exception:                     # noqa: BLE001
+                        pass
                 leg_s[key] = round(time.perf_counter() - t_, 1)
 
             if args.dtype == "f32" and "bf16" in legs:    # informational: the engine's bf16 mode on the same inputs (configs[1] is fp32)
