@@ -610,6 +610,267 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dual_bf16_kernel(DualArgsH p)
     }
 }
 
+// ---- bottleneck tail CHAINED into the next block's conv1 (layer1; reference model.py:78-81 + torchvision Bottleneck) ----------
+//   out = relu(bn3(conv3(t2)) + x)                (1x1, 64 -> 256, the block's output: kept, it is the next residual)
+//   t1' = relu(bn1'(conv1'(out)))                 (1x1, 256 -> 64, the NEXT block's first conv)
+// As two launches the 537 MB `out` (B = 32) is written and immediately read back; on layer1 both launches sit on the HBM roof.
+// Here a workgroup owns 64 pixels: phase 1 computes their 256 output channels (one 64-deep K chunk), the epilogue stores the
+// bf16 rows to HBM AND into LDS as the A operand of phase 2 (4 K chunks x 64 rows x 128 B, the tile loader's slot swizzle),
+// phase 2 multiplies them with W1' (prefetched by LDS-DMA at kernel start) and stores t1'.  80 KB of LDS, 2 workgroups per CU.
+// Same k order and rounding points as the two-launch form: bit-identical (tested).
+struct ChainArgsH {
+    const u16* a1;       // t2 [M][64]
+    const u16* w3;       // [256][64]
+    const float* scale3;
+    const float* shift3;
+    const u16* res;      // block input x [M][256]                      (plain form)
+    const u16* ad;       // block input [M][64] of the downsample branch (DUAL form: block 0, stride 1)
+    const u16* wd;       // downsample weights [256][64]
+    const float* scale_d;
+    const float* shift_d;
+    u16* y;              // out [M][256]
+    const u16* w1n;      // next conv1 [64][256]
+    const float* scale1n;
+    const float* shift1n;
+    u16* y2;             // t1' [M][64]
+    int M;
+    int xcd_swizzle;
+};
+
+constexpr int CH_BM = 64, CH_N1 = 256, CH_N2 = 64;
+constexpr int CH_CS = 0;                         // f32 C staging: 16 rows x 256 floats (epilogue 1) / 64 rows x 64 floats (epilogue 2)
+constexpr int CH_A2 = 16384;                     // out tile as A operand: 4 chunks x 64 rows x 128 B
+constexpr int CH_W1N = CH_A2 + 32768;            // W1': 4 chunks x 64 rows x 128 B
+constexpr int CH_LDS = CH_W1N + 32768;           // 81920
+constexpr int CH_A1 = 0;                         // phase-1 operands overlay the staging / A2 areas (dead before those are written)
+constexpr int CH_W3 = 8192;
+constexpr int CH_AD = 40960;                     // DUAL: downsample operands (the W1' area is loaded after phase 1 instead of up front)
+constexpr int CH_WD = 49152;
+
+// DUAL: block 0 of layer1 -- out = relu(bn3(conv3(t2)) + bf16(bn_d(downsample(x)))) like conv1x1_dual_bf16_kernel (two accumulator
+// sets, the downsample branch rounded to bf16 where the two-launch form stores it), then the chained conv1'.
+template <bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lrow = tid >> 3;
+    const int lslot = tid & 7;
+    const int lcol = lslot ^ ((lrow >> 1) & 7);
+
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = bid * CH_BM;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.a1 + (size_t)m0 * 64), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w3), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1n = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w1n), 0, 0x7fffffff, 0x00020000);
+    auto load_w1n = [&]() __attribute__((always_inline)) {      // W1': chunk c = input channels 64c .. 64c+63 of its 64 rows
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                dma16(rsrc_w1n, smem + CH_W1N + c * 8192 + (q * 4 + wave) * 1024, (unsigned)((lrow + 32 * q) * 256 + lcol * 8) * 2u, (unsigned)c * ROWB);
+    };
+
+    // ---- every load of the tile is issued up front: t2 rows + W3 (phase 1), then W1' (phase 2) and the residual rows (plain) or
+    //      the downsample operands (DUAL; W1' follows after phase 1, into the area they free) ----
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                      // t2: 64 rows x 128 B
+        const int row = lrow + 32 * q;
+        const unsigned off = (m0 + row < p.M) ? (unsigned)(row * 64 + lcol * 8) * 2u : OOB;
+        dma16(rsrc_a1, smem + CH_A1 + (q * 4 + wave) * 1024, off, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)                        // W3: 256 rows x 128 B
+        dma16(rsrc_w3, smem + CH_W3 + (q * 4 + wave) * 1024, (unsigned)((lrow + 32 * q) * 64 + lcol * 8) * 2u, 0);
+    const int ccol = (tid & 31) * 8;                   // epilogue 1: 32 threads per row (8 channels each), 8 rows per step
+    const int crow = tid >> 5;
+    u32x4 rres[DUAL ? 1 : 8];
+    if (DUAL) {
+        const __amdgpu_buffer_rsrc_t rsrc_ad = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.ad + (size_t)m0 * 64), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.wd), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = lrow + 32 * q;
+            const unsigned off = (m0 + row < p.M) ? (unsigned)(row * 64 + lcol * 8) * 2u : OOB;
+            dma16(rsrc_ad, smem + CH_AD + (q * 4 + wave) * 1024, off, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            dma16(rsrc_wd, smem + CH_WD + (q * 4 + wave) * 1024, (unsigned)((lrow + 32 * q) * 64 + lcol * 8) * 2u, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_w1n();
+        asm volatile("" ::: "memory");                 // (pins the issue order the counted wait below relies on: DMA pieces, then residual loads)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = m0 + it * 8 + crow;
+            const int mc = m < p.M ? m : p.M - 1;
+            rres[it] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * CH_N1 + ccol);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // the 18 LDS-DMA pieces (issued first) have landed; the 8 residual loads may be in flight
+    }
+    __syncthreads();
+
+    const int fr = lane & 31;
+    const int half = lane >> 5;
+    const int fswz = (fr >> 1) & 7;
+
+    // ---- phase 1: 64 x 256 x 64 (DUAL: twice, two accumulator sets); wave (wm, wn) owns rows 32 wm .. +32, columns 128 wn .. +128 ----
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[4], accd[4];                            // (accd is dead code in the plain form)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+            accd[j][r] = 0.f;
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int koff = ((2 * ks + half) ^ fswz) * 16;
+        const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + CH_A1 + (wm * 32 + fr) * ROWB + koff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + CH_W3 + (wn * 128 + j * 32 + fr) * ROWB + koff);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[j], 0, 0, 0);
+        }
+    }
+    if (DUAL) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int koff = ((2 * ks + half) ^ fswz) * 16;
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + CH_AD + (wm * 32 + fr) * ROWB + koff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + CH_WD + (wn * 128 + j * 32 + fr) * ROWB + koff);
+                accd[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), accd[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // every wave has read the phase-1 operands: their LDS is free
+    if (DUAL) load_w1n();                              // lands during epilogue 1
+
+    // ---- epilogue 1: four passes of 16 rows through the f32 staging tile; rows -> HBM (out) and -> LDS (phase-2 A operand) ----
+    float* cs = reinterpret_cast<float*>(smem + CH_CS);
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale3 + ccol), sc1 = *reinterpret_cast<const f32x4*>(p.scale3 + ccol + 4);
+    const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift3 + ccol), sf1 = *reinterpret_cast<const f32x4*>(p.shift3 + ccol + 4);
+    f32x4 sd0 = sc0, sd1 = sc1, td0 = sf0, td1 = sf1;
+    if (DUAL) {
+        sd0 = *reinterpret_cast<const f32x4*>(p.scale_d + ccol); sd1 = *reinterpret_cast<const f32x4*>(p.scale_d + ccol + 4);
+        td0 = *reinterpret_cast<const f32x4*>(p.shift_d + ccol); td1 = *reinterpret_cast<const f32x4*>(p.shift_d + ccol + 4);
+    }
+    auto to_stage = [&](const f32x16 (&a4)[4], int ps) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 8 * (ps & 1) + rr;                         // accumulator registers of rows 16 (ps & 1) .. +16 of the wave's 32
+                const int lr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;  // row inside the pass, 0..15
+                const int col = (wn * 128 + j * 32 + fr) ^ (((lr >> 2) & 1) << 5);   // rows 4 apart: other half of the bank space
+                cs[lr * CH_N1 + col] = a4[j][r];
+            }
+    };
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        f32x4 d0[2], d1[2];
+        if constexpr (DUAL) {                          // downsample branch first: bn_d, then the bf16 rounding of its stored form
+            if (wm == (ps >> 1)) to_stage(accd, ps);
+            __syncthreads();
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int lr = crow + 8 * st;
+                const float* src = cs + lr * CH_N1 + (ccol ^ (((lr >> 2) & 1) << 5));
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sd0 + td0;
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * sd1 + td1;
+                const unsigned q0 = pack_bf16(v0[0], v0[1]), q1 = pack_bf16(v0[2], v0[3]), q2 = pack_bf16(v1[0], v1[1]), q3 = pack_bf16(v1[2], v1[3]);
+                d0[st] = f32x4{bf16_lo(q0), bf16_hi(q0), bf16_lo(q1), bf16_hi(q1)};
+                d1[st] = f32x4{bf16_lo(q2), bf16_hi(q2), bf16_lo(q3), bf16_hi(q3)};
+            }
+            __syncthreads();
+        }
+        if (wm == (ps >> 1)) to_stage(acc, ps);
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int lr = crow + 8 * st;
+            const int R = ps * 16 + lr;                                       // row inside the 64-row tile
+            const float* src = cs + lr * CH_N1 + (ccol ^ (((lr >> 2) & 1) << 5));
+            f32x4 v0, v1;
+            if (DUAL) {
+                v0 = *reinterpret_cast<const f32x4*>(src) * sc0 + sf0 + d0[st];
+                v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc1 + sf1 + d1[st];
+            } else {
+                v0 = *reinterpret_cast<const f32x4*>(src);
+                v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                v0 = v0 * sc0 + sf0;
+                v1 = v1 * sc1 + sf1;
+                const u32x4 rr = rres[ps * 2 + st];
+                v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
+                v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+            u32x4 o;
+            o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+            o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+            if (m0 + R < p.M) *reinterpret_cast<u32x4*>(p.y + (size_t)(m0 + R) * CH_N1 + ccol) = o;
+            // phase-2 A operand: K chunk ccol / 64, 16-byte slot (ccol % 64) / 8, swizzled like the tile loader's rows
+            *reinterpret_cast<u32x4*>(smem + CH_A2 + (ccol >> 6) * 8192 + R * ROWB + ((((ccol & 63) >> 3) ^ ((R >> 1) & 7)) << 4)) = o;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: 64 x 64 x 256 from LDS; wave (wm, wn) owns rows 32 wm .. +32, columns 32 wn .. +32 ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1' has landed
+    __syncthreads();
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int koff = ((2 * ks + half) ^ fswz) * 16;
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + CH_A2 + c * 8192 + (wm * 32 + fr) * ROWB + koff);
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + CH_W1N + c * 8192 + (wn * 32 + fr) * ROWB + koff);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc2, 0, 0, 0);
+        }
+    // ---- epilogue 2: 64 x 64 through the staging tile (free since the last pass's barrier) ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        cs[row * CH_N2 + ((wn * 32 + fr) ^ (((row >> 2) & 1) << 5))] = acc2[r];
+    }
+    __syncthreads();
+    {
+        const int c2 = (tid & 7) * 8;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale1n + c2), s1 = *reinterpret_cast<const f32x4*>(p.scale1n + c2 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.shift1n + c2), t1 = *reinterpret_cast<const f32x4*>(p.shift1n + c2 + 4);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int row = (tid >> 3) + 32 * st;
+            const float* src = cs + row * CH_N2 + (c2 ^ (((row >> 2) & 1) << 5));
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s0 + t0;
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * s1 + t1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+            u32x4 o;
+            o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+            o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+            if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.y2 + (size_t)(m0 + row) * CH_N2 + c2) = o;
+        }
+    }
+}
+
 // ---- 8-wave large-tile variant (inference forward; no stem / data-gradient / statistics modes) ---------------------
 // 512 threads = 2 waves per SIMD from ONE workgroup, tiles 256x256 (wave tile 128x64), 256x128 and 128x256 (64x64):
 // the 128x128 / 4-wave kernel above moves 0.5 KiB from L2 into LDS per MFMA -- 64 B/clk/CU at the full matrix rate, more
@@ -1340,6 +1601,36 @@ int hn_launch_conv1x1_dual_bf16(const void* t2, const void* w1, const float* sca
         attr_done[dev] = true;
     }
     hipLaunchKernelGGL(conv1x1_dual_bf16_kernel, dim3((unsigned)(hn_cdiv(a.M, 128) * (Cout / 128))), dim3(256), lds, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = relu(bn3(conv3(t2)) + x) and t1n = relu(bn1'(conv1'(out))) in one launch (layer1: 64 -> 256 -> 64 channels).
+// xd != NULL: block 0 -- the residual is the downsample branch bf16(bn_d(wd . xd)) computed in the same launch (xd [M][64], stride 1).
+int hn_launch_conv1x1_chain_bf16(const void* t2, const void* w3, const float* scale3, const float* shift3, const void* x, void* out,
+                                 const void* w1n, const float* scale1n, const float* shift1n, void* t1n, long M, int K1, int N1, int N2,
+                                 hipStream_t s, const void* xd, const void* wd, const float* scale_d, const float* shift_d)
+{
+    static const char* env = getenv("HN_XCD_SWIZZLE");
+    HN_REQUIRE(K1 == 64 && N1 == CH_N1 && N2 == CH_N2, "chained 1x1 convs: built for 64 -> 256 -> 64 channels (got %d -> %d -> %d)", K1, N1, N2);
+    HN_REQUIRE(M > 0 && M < 0x7fffffffL / 256, "chained 1x1 convs: bad M");
+    ChainArgsH a;
+    a.a1 = reinterpret_cast<const u16*>(t2); a.w3 = reinterpret_cast<const u16*>(w3); a.scale3 = scale3; a.shift3 = shift3;
+    a.res = reinterpret_cast<const u16*>(x); a.y = reinterpret_cast<u16*>(out);
+    a.ad = reinterpret_cast<const u16*>(xd); a.wd = reinterpret_cast<const u16*>(wd); a.scale_d = scale_d; a.shift_d = shift_d;
+    a.w1n = reinterpret_cast<const u16*>(w1n); a.scale1n = scale1n; a.shift1n = shift1n; a.y2 = reinterpret_cast<u16*>(t1n);
+    a.M = (int)M;
+    a.xcd_swizzle = env ? atoi(env) : 1;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_chain_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_chain_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        attr_done[dev] = true;
+    }
+    if (xd) hipLaunchKernelGGL(conv1x1_chain_bf16_kernel<true>, dim3((unsigned)hn_cdiv(M, CH_BM)), dim3(256), CH_LDS, s, a);
+    else hipLaunchKernelGGL(conv1x1_chain_bf16_kernel<false>, dim3((unsigned)hn_cdiv(M, CH_BM)), dim3(256), CH_LDS, s, a);
     HN_LAUNCH_CHECK();
     return 0;
 }

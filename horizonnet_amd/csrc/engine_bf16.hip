@@ -221,8 +221,26 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
             const int stride = (j == 0 && li > 0) ? 2 : 1;
             const int i1 = a.block_first[li][j];
             char* out = (j == nblk[li] - 1) ? W + pl.c[li] : ((cur == W + pl.p0) ? W + pl.p1 : W + pl.p0);
-            if ((rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
+            // layer1, block j -> j+1: conv3 (+ residual + ReLU) and the NEXT block's conv1 as ONE launch (conv1x1_chain_bf16_kernel):
+            // the 537 MB block output is not read back from HBM by the next conv1.  Bit-identical to the two-launch form.
+            // Block 0 -> 1 likewise, with the downsample branch as a second accumulator set of the same launch (DUAL form).
+            const bool chain_out = li == 0 && (j == 0 || j == 1) && e->chain_layer1 && !e->profiling && (j == 1 || e->fuse_downsample);
+            const bool chained_in = li == 0 && (j == 1 || j == 2) && e->chain_layer1 && !e->profiling && (j == 2 || e->fuse_downsample);
+            if (!chained_in && (rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
+            if (chain_out) {
+                const ConvLayer& c3 = a.convs[i1 + 2];
+                const int in1 = a.block_first[li][j + 1];
+                const ConvLayer& c1n = a.convs[in1];
+                const int id = a.block_down[li];
+                const ConvLayer& cd = a.convs[id];
+                if ((rc = hn_launch_conv1x1_chain_bf16(W + pl.t2, H + h.conv[i1 + 2], P + c3.scale_off, P + c3.shift_off, cur, out, H + h.conv[in1],
+                                                       P + c1n.scale_off, P + c1n.shift_off, W + pl.t1, (long)B * Hh * Wd, c3.cin, c3.cout, c1n.cout, s,
+                                                       j == 0 ? cur : nullptr, j == 0 ? H + h.conv[id] : nullptr, P + cd.scale_off, P + cd.shift_off)))
+                    return rc;
+                cur = out;
+                continue;
+            }
             const char* idt = cur;
             // block 0 of the HBM-bound stages (layer1, layer2): downsample + conv3 + add + ReLU in ONE launch -- the
             // downsample output never goes to HBM (conv1x1_dual_bf16_kernel; bit-identical to the two-launch form)

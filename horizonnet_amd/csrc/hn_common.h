@@ -152,6 +152,10 @@ int hn_launch_conv1x1_dual_f32(const float* t2, const float* w1, const float* sc
 int hn_launch_conv1x1_dual_bf16(const void* t2, const void* w1, const float* scale1, const float* shift1, const void* x, const void* w2,
                                 const float* scale2, const float* shift2, void* y, int B, int Ho, int Wo, int K1, int Hi2, int Wi2,
                                 int K2, int s2, int Cout, hipStream_t s);
+int hn_launch_conv1x1_chain_bf16(const void* t2, const void* w3, const float* scale3, const float* shift3, const void* x, void* out,
+                                 const void* w1n, const float* scale1n, const float* shift1n, void* t1n, long M, int K1, int N1, int N2,
+                                 hipStream_t s, const void* xd = nullptr, const void* wd = nullptr, const float* scale_d = nullptr,
+                                 const float* shift_d = nullptr);
 size_t hn_lstm_bf16_xch_bytes(void);
 int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B, void* xch,
                               void* sync_ws, hipStream_t s, float* save = nullptr);

@@ -99,6 +99,8 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * (model.py:138-156), which depend only on C1..C4, on an engine-owned second HIP stream beside the following ResNet
  * stages (fork / join with events: the caller's stream still orders the whole call); 0 = everything on the caller's
  * stream.  Results are identical either way.
+ * "chain_layer1" (default 1): hn_forward_bf16 runs layer1.1's conv3 (+ residual + ReLU) and layer1.2's conv1 as one launch
+ * (the block output is not read back from HBM; bit-identical).
  * "lstm_wide_rows" (16 | 8, default 16) / "lstm_wide_xcds" (1 | 2, default 2): geometry of the wide recurrence kernel of
  * hn_forward_bf16_submit (speed only).
  * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores

@@ -413,3 +413,23 @@ def test_bf16_forward_trained_checkpoint_vs_emulation_and_reference(golden_dir):
         got = taps[k].float()[:, ::stp[0], ::stp[1], ::stp[2]].cpu().numpy()
         ok &= report("bf16 trained tap %s vs reference f32" % k, got, g["tap_" + k], 5e-2 * float(np.abs(g["tap_" + k]).max()))
     assert ok
+
+
+def test_chained_conv3_conv1_bit_identical():
+    """layer1.1.conv3 (+ residual + ReLU) chained into layer1.2.conv1 (conv1x1_chain_bf16_kernel: the 64-pixel output tile stays
+    in LDS as the A operand of the next conv) against the two-launch form: same k order, same rounding points -> every tap
+    and both outputs bit-identical, at a ragged batch (B = 3: M = 98304 rows) and at B = 1."""
+    net = _net(4, "random")
+    net.precision = "bf16"
+    gen = torch.Generator().manual_seed(55)
+    for B in (3, 1):
+        x = torch.rand(B, 3, 512, 1024, generator=gen).to(DEV)
+        with torch.no_grad():
+            net.set_engine_option("chain_layer1", 0)
+            b0, c0, t0 = net.forward_with_taps(x, names=("c1", "c2", "feature"))
+            net.set_engine_option("chain_layer1", 1)
+            b1, c1, t1 = net.forward_with_taps(x, names=("c1", "c2", "feature"))
+        torch.cuda.synchronize()
+        for k in ("c1", "c2", "feature"):
+            assert torch.equal(t0[k], t1[k]), "tap %s differs: %g" % (k, float((t0[k].float() - t1[k].float()).abs().max()))
+        assert torch.equal(b0, b1) and torch.equal(c0, c1)
