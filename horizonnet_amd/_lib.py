@@ -74,6 +74,7 @@ SIGNATURES = {
                                _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _i, _i, _i, _vp]),
     "hn_find_peaks": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "hn_vote_scan": (_i, [_vp, _i, _c.c_double, _vp]),
+    "hn_interquartile_mean_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "hn_layout_fit_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hn_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "hn_packed_conv_weight_floats": (_sz, [_i, _i, _i, _i]),

@@ -339,7 +339,46 @@ int fit_one(Ctx& c, const unsigned char* mask, double tol, int force_cuboid, dou
     return 0;
 }
 
+// numpy's pairwise summation in float32 (FLOAT_pairwise_sum): what np.mean of a contiguous float32 vector sums with
+float pw_sum_f32(const float* a, long n)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_sum_f32(a, n2) + pw_sum_f32(a + n2, n - n2);
+}
+
 }  // namespace
+
+// mean_percentile (post_proc.py:69-72) for B rows: out[b] = mean of the z[b][k] with lo[b] <= z <= hi[b], float32 like
+// numpy's vec[(lo <= vec) & (vec <= hi)].mean() on a float32 vector (compaction in order, pairwise sum, one division)
+extern "C" int hn_interquartile_mean_f32(const float* z, const float* lo, const float* hi, int B, int W, float* out)
+{
+    HN_REQUIRE(z && lo && hi && out && B >= 0 && W >= 1, "hn_interquartile_mean_f32: bad argument");
+    std::vector<float> buf(W);
+    for (int b = 0; b < B; ++b) {
+        const float* row = z + (size_t)b * W;
+        long n = 0;
+        for (int k = 0; k < W; ++k)
+            if (lo[b] <= row[k] && row[k] <= hi[b]) buf[n++] = row[k];
+        out[b] = n ? pw_sum_f32(buf.data(), n) / (float)n : (0.f / 0.f);       // numpy: mean of an empty slice = nan
+    }
+    return 0;
+}
 
 extern "C" int hn_layout_fit_batch(const double* xs, const double* ys, const unsigned char* peak_mask, const double* sin_u,
                                    const double* cos_u, const double* tol, int B, int W, int force_cuboid, int threads, double* pts,

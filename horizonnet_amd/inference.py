@@ -115,6 +115,28 @@ def _trig_tables(W):
     return _TABLES[W]
 
 
+_QUARTILE_CHECKED = {"ok": None}
+
+
+def _quartiles_f32(zz):
+    """np.percentile(zz, 25, axis=1), np.percentile(zz, 75, axis=1) for float32 rows of length 1024 from ONE partition:
+    numpy's 'linear' method puts the quartiles at virtual indices 255.75 / 767.25 and interpolates a + (b - a) t for t < 0.5,
+    b - (b - a)(1 - t) otherwise, in the array's own type.  The closed form is checked against np.percentile on the first
+    batch it sees; if numpy ever changes its formula the function falls back to np.percentile for good."""
+    if zz.shape[1] != 1024 or zz.dtype != np.float32 or _QUARTILE_CHECKED["ok"] is False:
+        return np.percentile(zz, 25, axis=1), np.percentile(zz, 75, axis=1)      # (two calls: a [25, 75] list interpolates in float64)
+    p = np.partition(zz, [255, 256, 767, 768], axis=1)
+    a, b = p[:, 255], p[:, 256]
+    lo = b - (b - a) * np.float32(0.25)
+    a, b = p[:, 767], p[:, 768]
+    hi = a + (b - a) * np.float32(0.25)
+    if _QUARTILE_CHECKED["ok"] is None:
+        _QUARTILE_CHECKED["ok"] = bool(np.array_equal(lo, np.percentile(zz, 25, axis=1)) and np.array_equal(hi, np.percentile(zz, 75, axis=1)))
+        if not _QUARTILE_CHECKED["ok"]:
+            return np.percentile(zz, 25, axis=1), np.percentile(zz, 75, axis=1)
+    return lo, hi
+
+
 def layouts_from_signals_batch(y_bon, y_cor, mask_main, mask_zero=None, H=512, W=1024, force_cuboid=False, threads=1):
     """The host half of inference.py:89-141 for a BATCH: y_bon [B,2,W] float32 latitudes (radians), y_cor [B,W] float32 corner
     probability, mask_main / mask_zero [B,W] uint8 corner peaks at the caller's threshold / at 0 (the cuboid fallback's)
@@ -139,11 +161,12 @@ def layouts_from_signals_batch(y_bon, y_cor, mask_main, mask_zero=None, H=512, W
     v0 = postproc.row_to_v(yb[:, 0], H)
     v1 = postproc.row_to_v(yb[:, 1], H)
     zz = (z0 / np.tan(v0)) * np.tan(v1)
-    lo = np.percentile(zz, 25, axis=1)              # (two calls: np.percentile(zz, [25, 75]) interpolates in float64 and differs)
-    hi = np.percentile(zz, 75, axis=1)
+    lo, hi = _quartiles_f32(zz)
     z1 = np.empty(B, np.float32)
-    for b in range(B):
-        z1[b] = zz[b][(lo[b] <= zz[b]) & (zz[b] <= hi[b])].mean()
+    zz = np.ascontiguousarray(zz, np.float32)
+    vpf = lambda a: ctypes.c_void_p(a.ctypes.data)                           # noqa: E731
+    _lib.check(lib.hn_interquartile_mean_f32(vpf(zz), vpf(np.ascontiguousarray(lo)), vpf(np.ascontiguousarray(hi)), B, W, vpf(z1)),
+               "hn_interquartile_mean_f32")
     tol = np.abs(0.16 * z1 / 1.6)                                           # inference.py:111, float32 arithmetic
     # np_coor2xy of (column, ceiling row) (post_proc.py:29-43) in float64, all panoramas at once
     sin_u, cos_u = _trig_tables(W)
@@ -194,22 +217,21 @@ def layouts_from_signals_batch(y_bon, y_cor, mask_main, mask_zero=None, H=512, W
     zh = np.repeat((z0 + (z1 - z0)).astype(np.float64), npts)              # z0 + h with h = z1 - z0 in float32 (inference.py:128)
     vv = postproc.row_to_v(cor[:, 1], H)
     floor_rows = (-np.arctan2(zh, z0 / np.tan(vv)) / PI + 0.5) * H - 0.5
-    out = []
+    # gen_ww's np.roll(cor, -2 * argmin, axis=0) (post_proc.py:357) as one gather over all panoramas, then cor_id (inference.py:128-137)
+    perm = np.empty(int(off[-1]), np.int64)
     for b in range(B):
-        cb = cor[off[b]:off[b + 1]]
-        fb = floor_rows[off[b]:off[b + 1]]
-        k = (2 * int(cb[::2, 0].argmin())) % len(cb)                        # gen_ww's np.roll(cor, -2 * argmin, axis=0) (post_proc.py:357)
-        if k:
-            cb, fb = np.concatenate((cb[k:], cb[:k])), np.concatenate((fb[k:], fb[:k]))
-        cor_id = np.zeros((len(cb) * 2, 2), np.float32)
-        cor_id[0::2, 0] = cb[:, 0]
-        cor_id[0::2, 1] = cb[:, 1]
-        cor_id[1::2, 0] = cb[:, 0]
-        cor_id[1::2, 1] = fb
-        cor_id[:, 0] /= W
-        cor_id[:, 1] /= H
-        out.append((cor_id, z0, z1[b]))
-    return out
+        n, o = int(npts[b]), int(off[b])
+        k = (2 * int(cor[o:o + n:2, 0].argmin())) % n
+        perm[o:o + n] = o + (np.arange(n) + k) % n
+    cor, floor_rows = cor[perm], floor_rows[perm]
+    ids = np.zeros((2 * len(cor), 2), np.float32)
+    ids[0::2, 0] = cor[:, 0]
+    ids[0::2, 1] = cor[:, 1]
+    ids[1::2, 0] = cor[:, 0]
+    ids[1::2, 1] = floor_rows
+    ids[:, 0] /= W
+    ids[:, 1] /= H
+    return [(ids[2 * off[b]:2 * off[b + 1]].copy(), z0, z1[b]) for b in range(B)]
 
 
 def _forward_signals(net, x, device, flip, rotate):

@@ -311,6 +311,10 @@ int hn_find_peaks(const float* signal, int B, int n, int r, float min_v, int app
 int hn_layout_fit_batch(const double* xs, const double* ys, const unsigned char* peak_mask, const double* sin_u, const double* cos_u,
                         const double* tol, int B, int W, int force_cuboid, int threads, double* pts, int32_t* npts, int32_t* flags);
 
+/* Host function: mean_percentile (post_proc.py:69-72) for B float32 rows -- out[b] = numpy's vec[(lo <= vec) & (vec <= hi)].mean()
+ * (compaction in order, numpy's float32 pairwise summation, one float32 division). */
+int hn_interquartile_mean_f32(const float* z, const float* lo, const float* hi, int B, int W, float* out);
+
 /* HOST function (no device work, no stream): the decision loop of the reference's `vote` on an ascending float64 sample
  * vector -- the longest run v[i..j] with (v[j] - v[i]) + 1e-9 <= tol that covers at least 40 % of the samples, first maximum in
  * (i, j) row-major order as post_proc.py:78-90's N x N span matrix finds it.  best3 = {span, i, j} (span = -1: none).  The
