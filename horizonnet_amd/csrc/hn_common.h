@@ -160,7 +160,7 @@ size_t hn_lstm_bf16_xch_bytes(void);
 int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B, void* xch,
                               void* sync_ws, hipStream_t s, float* save = nullptr);
 int hn_launch_lstm_layer_bf16_wide(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B,
-                                   void* sync_ws, int rows_per_group, int xcds_per_group, hipStream_t s);
+                                   void* sync_ws, int rows_per_group, int xcds_per_group, hipStream_t s, float* save = nullptr);
 size_t hn_lstm_bwd_bf16_xch_bytes(void);
 int hn_launch_lstm_layer_bwd_bf16(const float* saved, const float* dy, const void* whhT_f, const void* whhT_r, float* dgx, int T, int B,
                                   void* xch, void* sync_ws, hipStream_t s);

@@ -214,7 +214,7 @@ template <int BW>
 __global__ __launch_bounds__(256) void lstm_layer_bf16_wide_kernel(const float* __restrict__ gx, const u16* __restrict__ whh_f,
                                                                    const u16* __restrict__ whh_r, float* __restrict__ y, u16* y_h,
                                                                    int T, int B, int b0, int bc, int ngroups, int xcds_per_group,
-                                                                   unsigned* sync)
+                                                                   unsigned* sync, float* __restrict__ save)
 {
     static_assert(BW == 8 || BW == 16, "rows per group");
     constexpr int RPW = BW / 4;                                       // rows swept per wave
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_wide_kernel(const float* 
         }
 
         if (gate_lane) {
-            float hval[4];
+            float hval[4], gsv[4][4];
             unsigned hb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_wide_kernel(const float* 
                 c_state[r] = fg * c_state[r] + ig * gg;
                 hval[r] = og * tanh_fast(c_state[r]);
                 hb[r] = bf16_rn(hval[r]);
+                gsv[r][0] = ig; gsv[r][1] = fg; gsv[r][2] = gg; gsv[r][3] = og;
             }
             // publish FIRST: 4 rows x 1 unit per lane -> 1 row x 4 units per lane (a 4 x 4 transpose inside the quad of unit lanes)
             const unsigned lo = hb[0] | (hb[1] << 16), hi = hb[2] | (hb[3] << 16);
@@ -356,7 +357,13 @@ __global__ __launch_bounds__(256) void lstm_layer_bf16_wide_kernel(const float* 
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (row0 + r < nvalid) y[((size_t)t * B + b0 + bfirst + row0 + r) * 1024 + dir * LH + u0 + col] = hval[r];
+                if (row0 + r < nvalid) {
+                    y[((size_t)t * B + b0 + bfirst + row0 + r) * 1024 + dir * LH + u0 + col] = hval[r];
+                    if (save) {      // training: post-activation gates + cell state for the adjoint, [t][b][dir][5][512]
+                        float* sv = save + (((size_t)t * B + b0 + bfirst + row0 + r) * 2 + dir) * 5 * LH + u0 + col;
+                        sv[0] = gsv[r][0]; sv[LH] = gsv[r][1]; sv[2 * LH] = gsv[r][2]; sv[3 * LH] = gsv[r][3]; sv[4 * LH] = c_state[r];
+                    }
+                }
         }
     }
 }
@@ -548,7 +555,7 @@ int hn_launch_lstm_layer_bf16(const float* gx, const void* whh_f, const void* wh
 // The wide form (see lstm_layer_bf16_wide_kernel): rows_per_group 16 (default) or 8, xcds_per_group 1 or 2; <= 0 picks the default.
 // y_h (bf16 [T*B][1024]) is REQUIRED: it is the kernel's exchange buffer as well as its bf16 output.
 int hn_launch_lstm_layer_bf16_wide(const float* gx, const void* whh_f, const void* whh_r, float* y, void* y_h, int T, int B,
-                                   void* sync_ws, int rows_per_group, int xcds_per_group, hipStream_t s)
+                                   void* sync_ws, int rows_per_group, int xcds_per_group, hipStream_t s, float* save)
 {
     HN_REQUIRE(T >= 1 && B >= 1 && T < 0x7fffffff && y_h != nullptr, "lstm bf16 wide: bad T/B or no y_h");
     const int bw = rows_per_group == 8 ? 8 : 16;
@@ -563,12 +570,12 @@ int hn_launch_lstm_layer_bf16_wide(const float* gx, const void* whh_f, const voi
             if (int rc = hn_require_coresident(lstm_layer_bf16_wide_kernel<16>, grid, 256, "bf16 LSTM recurrence (wide)")) return rc;
             hipLaunchKernelGGL(lstm_layer_bf16_wide_kernel<16>, dim3(grid), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
                                reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), T, B, b0, bc, ngroups, xs,
-                               reinterpret_cast<unsigned*>(sync_ws));
+                               reinterpret_cast<unsigned*>(sync_ws), save);
         } else {
             if (int rc = hn_require_coresident(lstm_layer_bf16_wide_kernel<8>, grid, 256, "bf16 LSTM recurrence (wide)")) return rc;
             hipLaunchKernelGGL(lstm_layer_bf16_wide_kernel<8>, dim3(grid), dim3(256), 0, s, gx, reinterpret_cast<const u16*>(whh_f),
                                reinterpret_cast<const u16*>(whh_r), y, reinterpret_cast<u16*>(y_h), T, B, b0, bc, ngroups, xs,
-                               reinterpret_cast<unsigned*>(sync_ws));
+                               reinterpret_cast<unsigned*>(sync_ws), save);
         }
         HN_LAUNCH_CHECK();
     }

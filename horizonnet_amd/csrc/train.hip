@@ -8,6 +8,8 @@
 // re-reads instead of recomputing.
 #include "engine_internal.h"
 
+#include <stdlib.h>
+
 #include <string.h>
 
 namespace {
@@ -493,8 +495,16 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
             HN_REQUIRE((size_t)rows * 1024 <= ((size_t)1024 * 18432) * 2, "hn_train_forward: batch too large for the bf16 LSTM input staging");
             if ((rc = hn_launch_f32_to_bf16(lin, lin_h, rows * 1024, s))) return rc;
             if ((rc = gemm_rows_bf16(lin_h, H + hn_bf16_wih_offset(l), c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
-            if ((rc = hn_launch_lstm_layer_bf16(W + pl.gx, H + hn_bf16_whh_offset(l, 0), H + hn_bf16_whh_offset(l, 1), ybuf[l], nullptr,
-                                                T_COLS, B, W + pl.lxch, W + pl.sync, s, W + pl.save[l])))
+            // the wide recurrence kernel (a group = one direction of 16 panoramas: one launch for up to 64 panoramas on 64 compute
+            // units instead of one 256-workgroup launch per 32); its exchange buffer is the bf16 staging of the layer input, free
+            // again once the input GEMM above has read it.  HN_TRAIN_WIDE_LSTM=0: the narrow kernel (A/B).
+            static const char* wenv = getenv("HN_TRAIN_WIDE_LSTM");
+            if (!(wenv && wenv[0] == '0')) {
+                if ((rc = hn_launch_lstm_layer_bf16_wide(W + pl.gx, H + hn_bf16_whh_offset(l, 0), H + hn_bf16_whh_offset(l, 1), ybuf[l], lin_h,
+                                                         T_COLS, B, W + pl.sync, 16, 2, s, W + pl.save[l])))
+                    return rc;
+            } else if ((rc = hn_launch_lstm_layer_bf16(W + pl.gx, H + hn_bf16_whh_offset(l, 0), H + hn_bf16_whh_offset(l, 1), ybuf[l], nullptr,
+                                                       T_COLS, B, W + pl.lxch, W + pl.sync, s, W + pl.save[l])))
                 return rc;
         } else {
             if ((rc = gemm_rows(lin, 0, c.P + a.wih_off[l], c.P + a.ones_off, c.P + a.lbias_off[l], W + pl.gx, rows, 1024, 4096, s))) return rc;
