@@ -632,9 +632,10 @@ struct ChainArgsH {
     const u16* w1n;      // next conv1 [64][256]
     const float* scale1n;
     const float* shift1n;
-    u16* y2;             // t1' [M][64]
+    u16* y2;             // t1' [M][64 * n2_passes]
     int M;
     int xcd_swizzle;
+    int n2_passes;       // 1: conv1' has 64 output channels (layer1 blocks); 2: 128 (layer2.0.conv1), two passes over the same A operand
 };
 
 constexpr int CH_BM = 64, CH_N1 = 256, CH_N2 = 64;
@@ -672,12 +673,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p
     const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.a1 + (size_t)m0 * 64), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w3), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w1n = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w1n), 0, 0x7fffffff, 0x00020000);
-    auto load_w1n = [&]() __attribute__((always_inline)) {      // W1': chunk c = input channels 64c .. 64c+63 of its 64 rows
+    auto load_w1n = [&](int pass) __attribute__((always_inline)) {   // W1' rows 64 pass .. +64: chunk c = their input channels 64c .. 64c+63
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                dma16(rsrc_w1n, smem + CH_W1N + c * 8192 + (q * 4 + wave) * 1024, (unsigned)((lrow + 32 * q) * 256 + lcol * 8) * 2u, (unsigned)c * ROWB);
+                dma16(rsrc_w1n, smem + CH_W1N + c * 8192 + (q * 4 + wave) * 1024, (unsigned)((64 * pass + lrow + 32 * q) * 256 + lcol * 8) * 2u,
+                      (unsigned)c * ROWB);
     };
 
     // ---- every load of the tile is issued up front: t2 rows + W3 (phase 1), then W1' (phase 2) and the residual rows (plain) or
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p
             dma16(rsrc_wd, smem + CH_WD + (q * 4 + wave) * 1024, (unsigned)((lrow + 32 * q) * 64 + lcol * 8) * 2u, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        load_w1n();
+        load_w1n(0);
         asm volatile("" ::: "memory");                 // (pins the issue order the counted wait below relies on: DMA pieces, then residual loads)
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p
         }
     }
     __syncthreads();                                   // every wave has read the phase-1 operands: their LDS is free
-    if (DUAL) load_w1n();                              // lands during epilogue 1
+    if (DUAL) load_w1n(0);                             // lands during epilogue 1
 
     // ---- epilogue 1: four passes of 16 rows through the f32 staging tile; rows -> HBM (out) and -> LDS (phase-2 A operand) ----
     float* cs = reinterpret_cast<float*>(smem + CH_CS);
@@ -829,44 +831,50 @@ __global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p
         __syncthreads();
     }
 
-    // ---- phase 2: 64 x 64 x 256 from LDS; wave (wm, wn) owns rows 32 wm .. +32, columns 32 wn .. +32 ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1' has landed
-    __syncthreads();
-    f32x16 acc2;
+    // ---- phase 2: 64 x 64 x 256 from LDS per pass; wave (wm, wn) owns rows 32 wm .. +32, columns 32 wn .. +32 of the pass ----
+    const int ldy2 = CH_N2 * p.n2_passes;
+    for (int pass = 0; pass < p.n2_passes; ++pass) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this pass's W1' rows have landed
+        __syncthreads();
+        f32x16 acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int koff = ((2 * ks + half) ^ fswz) * 16;
-            const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + CH_A2 + c * 8192 + (wm * 32 + fr) * ROWB + koff);
-            const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + CH_W1N + c * 8192 + (wn * 32 + fr) * ROWB + koff);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc2, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int koff = ((2 * ks + half) ^ fswz) * 16;
+                const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + CH_A2 + c * 8192 + (wm * 32 + fr) * ROWB + koff);
+                const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + CH_W1N + c * 8192 + (wn * 32 + fr) * ROWB + koff);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc2, 0, 0, 0);
+            }
+        __syncthreads();                               // every wave has read this pass's W1' (and the staging tile of the previous pass)
+        if (pass + 1 < p.n2_passes) load_w1n(pass + 1);   // lands during this pass's epilogue
+        // ---- epilogue 2: 64 x 64 through the staging tile ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            cs[row * CH_N2 + ((wn * 32 + fr) ^ (((row >> 2) & 1) << 5))] = acc2[r];
         }
-    // ---- epilogue 2: 64 x 64 through the staging tile (free since the last pass's barrier) ----
+        __syncthreads();
+        {
+            const int c2 = (tid & 7) * 8;
+            const int cg = CH_N2 * pass + c2;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale1n + cg), s1 = *reinterpret_cast<const f32x4*>(p.scale1n + cg + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.shift1n + cg), t1 = *reinterpret_cast<const f32x4*>(p.shift1n + cg + 4);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        cs[row * CH_N2 + ((wn * 32 + fr) ^ (((row >> 2) & 1) << 5))] = acc2[r];
-    }
-    __syncthreads();
-    {
-        const int c2 = (tid & 7) * 8;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale1n + c2), s1 = *reinterpret_cast<const f32x4*>(p.scale1n + c2 + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.shift1n + c2), t1 = *reinterpret_cast<const f32x4*>(p.shift1n + c2 + 4);
+            for (int st = 0; st < 2; ++st) {
+                const int row = (tid >> 3) + 32 * st;
+                const float* src = cs + row * CH_N2 + (c2 ^ (((row >> 2) & 1) << 5));
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s0 + t0;
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * s1 + t1;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int row = (tid >> 3) + 32 * st;
-            const float* src = cs + row * CH_N2 + (c2 ^ (((row >> 2) & 1) << 5));
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s0 + t0;
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * s1 + t1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
-            u32x4 o;
-            o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
-            o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
-            if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.y2 + (size_t)(m0 + row) * CH_N2 + c2) = o;
+                for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+                u32x4 o;
+                o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+                o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+                if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.y2 + (size_t)(m0 + row) * ldy2 + cg) = o;
+            }
         }
     }
 }
@@ -1612,7 +1620,7 @@ int hn_launch_conv1x1_chain_bf16(const void* t2, const void* w3, const float* sc
                                  hipStream_t s, const void* xd, const void* wd, const float* scale_d, const float* shift_d)
 {
     static const char* env = getenv("HN_XCD_SWIZZLE");
-    HN_REQUIRE(K1 == 64 && N1 == CH_N1 && N2 == CH_N2, "chained 1x1 convs: built for 64 -> 256 -> 64 channels (got %d -> %d -> %d)", K1, N1, N2);
+    HN_REQUIRE(K1 == 64 && N1 == CH_N1 && (N2 == CH_N2 || N2 == 2 * CH_N2), "chained 1x1 convs: built for 64 -> 256 -> 64 | 128 channels (got %d -> %d -> %d)", K1, N1, N2);
     HN_REQUIRE(M > 0 && M < 0x7fffffffL / 256, "chained 1x1 convs: bad M");
     ChainArgsH a;
     a.a1 = reinterpret_cast<const u16*>(t2); a.w3 = reinterpret_cast<const u16*>(w3); a.scale3 = scale3; a.shift3 = shift3;
@@ -1621,6 +1629,7 @@ int hn_launch_conv1x1_chain_bf16(const void* t2, const void* w3, const float* sc
     a.w1n = reinterpret_cast<const u16*>(w1n); a.scale1n = scale1n; a.shift1n = shift1n; a.y2 = reinterpret_cast<u16*>(t1n);
     a.M = (int)M;
     a.xcd_swizzle = env ? atoi(env) : 1;
+    a.n2_passes = N2 / CH_N2;
     static bool attr_done[64] = {};
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));

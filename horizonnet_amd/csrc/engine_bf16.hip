@@ -224,13 +224,16 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
             // layer1, block j -> j+1: conv3 (+ residual + ReLU) and the NEXT block's conv1 as ONE launch (conv1x1_chain_bf16_kernel):
             // the 537 MB block output is not read back from HBM by the next conv1.  Bit-identical to the two-launch form.
             // Block 0 -> 1 likewise, with the downsample branch as a second accumulator set of the same launch (DUAL form).
-            const bool chain_out = li == 0 && (j == 0 || j == 1) && e->chain_layer1 && !e->profiling && (j == 1 || e->fuse_downsample);
-            const bool chained_in = li == 0 && (j == 1 || j == 2) && e->chain_layer1 && !e->profiling && (j == 2 || e->fuse_downsample);
+            // Block 2 -> layer2.0.conv1 (128 output channels: two 64-column passes over the same LDS tile); the block output C1 is
+            // still written (the downsample branch, the height compression and the next residual read it).
+            const bool chain_on = e->chain_layer1 && !e->profiling;
+            const bool chain_out = chain_on && li == 0 && (j >= 1 || e->fuse_downsample);
+            const bool chained_in = chain_on && ((li == 0 && (j == 2 || (j == 1 && e->fuse_downsample))) || (li == 1 && j == 0));
             if (!chained_in && (rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
             if (chain_out) {
                 const ConvLayer& c3 = a.convs[i1 + 2];
-                const int in1 = a.block_first[li][j + 1];
+                const int in1 = j + 1 < nblk[li] ? a.block_first[li][j + 1] : a.block_first[li + 1][0];
                 const ConvLayer& c1n = a.convs[in1];
                 const int id = a.block_down[li];
                 const ConvLayer& cd = a.convs[id];
