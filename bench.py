@@ -94,7 +94,7 @@ def shard_for_rank(global_units, world, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=12.0):
     """Oracle (CPU restatement of the reference forward, torch fp32 on the host cores), bounded sample."""
     from oracle import horizonnet_ref
     from oracle.weights import make_state_dict
@@ -109,7 +109,9 @@ def cpu_baseline(seconds_budget=20.0):
         horizonnet_ref.forward(x, sd)
         n += x.shape[0]
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 16:
+        if el > seconds_budget and n >= 16:              # a bounded sample: ~12 s of CPU work, at least 16 panoramas
+            break
+        if el > 3 * seconds_budget:
             break
     return {"value": n / el, "unit": "panoramas/s", "cores": cores, "kind": "port",
             "sample": "%d panoramas (batches of 2) through oracle.horizonnet_ref.forward, torch %s fp32, %d threads, %.1f s"
