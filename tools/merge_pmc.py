@@ -29,7 +29,8 @@ def main():
         for k, row in recs["WRITE_SIZE"]["per_forward_by_kernel_family"].items():
             fam.setdefault(k, {"dispatches_per_forward": row["dispatches_per_forward"]})["write_bytes"] = row.get("write_bytes", 0.0)
         for k, row in recs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("per_forward_by_kernel_family", {}).items():
-            busy, tot = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), row.get("SQ_BUSY_CYCLES", 0.0)
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the busy counter over the 1024 SIMDs
+            busy, tot = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), row.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * 1024.0
             f = fam.setdefault(k, {"dispatches_per_forward": row["dispatches_per_forward"]})
             f["mfma_busy_pct"] = round(100.0 * busy / tot, 1) if tot else 0.0
             f["gpu_cycles_per_xcd"] = row.get("GRBM_GUI_ACTIVE", 0.0) / 8.0

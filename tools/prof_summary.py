@@ -16,7 +16,12 @@ from collections import defaultdict
 
 def family(name):
     n = name
-    for key in ("conv_igemm_bf16_w8", "conv1x1_dual_bf16", "conv_igemm_bf16", "conv_igemm_kernel", "conv_wgrad", "lstm_layer_bf16", "lstm_layer",
+    if "at::native" in n or "rocclr" in n:
+        return "other:framework"
+    if "multi_job" in n:
+        return "pack_multi_job"                         # weight packing, once per engine
+    for key in ("conv_igemm_bf16_w8", "conv1x1_dual_bf16", "conv1x1_chain_bf16", "conv1x1_dual_f32", "conv_igemm_bf16", "conv_igemm_kernel", "conv_wgrad",
+                "splitk_reduce", "lstm_layer_bf16", "lstm_layer",
                 "maxpool", "prep_nhwc", "upsample_flatten", "linear_head", "f32_to_bf16", "pack_", "fold_bn", "find_peaks", "pano_stretch",
                 "augment"):
         if key in n:
@@ -54,8 +59,8 @@ def counters(d, forwards, title):
             ndisp[k].add(r["Dispatch_Id"])
     out = {"what": title, "forwards_in_run": forwards, "per_forward_by_kernel_family": {}, "per_forward_total": defaultdict(float)}
     for k, cs in sorted(fam.items()):
-        if k.startswith("pack_") or k.startswith("fold_bn") or k.startswith("other:"):
-            continue                                   # weight packing etc.: once per process, not part of a forward
+        if k.startswith("pack_") or k.startswith("fold_bn") or k == "other:framework":
+            continue                                   # weight packing, torch fills/copies: once per process, not part of a forward
         row = {"dispatches_per_forward": len(ndisp[k]) / forwards}
         for c, v in cs.items():
             v = v / forwards
