@@ -50,7 +50,21 @@ struct ConvArgsH {
     int sh_log2, sw_log2;
     int ca, cb, cHo, cWo;
     int tdh[3], tdw[3], ntdh, ntdw;
+#ifdef HN_CONV_TRACE
+    unsigned long long* trace = nullptr;   // throw-away measurement builds only (tools/conv_trace.py): 8 stamps per workgroup / tile
+#endif
 };
+
+// Measurement builds (-DHN_CONV_TRACE, tools/conv_trace.py): s_memrealtime stamps per workgroup (per tile in the persistent
+// kernel) at entry, first chunk landed, k loop done, after every epilogue band; HW_ID / XCC_ID in slot 7.  Compiled out otherwise.
+#ifdef HN_CONV_TRACE
+#define HN_TR_STAMP(wg, k) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)(wg) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define HN_TR_HWID(wg) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)(wg) * 8 + 7] = \
+    (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); } while (0)
+#else
+#define HN_TR_STAMP(wg, k) do {} while (0)
+#define HN_TR_HWID(wg) do {} while (0)
+#endif
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, unsigned voff, unsigned soff)
 {
@@ -218,11 +232,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
     const int half = lane >> 5;
     const int fswz = (fr >> 1) & 7;
 
+    [[maybe_unused]] const size_t tr_wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    HN_TR_STAMP(tr_wg, 0);
+    HN_TR_HWID(tr_wg);
     if (!TR || p.nk > 0) {      // a parity class no tap reaches (1x1 stride 2) has K = 0: dX = add there
         fetch(kb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    HN_TR_STAMP(tr_wg, 1);
 
     {
         u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
@@ -261,6 +279,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
         }
         __syncthreads();
     }
+    HN_TR_STAMP(tr_wg, 2);
 
     // ---- epilogue: f32 accumulators -> LDS -> 8 channels per lane: scale/shift, residual, ReLU, bf16 (or f32) rows ----
     constexpr int CS = BN + 4;
@@ -361,6 +380,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                     }
                 }
             }
+            HN_TR_STAMP(tr_wg, 3 + h);
         }
         if (p.stat_sum) {        // see conv_igemm_f32.hip: per-channel sums of the stored tile -> one f64 atomic per channel
             __syncthreads();
@@ -888,10 +908,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p
 // kernel's (same results bit for bit: the accumulation order over k does not depend on the tile shape).
 // STATS: train-mode BatchNorm statistics of the stored rows (per-channel sum / sum of squares -> one f64 atomic per channel and
 // workgroup), as in the 4-wave kernel's epilogue; a separate instantiation so that the inference kernel's registers stay as they are.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false>
+// PERSIST: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... of the (XCD-swizzled) tile list.  What it buys is
+// measured with tools/conv_trace.py: a 256x256 workgroup owns its CU alone (128 KiB of LDS), so between two tiles the CU sat
+// idle for the dispatch of the next workgroup (1.6-1.7 us) plus the first chunk's flight (1.2-1.9 us) -- 15-20 % of a 1x1
+// expansion's tile.  Here the next tile's first chunk is requested right after the k loop, into stage 0, and lands while the
+// epilogue runs out of a slab at the TOP of the 160 KiB (over stage 1 and the 32 KiB above it).  Same arithmetic, same bits.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
 {
     static_assert(WAVES_M * WAVES_N == 8, "8 waves per workgroup");
+    static_assert(!(PERSIST && STATS), "the persistent form is an inference kernel");
     constexpr int NW = 8;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -899,6 +925,12 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     constexpr int AP = BM / 64, BP = BN / 64;              // loader passes: 64 rows (512 threads x 16 bytes) each
     constexpr int A_BYTES = BM * ROWB;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int CS = BN + 4;
+    constexpr int SLAB = 32 * CS;                           // floats
+    static_assert(WAVES_M * SLAB * 4 <= 2 * STAGE_BYTES, "C slabs must fit in the staging LDS");
+    constexpr int LDS_P = 160 * 1024;                       // persistent launches take the whole LDS
+    constexpr int SLAB_OFF = PERSIST ? LDS_P - WAVES_M * SLAB * 4 : 0;     // bytes
+    static_assert(!PERSIST || (SLAB_OFF >= STAGE_BYTES && SLAB_OFF % 16 == 0), "epilogue slabs must leave stage 0 alone");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -910,55 +942,26 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     const int lslot = tid & 7;
     const int lcol = lslot ^ ((lrow >> 1) & 7);
 
-    int bid = blockIdx.x;
-    if (p.xcd_swizzle) {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int NT = p.Cout / BN;
-    const int nt = bid % NT;
-    const int mt = bid / NT;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
-
     const int hw_out = p.Ho * p.Wo;
-    const int b_first = m0 / hw_out;
     const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
-    const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w + (size_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
+    const int total = PERSIST ? ((p.M + BM - 1) / BM) * NT : (int)gridDim.x;
 
+    // ---- per-tile state (re-made by setup() for every tile of a persistent workgroup) ----
+    int m0 = 0, n0 = 0;
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
     int a_pix0[AP], a_hi0[AP], a_wi0[AP];
-#pragma unroll
-    for (int q = 0; q < AP; ++q) {
-        const int m = m0 + lrow + 64 * q;
-        if (m < p.M) {
-            const int wo = m % p.Wo;
-            const int t = m / p.Wo;
-            const int ho = t % p.Ho;
-            const int b = t / p.Ho;
-            a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
-            a_hi0[q] = ho * p.sh - p.ph;
-            a_wi0[q] = wo * p.sw - p.pw;
-        } else {
-            a_pix0[q] = -1;
-            a_hi0[q] = 0;
-            a_wi0[q] = 0;
-        }
-    }
+    unsigned a_off[AP];
+    int dh = 0, dw = 0, c0 = 0;
     unsigned w_off[BP];
 #pragma unroll
     for (int q = 0; q < BP; ++q) w_off[q] = (unsigned)((lrow + 64 * q) * p.K + lcol * 8) * 2u;
 
-    unsigned a_off[AP];
-    auto tap_offsets = [&](int dh, int dw) {
+    auto tap_offsets = [&](int th, int tw) {
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
-            const int hi = a_hi0[q] + dh;
-            int wi = a_wi0[q] + dw;
+            const int hi = a_hi0[q] + th;
+            int wi = a_wi0[q] + tw;
             wi = wi < 0 ? wi + p.Wi : wi;
             wi = wi >= p.Wi ? wi - p.Wi : wi;
             const bool ok = a_pix0[q] >= 0 && ((unsigned)hi < (unsigned)p.Hi);
@@ -966,9 +969,40 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
             a_off[q] = ok ? (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u : OOB;
         }
     };
-
-    int dh = 0, dw = 0, c0 = 0;
-    tap_offsets(0, 0);
+    auto setup = [&](int vb) {       // tile vb of the launch order -> (m0, n0), buffer resources, row coordinates, first tap
+        int bid = vb;
+        if (p.xcd_swizzle) {
+            const int q = total >> 3, r = total & 7;
+            const int xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const int nt = bid % NT;
+        const int mt = bid / NT;
+        m0 = mt * BM;
+        n0 = nt * BN;
+        const int b_first = m0 / hw_out;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
+        rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.w + (size_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const int m = m0 + lrow + 64 * q;
+            if (m < p.M) {
+                const int wo = m % p.Wo;
+                const int t = m / p.Wo;
+                const int ho = t % p.Ho;
+                const int b = t / p.Ho;
+                a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
+                a_hi0[q] = ho * p.sh - p.ph;
+                a_wi0[q] = wo * p.sw - p.pw;
+            } else {
+                a_pix0[q] = -1;
+                a_hi0[q] = 0;
+                a_wi0[q] = 0;
+            }
+        }
+        dh = 0; dw = 0; c0 = 0;
+        tap_offsets(0, 0);
+    };
 
     auto fetch = [&](int kc) {       // chunk kc -> LDS stage (kc & 1)
         char* a_s = smem + (kc & 1) * STAGE_BYTES;
@@ -985,134 +1019,159 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
         }
     };
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int fr = lane & 31;
     const int half = lane >> 5;
     const int fswz = (fr >> 1) & 7;
 
-    fetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    {
-        u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        auto ldfrag = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN], int buf, int ks) {
-            const int koff = ((2 * ks + half) ^ fswz) * 16;
-            const char* a_s = smem + buf * STAGE_BYTES + (wm * WM + fr) * ROWB + koff;
-            const char* b_s = smem + buf * STAGE_BYTES + A_BYTES + (wn * WN + fr) * ROWB + koff;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a_s + i * 32 * ROWB);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b_s + j * 32 * ROWB);
-        };
-        auto mma = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                        acc[i][j], 0, 0, 0);
-        };
-        ldfrag(fa0, fb0, 0, 0);
-        for (int kc = 0; kc < p.nk; ++kc) {
-            const int buf = kc & 1;
-            const bool more = kc + 1 < p.nk;
-            if (more) fetch(kc + 1);
-            ldfrag(fa1, fb1, buf, 1);
-            mma(fa0, fb0);
-            ldfrag(fa0, fb0, buf, 2);
-            mma(fa1, fb1);
-            ldfrag(fa1, fb1, buf, 3);
-            mma(fa0, fb0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc+1 has landed
-            __syncthreads();
-            if (more) ldfrag(fa0, fb0, buf ^ 1, 0);
-            mma(fa1, fb1);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: per 32-row MFMA band i, every wave row writes its band into its own LDS slab ([32][BN] floats);
-    //      the 512 threads then sweep the WAVES_M slabs as whole rows: scale/shift, residual, ReLU, 16-byte stores ----
-    constexpr int CS = BN + 4;
-    constexpr int SLAB = 32 * CS;                           // floats
-    static_assert(WAVES_M * SLAB * 4 <= 2 * STAGE_BYTES, "C slabs must fit in the staging LDS");
+    // epilogue geometry: per 32-row MFMA band i, every wave row writes its band into its own LDS slab ([32][BN] floats);
+    // the 512 threads then sweep the WAVES_M slabs as whole rows: scale/shift, residual, ReLU, 16-byte stores
     constexpr int TPR = BN / 8;                             // threads per output row (8 channels each)
     constexpr int RPP = 512 / TPR;                          // rows per sweep pass
     constexpr int NPASS = WAVES_M * 32 / RPP;
     static_assert(NPASS >= 1 && (WAVES_M * 32) % RPP == 0, "sweep geometry");
-    float* cs = reinterpret_cast<float*>(smem);
+    float* cs = reinterpret_cast<float*>(smem + SLAB_OFF);
     const int ccol = (tid % TPR) * 8;
     const int crow = tid / TPR;
-    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
-    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol + 4);
-    const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
-    const f32x4 sf1 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol + 4);
     const bool has_res = p.res != nullptr;
     f32x4 st1a = {0.f, 0.f, 0.f, 0.f}, st1b = st1a, st2a = st1a, st2b = st1a;     // STATS: sums of this thread's 8 columns
+
+    int vb = blockIdx.x;
+    [[maybe_unused]] int tr_wg = vb;
+    HN_TR_STAMP(tr_wg, 0);
+    HN_TR_HWID(tr_wg);
+    setup(vb);
+    fetch(0);
+
+    while (true) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // chunk 0 of this tile is in stage 0 (and the previous tile's slab reads are over)
+        HN_TR_STAMP(tr_wg, 1);
+
+        f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        u32x4 rres[NPASS];
-        if (has_res) {
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int sr = crow + ps * RPP;             // 0 .. WAVES_M*32-1: slab sr / 32, row sr % 32
-                const int m = m0 + (sr >> 5) * WM + i * 32 + (sr & 31);
-                const int mc = m < p.M ? m : p.M - 1;
-                rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + n0 + ccol);
-            }
-        }
-        if (i > 0) __syncthreads();
-        {
-            float* c_w = cs + wm * SLAB + (4 * half) * CS + wn * WN + fr;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c_w[((r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
-        }
-        __syncthreads();
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        {
+            u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+            auto ldfrag = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN], int buf, int ks) {
+                const int koff = ((2 * ks + half) ^ fswz) * 16;
+                const char* a_s = smem + buf * STAGE_BYTES + (wm * WM + fr) * ROWB + koff;
+                const char* b_s = smem + buf * STAGE_BYTES + A_BYTES + (wn * WN + fr) * ROWB + koff;
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int sr = crow + ps * RPP;
-            const int m = m0 + (sr >> 5) * WM + i * 32 + (sr & 31);
-            const float* src = cs + (sr >> 5) * SLAB + (sr & 31) * CS + ccol;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-            v0 = v0 * sc0 + sf0;
-            v1 = v1 * sc1 + sf1;
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a_s + i * 32 * ROWB);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b_s + j * 32 * ROWB);
+            };
+            auto mma = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                            acc[i][j], 0, 0, 0);
+            };
+            ldfrag(fa0, fb0, 0, 0);
+            for (int kc = 0; kc < p.nk; ++kc) {
+                const int buf = kc & 1;
+                const bool more = kc + 1 < p.nk;
+                if (more) fetch(kc + 1);
+                ldfrag(fa1, fb1, buf, 1);
+                mma(fa0, fb0);
+                ldfrag(fa0, fb0, buf, 2);
+                mma(fa1, fb1);
+                ldfrag(fa1, fb1, buf, 3);
+                mma(fa0, fb0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc+1 has landed
+                __syncthreads();
+                if (more) ldfrag(fa0, fb0, buf ^ 1, 0);
+                mma(fa1, fb1);
+            }
+            __syncthreads();
+        }
+        HN_TR_STAMP(tr_wg, 2);
+
+        // the tile being written; a persistent workgroup now points its loader at the next tile and requests its first chunk
+        const int em0 = m0, en0 = n0;
+        [[maybe_unused]] const int tr_done = tr_wg;
+        bool has_next = false;
+        if (PERSIST) {
+            vb += (int)gridDim.x;
+            has_next = vb < total;
+            if (has_next) {
+                tr_wg = vb;
+                HN_TR_STAMP(tr_wg, 0);
+                HN_TR_HWID(tr_wg);
+                setup(vb);
+                fetch(0);
+            }
+        }
+
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + en0 + ccol);
+        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + en0 + ccol + 4);
+        const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + en0 + ccol);
+        const f32x4 sf1 = *reinterpret_cast<const f32x4*>(p.shift + en0 + ccol + 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            u32x4 rres[NPASS];
             if (has_res) {
-                const u32x4 rr = rres[ps];
-                v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
-                v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
-            }
-            if (p.relu) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
-            }
-            if (m < p.M) {
-                if (STATS) {
-                    st1a += v0; st1b += v1;
-                    st2a += v0 * v0; st2b += v1 * v1;
-                }
-                if (OUT_F32) {
-                    float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n0 + ccol;
-                    *reinterpret_cast<f32x4*>(yo) = v0;
-                    *reinterpret_cast<f32x4*>(yo + 4) = v1;
-                } else {
-                    u32x4 o;
-                    o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
-                    o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + n0 + ccol) = o;
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int sr = crow + ps * RPP;             // 0 .. WAVES_M*32-1: slab sr / 32, row sr % 32
+                    const int m = em0 + (sr >> 5) * WM + i * 32 + (sr & 31);
+                    const int mc = m < p.M ? m : p.M - 1;
+                    rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + en0 + ccol);
                 }
             }
+            if (i > 0) __syncthreads();
+            {
+                float* c_w = cs + wm * SLAB + (4 * half) * CS + wn * WN + fr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c_w[((r & 3) + 8 * (r >> 2)) * CS + j * 32] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int sr = crow + ps * RPP;
+                const int m = em0 + (sr >> 5) * WM + i * 32 + (sr & 31);
+                const float* src = cs + (sr >> 5) * SLAB + (sr & 31) * CS + ccol;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                v0 = v0 * sc0 + sf0;
+                v1 = v1 * sc1 + sf1;
+                if (has_res) {
+                    const u32x4 rr = rres[ps];
+                    v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
+                    v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+                }
+                if (m < p.M) {
+                    if (STATS) {
+                        st1a += v0; st1b += v1;
+                        st2a += v0 * v0; st2b += v1 * v1;
+                    }
+                    if (OUT_F32) {
+                        float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + en0 + ccol;
+                        *reinterpret_cast<f32x4*>(yo) = v0;
+                        *reinterpret_cast<f32x4*>(yo + 4) = v1;
+                    } else {
+                        u32x4 o;
+                        o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+                        o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + en0 + ccol) = o;
+                    }
+                }
+            }
+            HN_TR_STAMP(tr_done, 3 + i);
         }
+        if (!PERSIST || !has_next) break;
     }
     if (STATS) {             // per-channel sums of the stored tile: threads of one column group -> LDS -> one f64 atomic per channel
         static_assert(2 * RPP * BN * 4 <= 2 * STAGE_BYTES, "statistics scratch must fit in the staging LDS");
@@ -1136,21 +1195,29 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false, bool PERSIST = false>
 int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
 {
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32, STATS>;
+    const size_t lds = PERSIST ? (size_t)160 * 1024 : 2 * (size_t)(BM + BN) * ROWB;
+    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32, STATS, PERSIST>;
     static bool attr_done[64] = {};   // per instantiation, per device
+    static int n_cu[64] = {};
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_done[dev]) {
         HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HN_HIP(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
         attr_done[dev] = true;
     }
     const int MT = hn_cdiv(a.M, BM);
     const int NT = a.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(MT * NT)), dim3(512), lds, s, a);
+    const int tiles = MT * NT;
+    int grid = tiles;
+    if (PERSIST) {
+        const int cus = dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
+        grid = tiles < cus ? tiles : cus;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, a);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -1184,7 +1251,13 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     // 256x256 tile wins by 10-25 % wherever it yields >= 224 workgroups (1.0-1.16 PF on the deep-K convs vs 0.8-0.96),
     // also on the HBM-bound 1x1 convs; with 128 workgroups (layer4 3x3, ghc3.0) half the CUs idle and it loses; the
     // 256x128 / 128x256 shapes (64x64 wave tiles) never beat the 4-wave 128x128 kernel and are kept for A/B runs only
-    if (force < 0 && t256 >= 224) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
+    if (force < 0 && t256 >= 224) {
+        // more than one tile per CU: the persistent form (next tile's first chunk in flight under the epilogue, no workgroup
+        // dispatch between tiles); HN_W8_PERSIST=0 for A/B runs
+        const char* pe = getenv("HN_W8_PERSIST");
+        if (t256 > 256 && !(pe && atoi(pe) == 0)) return launch_cfg_w8<256, 256, 2, 4, OUT_F32, false, true>(a, s);
+        return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
+    }
     *taken = false;
     return 0;
 }
@@ -1410,6 +1483,11 @@ inline unsigned grid_for(long total, long cap = 256L * 16)
 
 }  // namespace
 
+#ifdef HN_CONV_TRACE
+static unsigned long long* g_conv_trace = nullptr;
+extern "C" int hn_debug_conv_trace(void* buf) { g_conv_trace = static_cast<unsigned long long*>(buf); return 0; }
+#endif
+
 // d.x / d.w / d.res / d.y are reinterpreted as bf16 buffers (d.y as f32 when out_f32)
 int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
 {
@@ -1428,6 +1506,9 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.ksplit = 1;
     a.sh_log2 = a.sw_log2 = a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
     for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;
+#ifdef HN_CONV_TRACE
+    a.trace = g_conv_trace;
+#endif
     HN_REQUIRE(!d.res || !out_f32, "conv bf16: a residual with float32 output is only used by the data-gradient launcher");
     {
         const double span = 256.0 / ((double)d.Ho * d.Wo) + 2.0;
