@@ -38,6 +38,7 @@ SIGNATURES = {
     "hn_pack_weights_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "hn_workspace_bf16_bytes": (_sz, [_i]),
     "hn_forward_bf16": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hn_stem_pool_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hn_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_workspace_bf16_pipelined_bytes": (_sz, [_i]),
     "hn_forward_bf16_submit": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),

@@ -39,7 +39,7 @@ struct ConvArgsH {
     const u16* res;
     void* y;
     int Hi, Wi, Cin, Ho, Wo, Cout;
-    int KW, sh, sw, ph, pw;
+    int KH, KW, sh, sw, ph, pw;   // K order of the forward kernels: (64-channel chunk, filter tap, channel in chunk) -- see fetch()
     int M, K, nk, relu, ldy;
     int xstride;
     int xcd_swizzle;
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
         const int sl = blockIdx.y;
         kb = (int)((long)p.nk * sl / p.ksplit);
         ke = (int)((long)p.nk * (sl + 1) / p.ksplit);
-        const int cpt = p.Cin / BKE;                     // chunks per filter tap
-        const int tap = kb / cpt;
-        c0 = (kb - tap * cpt) * BKE;
+        const int ntap = p.KH * p.KW;                    // chunk index = channel chunk * taps + tap
+        const int cc = kb / ntap;
+        const int tap = kb - cc * ntap;
+        c0 = cc * BKE;
         dh = tap / p.KW;
         dw = tap - dh * p.KW;
     }
@@ -210,13 +211,22 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
         if (STEM) {
             dh += 1;
             tap_offsets(dh, 0);
-        } else {
+        } else if (TR) {                 // data gradient: taps outer, channels inner (its own per-class packing)
             c0 += BKE;
             if (c0 == p.Cin) {
                 c0 = 0;
-                if (++dw == (TR ? p.ntdw : p.KW)) { dw = 0; ++dh; }
-                if (!TR || dh < p.ntdh) tap_offsets(dh, dw);
+                if (++dw == p.ntdw) { dw = 0; ++dh; }
+                if (dh < p.ntdh) tap_offsets(dh, dw);
             }
+        } else {
+            // forward: the filter taps are the INNER loop of a 64-channel chunk -- the chunk of tap (dh, dw + 1) is the chunk of
+            // (dh, dw) moved by one pixel, so 127 of its 128 lines were fetched one iteration ago (L1 / L2 hits) instead of
+            // Cin / 64 iterations ago; rocprofv3 FETCH_SIZE of the 3x3 convs was 3-5x their input with taps outer
+            if (++dw == p.KW) {
+                dw = 0;
+                if (++dh == p.KH) { dh = 0; c0 += BKE; }
+            }
+            if (p.KH * p.KW > 1) tap_offsets(dh, dw);
         }
     };
 
@@ -1011,12 +1021,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
         for (int q = 0; q < AP; ++q) dma16(rsrc_a, a_s + (q * NW + wave) * 1024, a_off[q], (unsigned)c0 * 2u);
 #pragma unroll
         for (int q = 0; q < BP; ++q) dma16(rsrc_w, b_s + (q * NW + wave) * 1024, w_off[q], (unsigned)kc * (unsigned)ROWB);
-        c0 += BKE;
-        if (c0 == p.Cin) {
-            c0 = 0;
-            if (++dw == p.KW) { dw = 0; ++dh; }
-            tap_offsets(dh, dw);
+        if (++dw == p.KW) {              // taps inner, 64-channel chunks outer (see the 4-wave kernel's fetch)
+            dw = 0;
+            if (++dh == p.KH) { dh = 0; c0 += BKE; }
         }
+        if (p.KH * p.KW > 1) tap_offsets(dh, dw);
     };
 
     const int fr = lane & 31;
@@ -1398,18 +1407,22 @@ __global__ __launch_bounds__(256) void upsample_flatten_bf16_kernel(const u16* _
     }
 }
 
-// OIHW f32 -> packed bf16 [Cout][kh][KWp][Cp] (zero padded taps / channels for the stem)
+// OIHW f32 -> packed bf16 [Cout][Cp / 64][kh][KWp][64] (Cp a multiple of 64)
 __global__ __launch_bounds__(256) void pack_conv_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout, int Cin, int KH,
                                                              int KW, int KWp, int Cp)
 {
     const long total = (long)Cout * KH * KWp * Cp;
+    const int ntap = KH * KWp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cp);
-        long t = i / Cp;
-        const int dw = (int)(t % KWp);
-        t /= KWp;
-        const int dh = (int)(t % KH);
-        const int o = (int)(t / KH);
+        // k = (64-channel chunk, tap, channel in chunk): the forward kernels' chunk order (taps inner)
+        const int e = (int)(i % BKE);
+        long t = i / BKE;
+        const int tap = (int)(t % ntap);
+        t /= ntap;
+        const int cc = (int)(t % (Cp / BKE));
+        const int o = (int)(t / (Cp / BKE));
+        const int dh = tap / KWp, dw = tap - dh * KWp;
+        const int c = cc * BKE + e;
         float v = 0.f;
         if (c < Cin && dw < KW) v = w[(((long)o * Cin + c) * KH + dh) * KW + dw];
         out[i] = (u16)(pack_bf16(v, 0.f) & 0xffffu);
@@ -1497,7 +1510,7 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.x = reinterpret_cast<const u16*>(d.x); a.w = reinterpret_cast<const u16*>(d.w); a.scale = d.scale; a.shift = d.shift;
     a.res = reinterpret_cast<const u16*>(d.res); a.y = d.y;
     a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
-    a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
+    a.KH = d.KH; a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;
     a.xstride = d.xstride ? d.xstride : d.Cin;
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;

@@ -195,15 +195,22 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
     {   // stem: normalise -> NHWC4 bf16, 7x7/2 conv + BN + ReLU, max-pool
         const ConvLayer& c = a.convs[a.stem];
         ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
-        if ((rc = hn_launch_prep_nhwc4_bf16(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
+        const bool fused = e->fuse_stem_pool && e->taps.empty();
+        if (!fused && (rc = hn_launch_prep_nhwc4_bf16(x, W + pl.xn, B, C_in, IMG_H, IMG_W, s))) return rc;
         ConvDesc d;
         memset(&d, 0, sizeof(d));
         d.x = reinterpret_cast<const float*>(W + pl.xn); d.w = reinterpret_cast<const float*>(H + h.conv[a.stem]);
         d.scale = P + c.scale_off; d.shift = P + c.shift_off; d.y = reinterpret_cast<float*>(W + pl.stem);
         d.B = B; d.Hi = IMG_H; d.Wi = IMG_W; d.Cin = 8; d.Cout = 64; d.KH = 7; d.KW = 7; d.sh = 2; d.sw = 2; d.ph = 3; d.pw = 3;
         d.Ho = 256; d.Wo = 512; d.relu = 1; d.ldy = 64; d.stem = 1;
-        if ((rc = hn_launch_conv_bf16(d, 0, s))) return rc;
-        if ((rc = hn_launch_maxpool_bf16(W + pl.stem, W + pl.pool, B, 256, 512, 64, s))) return rc;
+        if (fused) {
+            // normalise + conv + BN + ReLU + max-pool in one kernel (stem_pool_bf16.hip): neither the NHWC4 copy of the input nor
+            // the 537 MB stem activation exists
+            if ((rc = hn_launch_stem_pool_bf16(x, C_in, H + h.conv[a.stem], d.scale, d.shift, W + pl.pool, B, s))) return rc;
+        } else {
+            if ((rc = hn_launch_conv_bf16(d, 0, s))) return rc;
+            if ((rc = hn_launch_maxpool_bf16(W + pl.stem, W + pl.pool, B, 256, 512, 64, s))) return rc;
+        }
     }
     if ((rc = e->tap("stem", W + pl.stem, (size_t)B * 256 * 512 * 64 * 2, s))) return rc;
     if ((rc = e->tap("pool", W + pl.pool, (size_t)B * 128 * 256 * 64 * 2, s))) return rc;
@@ -483,6 +490,28 @@ extern "C" int hn_lstm_layer_bwd_bf16(const float* saved, const float* dy, const
 {
     HN_REQUIRE(saved && dy && whhT_fwd_bf16 && whhT_rev_bf16 && dgx && exchange && sync_ws, "hn_lstm_layer_bwd_bf16: null pointer");
     return hn_launch_lstm_layer_bwd_bf16(saved, dy, whhT_fwd_bf16, whhT_rev_bf16, dgx, T, B, exchange, sync_ws, (hipStream_t)stream);
+}
+
+// per-stage entry point for the parity tests: the bf16 stem (normalise, 7x7/2 conv + BN + ReLU, 3x3/2 max-pool) of a
+// 512 x 1024 batch, fused (stem_pool_bf16.hip) or as the implicit GEMM + pool kernels
+extern "C" int hn_stem_pool_bf16(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift, void* x4_scratch,
+                                 void* w_scratch, void* stem_scratch, void* y, int B, int fused, void* stream)
+{
+    HN_REQUIRE(x_nchw && w_oihw && scale && shift && x4_scratch && w_scratch && y && B >= 1, "hn_stem_pool_bf16: null pointer / empty batch");
+    HN_REQUIRE(fused || stem_scratch, "hn_stem_pool_bf16: the two-kernel form needs the [B][256][512][64] bf16 scratch");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = hn_launch_pack_conv_bf16(w_oihw, w_scratch, 64, 3, 7, 7, s))) return rc;
+    if (fused) return hn_launch_stem_pool_bf16(x_nchw, 3, w_scratch, scale, shift, y, B, s);
+    if ((rc = hn_launch_prep_nhwc4_bf16(x_nchw, x4_scratch, B, 3, IMG_H, IMG_W, s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = reinterpret_cast<const float*>(x4_scratch); d.w = reinterpret_cast<const float*>(w_scratch);
+    d.scale = scale; d.shift = shift; d.y = reinterpret_cast<float*>(stem_scratch);
+    d.B = B; d.Hi = IMG_H; d.Wi = IMG_W; d.Cin = 8; d.Cout = 64; d.KH = 7; d.KW = 7; d.sh = 2; d.sw = 2; d.ph = 3; d.pw = 3;
+    d.Ho = 256; d.Wo = 512; d.relu = 1; d.ldy = 64; d.stem = 1;
+    if ((rc = hn_launch_conv_bf16(d, 0, s))) return rc;
+    return hn_launch_maxpool_bf16(stem_scratch, y, B, 256, 512, 64, s);
 }
 
 // per-stage entry point for the parity tests: x / w / res / y are bf16 device buffers (y f32 when out_f32)

@@ -35,7 +35,20 @@ __global__ __launch_bounds__(256) void multi_job_kernel(const MJob* __restrict__
     const int kind = j->kind;
     const float* __restrict__ src = reinterpret_cast<const float*>(j->src);
 
-    if (kind == MJ_PACK_F32 || kind == MJ_PACK_BF16) {
+    if (kind == MJ_PACK_BF16) {          // k = (64-channel chunk, tap, channel in chunk), see pack_conv_bf16_kernel
+        const int Cin = j->p[1], KH = j->p[2], KW = j->p[3];
+        const int ntap = KH * KW, nch = Cin / 64;
+        for (long long i = base + threadIdx.x; i < end; i += 256) {
+            const int e = (int)(i % 64);
+            long long t = i / 64;
+            const int tap = (int)(t % ntap);
+            t /= ntap;
+            const int cc = (int)(t % nch);
+            const int o = (int)(t / nch);
+            const int dh = tap / KW, dw = tap - dh * KW;
+            reinterpret_cast<u16*>(j->dst)[i] = to_bf16(src[(((long long)o * Cin + cc * 64 + e) * KH + dh) * KW + dw]);
+        }
+    } else if (kind == MJ_PACK_F32) {
         const int Cin = j->p[1], KH = j->p[2], KW = j->p[3], KWp = j->p[4], Cp = j->p[5];
         for (long long i = base + threadIdx.x; i < end; i += 256) {
             const int c = (int)(i % Cp);
@@ -46,8 +59,7 @@ __global__ __launch_bounds__(256) void multi_job_kernel(const MJob* __restrict__
             const int o = (int)(t / KH);
             float v = 0.f;
             if (c < Cin && dw < KW) v = src[(((long long)o * Cin + c) * KH + dh) * KW + dw];
-            if (kind == MJ_PACK_F32) reinterpret_cast<float*>(j->dst)[i] = v;
-            else reinterpret_cast<u16*>(j->dst)[i] = to_bf16(v);
+            reinterpret_cast<float*>(j->dst)[i] = v;
         }
     } else if (kind == MJ_PACK_STEM_BF16) {
         for (long long i = base + threadIdx.x; i < end; i += 256) {

@@ -146,6 +146,13 @@ int hn_forward_bf16_submit(hn_engine* e, const float* x, int B, int C_in, float*
                            size_t workspace_bytes, int slot, void* stream);
 int hn_forward_bf16_collect(hn_engine* e, int slot, void* stream);
 int hn_pipelined_status_offset(int B, int slot, size_t* byte_offset);
+/* per-stage (tests): the bf16 stem of hn_forward_bf16 on a [B][3][512][1024] float32 batch -- (x - mean) / std, 7x7/2
+ * convolution (circular in W) + folded BatchNorm + ReLU, 3x3/2 max-pool (reference model.py:73-81 with torchvision's
+ * resnet conv1 / bn1 / relu / maxpool and the LR padding of model.py:28-61) -> y [B][128][256][64] bf16 NHWC.
+ * fused != 0: the one-kernel form the engine runs (option "fuse_stem_pool"); 0: implicit-GEMM stem + pool kernel
+ * (needs stem_scratch [B][256][512][64] bf16).  x4_scratch: B*512*1024*4 bf16, w_scratch: 64*256 bf16.  Bit-identical. */
+int hn_stem_pool_bf16(const float* x_nchw, const float* w_oihw, const float* scale, const float* shift, void* x4_scratch,
+                      void* w_scratch, void* stem_scratch, void* y, int B, int fused, void* stream);
 /* per-stage (tests): x / res / y bf16 NHWC (y f32 when out_f32), w_oihw f32, w_scratch Cout*KH*KW*Cin bf16
  * (w_oihw == NULL: w_scratch already holds the packed weights of an earlier call) */
 int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,

@@ -433,3 +433,61 @@ def test_chained_conv3_conv1_bit_identical():
         for k in ("c1", "c2", "feature"):
             assert torch.equal(t0[k], t1[k]), "tap %s differs: %g" % (k, float((t0[k].float() - t1[k].float()).abs().max()))
         assert torch.equal(b0, b1) and torch.equal(c0, c1)
+
+
+def _stem_pool(x, w, scale, shift, fused):
+    from horizonnet_amd import _lib
+    L = _lib.load()
+    B = x.shape[0]
+    x4 = torch.empty(B * 512 * 1024 * 4, dtype=torch.bfloat16, device=DEV)
+    wp = torch.empty(64 * 256, dtype=torch.bfloat16, device=DEV)
+    stem = None if fused else torch.empty(B * 256 * 512 * 64, dtype=torch.bfloat16, device=DEV)
+    y = torch.full((B, 128, 256, 64), -1.0, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.hn_stem_pool_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(x4), _lib.ptr(wp), _lib.ptr(stem),
+                                   _lib.ptr(y), B, int(fused), _lib.stream_ptr(DEV)), "hn_stem_pool_bf16")
+    torch.cuda.synchronize()
+    return y
+
+
+def test_fused_stem_pool_bit_identical():
+    """stem_pool_bf16_kernel (7x7/2 conv straight out of an LDS ring of input rows + BN + ReLU + 3x3/2 max-pool in registers /
+    one LDS strip) against the implicit-GEMM stem + pool kernels: same k order and MFMA steps, same rounding point, max of
+    non-negative bf16 values -> bit-identical, for every band height the launcher picks (1, 2, 4, 8, 16 pooled rows per
+    workgroup), with negative BatchNorm scales (whole channels clamp to 0) and a torch float32 reference beside it."""
+    gen = torch.Generator().manual_seed(77)
+    w = ((torch.rand(64, 3, 7, 7, generator=gen) - 0.5) * 0.3).to(DEV)
+    scale = ((torch.rand(64, generator=gen) - 0.3) * 2.0).to(DEV)
+    shift = ((torch.rand(64, generator=gen) - 0.5) * 0.5).to(DEV)
+    for B in (1, 3, 6, 12, 20, 32):
+        x = torch.rand(B, 3, 512, 1024, generator=gen).to(DEV)
+        y1 = _stem_pool(x, w, scale, shift, True)
+        y0 = _stem_pool(x, w, scale, shift, False)
+        assert torch.equal(y0, y1), "B=%d: fused stem differs, max %g at %d elements" % (
+            B, float((y0.float() - y1.float()).abs().max()), int((y0 != y1).sum()))
+        if B == 3:      # float32 reference of the same stage (bf16 operands, float32 accumulation): loose, the exact check is above
+            mean = torch.tensor([0.485, 0.456, 0.406], device=DEV).view(1, 3, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225], device=DEV).view(1, 3, 1, 1)
+            xn = ((x - mean) / std).to(torch.bfloat16).float()
+            xp = torch.cat([xn[..., -3:], xn, xn[..., :3]], dim=3)
+            z = torch.nn.functional.conv2d(xp, w.to(torch.bfloat16).float(), stride=2, padding=(3, 0))
+            z = torch.relu(z * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+            ref = torch.nn.functional.max_pool2d(z, 3, 2, 1).permute(0, 2, 3, 1)
+            err = float((y1.float() - ref).abs().max())
+            assert err <= 2e-2 * float(ref.abs().max()), err
+
+
+def test_fused_stem_forward_bit_identical():
+    """The whole bf16 forward with the fused stem (default) and with the two-kernel stem: identical outputs, plain and pipelined."""
+    net = _net(4, "random")
+    net.precision = "bf16"
+    x = torch.rand(3, 3, 512, 1024, generator=torch.Generator().manual_seed(78)).to(DEV)
+    with torch.no_grad():
+        net.set_engine_option("fuse_stem_pool", 0)
+        b0, c0 = net(x)
+        net.set_engine_option("fuse_stem_pool", 1)
+        b1, c1 = net(x)
+        b2, c2 = net.forward_async(x).result()
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    assert torch.equal(b0, b1) and torch.equal(c0, c1)
+    assert torch.equal(b0, b2) and torch.equal(c0, c2)
