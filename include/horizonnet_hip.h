@@ -99,8 +99,11 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * (model.py:138-156), which depend only on C1..C4, on an engine-owned second HIP stream beside the following ResNet
  * stages (fork / join with events: the caller's stream still orders the whole call); 0 = everything on the caller's
  * stream.  Results are identical either way.
- * "chain_layer1" (default 1): hn_forward_bf16 runs layer1.1's conv3 (+ residual + ReLU) and layer1.2's conv1 as one launch
- * (the block output is not read back from HBM; bit-identical).
+ * "chain_layer1" (default 1): hn_forward_bf16 runs every layer1 block's conv3 (+ residual / downsample branch + ReLU) and the
+ * NEXT block's conv1 (layer2.0.conv1 after the last block) as one launch (the 256-channel block output is not read back
+ * from HBM; bit-identical).
+ * "fuse_stem_pool" (default 1): hn_forward_bf16 runs (x - mean) / std, the 7x7/2 stem conv + BN + ReLU and the 3x3/2 max-pool
+ * as ONE kernel (stem_pool_bf16.hip; bit-identical to the three-kernel form, which hn_set_forward_tap calls still use).
  * "lstm_wide_rows" (16 | 8, default 16) / "lstm_wide_xcds" (1 | 2, default 2): geometry of the wide recurrence kernel of
  * hn_forward_bf16_submit (speed only).
  * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores
