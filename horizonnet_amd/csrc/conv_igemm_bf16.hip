@@ -1444,6 +1444,26 @@ __global__ __launch_bounds__(256) void pack_stem_bf16_kernel(const float* __rest
     }
 }
 
+// OIHW f32 -> [Cin][Cout / 64][KH][KW][64] bf16 with flipped taps: the weights of a stride-1 conv's data gradient written as a
+// forward conv (channel roles swapped) in the forward kernels' K order (see hn_launch_conv_dgrad_bf16)
+__global__ __launch_bounds__(256) void pack_dgrad_fwd_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout, int Cin,
+                                                                  int KH, int KW)
+{
+    const long total = (long)Cin * KH * KW * Cout;
+    const int ntap = KH * KW, nch = Cout / BKE;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % BKE);
+        long t = i / BKE;
+        const int tap = (int)(t % ntap);
+        t /= ntap;
+        const int cc = (int)(t % nch);
+        const int c = (int)(t / nch);
+        const int dh = tap / KW, dw = tap - dh * KW;
+        const float v = w[(((long)(cc * BKE + e) * Cin + c) * KH + (KH - 1 - dh)) * KW + (KW - 1 - dw)];
+        out[i] = (u16)(pack_bf16(v, 0.f) & 0xffffu);
+    }
+}
+
 // OIHW f32 -> per-class data-gradient packing [Cin][ndh][ndw][Cout] in bf16 (only the taps that reach the class)
 __global__ __launch_bounds__(256) void pack_dgrad_class_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int Cout, int Cin,
                                                                     int KH, int KW, int dh0, int dh1, int dh2, int ndh, int dw0, int dw1,
@@ -1577,6 +1597,8 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
 // w_scratch already holds the class packings (the training step: packed once per optimiser step by hn_pack_weights_bf16);
 // add (optional) and dx are float32, or -- grad_bf16 -- both bf16 (train.hip keeps the gradients between conv units in bf16).
 // Needs Cout %% 64 == 0 (one K chunk = 64 bf16 channels of one tap).
+int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s);
+
 int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
                               const float* ones, const float* zeros, hipStream_t s, int grad_bf16)
 {
@@ -1585,6 +1607,26 @@ int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* 
     HN_REQUIRE(d.Cout % BKE == 0 && d.Cin % 32 == 0, "conv dgrad bf16: Cout %% 64 / Cin %% 32");
     HN_REQUIRE(d.Hi % d.sh == 0 && d.Wi % d.sw == 0, "conv dgrad bf16: input size must be a multiple of the stride");
     u16* wp = reinterpret_cast<u16*>(w_scratch);
+    if (d.sh == 1 && d.sw == 1 && grad_bf16 && d.KH == d.KW && d.ph == d.KH / 2 && d.pw == d.KW / 2) {
+        // Stride 1, bf16 gradients: dX = conv(dY, W') with W'[ci][dh][dw][co] = W[co][ci][KH-1-dh][KW-1-dw] and the same padding --
+        // a FORWARD conv with the channel roles swapped, so it gets the forward dispatcher: the 256x256 8-wave kernel
+        // (persistent where a CU has several tiles) and the taps-inner K order instead of the 128x128 data-gradient kernel
+        // (0.57 PFLOP/s on the training step's data gradients against 0.9-1.2 for the forward kernels).  The identity-branch
+        // gradient is the conv's bf16 residual; scale 1 / shift 0 leave the accumulator bits alone (fma(v, 1, 0) == v).
+        if (w_oihw != nullptr) {
+            const long total = (long)d.Cin * d.KH * d.KW * d.Cout;
+            hipLaunchKernelGGL(pack_dgrad_fwd_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, s, w_oihw, wp, d.Cout, d.Cin, d.KH, d.KW);
+            HN_LAUNCH_CHECK();
+        }
+        ConvDesc f;
+        memset(&f, 0, sizeof(f));
+        f.x = reinterpret_cast<const float*>(dz_h); f.w = reinterpret_cast<const float*>(wp); f.scale = ones; f.shift = zeros;
+        f.res = add; f.y = dx;
+        f.B = d.B; f.Hi = d.Ho; f.Wi = d.Wo; f.Cin = d.Cout; f.Ho = d.Hi; f.Wo = d.Wi; f.Cout = d.Cin;
+        f.KH = d.KH; f.KW = d.KW; f.sh = 1; f.sw = 1; f.ph = d.ph; f.pw = d.pw;
+        f.relu = 0; f.ldy = d.Cin;
+        return hn_launch_conv_bf16(f, 0, s);
+    }
     for (int ca = 0; ca < d.sh; ++ca) {
         for (int cb = 0; cb < d.sw; ++cb) {
             ConvArgsH a;

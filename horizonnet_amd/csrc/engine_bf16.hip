@@ -142,6 +142,12 @@ extern "C" int hn_pack_weights_bf16(hn_engine* e, void* packed_h, size_t bytes, 
         hn_conv_strides((int)i, &sh, &sw);
         u16* wp = H + h.dgrad[i];
         const int ph = c.k / 2, pw = c.k / 2;
+        if (sh == 1 && sw == 1) {       // stride 1: the data gradient runs as a forward conv with flipped taps (hn_launch_conv_dgrad_bf16)
+            MJob j = mj_make(MJ_PACK_DGRAD_FWD_BF16, w, wp, (long long)c.cin * c.k * c.k * c.cout);
+            j.p[0] = c.cout; j.p[1] = c.cin; j.p[2] = c.k; j.p[3] = c.k;
+            jobs.push_back(j);
+            continue;
+        }
         for (int ca = 0; ca < sh; ++ca) {
             for (int cb = 0; cb < sw; ++cb) {        // same class order and tap lists as hn_launch_conv_dgrad_bf16
                 int tdh[3] = {0, 0, 0}, tdw[3] = {0, 0, 0}, ntdh = 0, ntdw = 0;

@@ -14,7 +14,7 @@
 
 enum MJKind {
     MJ_PACK_F32 = 0,        // OIHW f32 -> [Cout][KH][KWp][Cp] f32          p = {Cout, Cin, KH, KW, KWp, Cp}
-    MJ_PACK_BF16,           // OIHW f32 -> [Cout][KH][KWp][Cp] bf16         p = {Cout, Cin, KH, KW, KWp, Cp}
+    MJ_PACK_BF16,           // OIHW f32 -> [Cout][Cin / 64][KH][KW][64] bf16 (taps inside a channel chunk)   p = {Cout, Cin, KH, KW, KWp, Cp}
     MJ_PACK_STEM_BF16,      // 7x7 stem  -> [64][4 chunks][2 rows][8 taps][4 ch] bf16 (conv_igemm_bf16.hip)   p = {Cout}
     MJ_FOLD_BN,             // src = gamma (null: scale 1), aux = {beta, mean, var, bias (null: 0)} -> dst = scale, dst2 = shift
     MJ_PACK_DGRAD_BF16,     // OIHW f32 -> [Cin][ndh][ndw][Cout] bf16       p = {Cout, Cin, KH, KW, dh0, dh1, dh2, ndh, dw0, dw1, dw2, ndw}
@@ -23,6 +23,8 @@ enum MJKind {
     MJ_F32_TO_BF16,         // float -> bf16 (round to nearest even)
     MJ_COPY_F32,            // float -> float
     MJ_ADD_VEC,             // dst = src + aux[0]
+    MJ_PACK_DGRAD_FWD_BF16, // OIHW f32 -> [Cin][Cout / 64][KH][KW][64] bf16 with flipped taps: the data gradient of a stride-1 conv as a
+                            // FORWARD conv (pack_dgrad_fwd_bf16_kernel)   p = {Cout, Cin, KH, KW}
 };
 
 struct MJob {

@@ -102,6 +102,19 @@ __global__ __launch_bounds__(256) void multi_job_kernel(const MJob* __restrict__
             const int dh = ih == 0 ? dh0 : (ih == 1 ? dh1 : dh2), dw = iw == 0 ? dw0 : (iw == 1 ? dw1 : dw2);
             reinterpret_cast<u16*>(j->dst)[i] = to_bf16(src[(((long long)o * Cin + c) * KH + dh) * KW + dw]);
         }
+    } else if (kind == MJ_PACK_DGRAD_FWD_BF16) {
+        const int Cout = j->p[0], Cin = j->p[1], KH = j->p[2], KW = j->p[3];
+        const int ntap = KH * KW, nch = Cout / 64;
+        for (long long i = base + threadIdx.x; i < end; i += 256) {
+            const int e = (int)(i % 64);
+            long long t = i / 64;
+            const int tap = (int)(t % ntap);
+            t /= ntap;
+            const int cc = (int)(t % nch);
+            const int c = (int)(t / nch);
+            const int dh = tap / KW, dw = tap - dh * KW;
+            reinterpret_cast<u16*>(j->dst)[i] = to_bf16(src[(((long long)(cc * 64 + e) * Cin + c) * KH + (KH - 1 - dh)) * KW + (KW - 1 - dw)]);
+        }
     } else if (kind == MJ_UNPACK) {
         const int Cin = j->p[1], KH = j->p[2], KW = j->p[3], KHp = j->p[4], KWp = j->p[5], Cp = j->p[6];
         for (long long i = base + threadIdx.x; i < end; i += 256) {
