@@ -277,8 +277,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b_s + j * 32 * LDS_STRIDE);
         };
         auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+            // element q of a fragment is k = 8 kk + q (lanes 0..31) / 8 kk + 4 + q (lanes 32..63).  In the stem's chunk (one filter
+            // row = 8 window pixels x 4 channels) that is channel q of two window pixels: q = 3 is the padding channel, zero in
+            // the input AND the weights -- its MFMAs add exact zeros and are skipped (a quarter of the stem's matrix work)
+            constexpr int NQ = STEM ? 3 : 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
