@@ -241,7 +241,6 @@ __global__ __launch_bounds__(256) void augment_sym_kernel(const unsigned char* _
     xoa = xoa >= W ? xoa - W : xoa;
     xob = xob >= W ? xob - W : xob;
 
-    const unsigned char* img = data + (size_t)p.index[b] * H * W * 3;
     float* out = dst + (size_t)b * 3 * H * W;
     const bool gam = p.use_gamma[b] != 0;
     const double ge = (double)p.gamma[b];
