@@ -23,7 +23,8 @@
 
 namespace {
 
-constexpr int PITCH = 320;              // bytes per LDS image row (128 bf16 + pad)
+constexpr int PITCH = 320;              // bytes per LDS image row of <= 128 columns (128 bf16 + 64 pad); 256 columns: 576 (same residue 16 dwords mod 64)
+constexpr int pitch_of(int cols) { return cols <= 128 ? 320 : cols * 2 + 64; }
 constexpr unsigned OOB = 0x80000000u;
 
 typedef unsigned short u16;
@@ -47,14 +48,14 @@ __device__ __forceinline__ u32x4 hbuf_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
 }
 
 // 8 consecutive m (image rows mb .. mb+7) of column nb + (lane & 15) [+16 for the odd 16-lane group]: one MFMA operand
-__device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int lane)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int lane, int pitch = PITCH)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int r = lane & 15;
     const int g = lane >> 4;
-    const char* p = img + (mb + 8 * (g >> 1) + (r >> 2)) * PITCH + (nb + 16 * (g & 1) + 4 * (r & 3)) * 2;
+    const char* p = img + (mb + 8 * (g >> 1) + (r >> 2)) * pitch + (nb + 16 * (g & 1) + 4 * (r & 3)) * 2;
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p);
-    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * PITCH));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * pitch));
     typedef short v8s __attribute__((ext_vector_type(8)));
     const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
@@ -65,21 +66,29 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int l
 
 // WCHB: m rows per chunk (one barrier per chunk): 32 = two k16 steps (8 MFMAs per wave and barrier for the 128x128 tile, 40 KB of
 // LDS: 4 workgroups per CU), 64 = four (16 MFMAs per barrier, 80 KB: 2 workgroups per CU)
-template <int TN, int TK, int WCHB>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
+// NW = 8 (512 threads, 4 x 2 waves): the 256-wide tiles.  A 128x128 tile moves 32 KB from L2 into the CU per 64-row chunk for
+// 2.1 MFLOP = 64 flop per byte, which caps it near 0.65 PFLOP/s at the ~10 TB/s the L2 -> CU path delivers chip-wide (the 61
+// launches of the training step ran at 0.6); 256x256 doubles that (one workgroup per CU, 147 KB of LDS, 128 accumulator
+// registers per wave).
+template <int TN, int TK, int WCHB, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 {
-    static_assert(TN == 128 && TK == 128 || TN == 64 || TK == 64, "tile");
-    constexpr int WN = TN / 2, WK = TK / 2;          // wave tile (2 x 2 waves)
+    static_assert(NW == 4 || NW == 8, "waves");
+    constexpr int THREADS = NW * 64;
+    constexpr int WAVES_N = NW / 2;                  // waves along n; 2 along k'
+    constexpr int WN = TN / WAVES_N, WK = TK / 2;    // wave tile
     constexpr int TI = WN / 32, TJ = WK / 32;
+    static_assert(TI >= 1 && TJ >= 1, "wave tile");
     constexpr int N_TPR = TN / 8, K_TPR = TK / 8;    // loader threads per image row (16 bytes = 8 bf16 each)
-    constexpr int N_RPP = 256 / N_TPR, K_RPP = 256 / K_TPR;
+    constexpr int N_RPP = THREADS / N_TPR, K_RPP = THREADS / K_TPR;
     constexpr int N_PS = WCHB / N_RPP, K_PS = WCHB / K_RPP;
     static_assert(N_PS >= 1 && K_PS >= 1, "loader geometry");
-    constexpr int IMG = WCHB * PITCH;                // bytes per operand image
+    constexpr int PN = pitch_of(TN), PK = pitch_of(TK);
+    constexpr int IMG_N = WCHB * PN, IMG_K = WCHB * PK;      // bytes per operand image
 
     extern __shared__ __attribute__((aligned(16))) char hsmem[];
-    char* s_dz0 = hsmem;                             // [2][IMG]
-    char* s_a0 = hsmem + 2 * IMG;                    // [2][IMG]
+    char* s_dz0 = hsmem;                             // [2][IMG_N]
+    char* s_a0 = hsmem + 2 * IMG_N;                  // [2][IMG_K]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,10 +181,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
     auto stage = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < N_PS; ++q)
-            *reinterpret_cast<u32x4*>(s_dz0 + buf * IMG + (n_row + q * N_RPP) * PITCH + n_col * 2) = rdz[q];
+            *reinterpret_cast<u32x4*>(s_dz0 + buf * IMG_N + (n_row + q * N_RPP) * PN + n_col * 2) = rdz[q];
 #pragma unroll
         for (int q = 0; q < K_PS; ++q)
-            *reinterpret_cast<u32x4*>(s_a0 + buf * IMG + (k_row + q * K_RPP) * PITCH + k_col * 2) = ra[q];
+            *reinterpret_cast<u32x4*>(s_a0 + buf * IMG_K + (k_row + q * K_RPP) * PK + k_col * 2) = ra[q];
     };
 
     f32x16 acc[TI][TJ];
@@ -193,15 +202,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
     for (int mc = mlo; mc < mhi; mc += WCHB) {
         const bool more = mc + WCHB < mhi;
         if (more) fetch(mc + WCHB);
-        const char* dz_s = s_dz0 + buf * IMG;
-        const char* a_s = s_a0 + buf * IMG;
+        const char* dz_s = s_dz0 + buf * IMG_N;
+        const char* a_s = s_a0 + buf * IMG_K;
 #pragma unroll
         for (int s = 0; s < WCHB / 16; ++s) {
             bf16x8 fa[TI], fb[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = tr_frag(dz_s, 16 * s, wi_ * WN + i * 32, lane);
+            for (int i = 0; i < TI; ++i) fa[i] = tr_frag(dz_s, 16 * s, wi_ * WN + i * 32, lane, PN);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = tr_frag(a_s, 16 * s, wj_ * WK + j * 32, lane);
+            for (int j = 0; j < TJ; ++j) fb[j] = tr_frag(a_s, 16 * s, wj_ * WK + j * 32, lane, PK);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsH p)
             }
 }
 
-template <int TN, int TK, int WCHB>
+template <int TN, int TK, int WCHB, int NW = 4>
 int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
 {
     const int NT = a.Cout / TN, KT = a.K / TK;
@@ -237,8 +246,8 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
     mchunk = (mchunk + WCHB - 1) / WCHB * WCHB;
     split = (a.M + mchunk - 1) / mchunk;
     a.mchunk = (int)mchunk;
-    const size_t lds = 4 * (size_t)WCHB * PITCH;
-    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB>;
+    const size_t lds = 2 * (size_t)WCHB * (pitch_of(TN) + pitch_of(TK));
+    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW>;
     if (lds > 65536) {
         static bool attr_done[64] = {};   // per instantiation, per device
         int dev = 0;
@@ -248,7 +257,7 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
             attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(NT * KT * split)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(NT * KT * split)), dim3(NW * 64), lds, s, a);
     HN_LAUNCH_CHECK();
     return 0;
 }
@@ -292,6 +301,17 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     HN_REQUIRE((double)B * Hi * Wi * a.xstride * 2.0 < 2147483648.0 && (double)a.M * a.dzstride * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
+    {
+        // 8-wave 256-wide tiles where both channel counts allow them (layer3 / layer4, the deep height-compression convs): one
+        // workgroup per CU, m split into ~256 workgroups.  HN_WGRAD_W8 = 0 disables, 1 = 256x256 (default), 2 = 256x128, 3 = 128x256, 4 = 256x256 then 256x128
+        static const char* e8 = getenv("HN_WGRAD_W8");
+        const int w8 = e8 ? atoi(e8) : 1;
+        static const char* envw = getenv("HN_WGRAD_W8_WGS");
+        const long target = envw ? atol(envw) : 256;
+        if ((w8 == 1 || w8 == 4) && Cout % 256 == 0 && Cin % 256 == 0) return launch_wgrad_h_w<256, 256, 64, 8>(a, s, target);
+        if ((w8 == 2 || w8 == 4) && Cout % 256 == 0 && Cin % 128 == 0) return launch_wgrad_h_w<256, 128, 64, 8>(a, s, target);
+        if (w8 == 3 && Cout % 128 == 0 && Cin % 256 == 0) return launch_wgrad_h_w<128, 256, 64, 8>(a, s, target);
+    }
     if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad_h<128, 128>(a, s);
     if (Cout % 128 == 0) return launch_wgrad_h<128, 64>(a, s);
     if (Cin % 128 == 0) return launch_wgrad_h<64, 128>(a, s);
