@@ -68,6 +68,7 @@ SIGNATURES = {
     "hn_conv2d_dgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_conv2d_wgrad_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_conv2d_dgrad_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hn_conv2d_dgrad_nhwc_bf16g": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_conv2d_wgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_pano_stretch": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _i, _i, _i, _i, _vp]),
     "hn_pano_stretch_tables": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _vp, _vp, _i, _i, _i, _i, _i, _vp]),

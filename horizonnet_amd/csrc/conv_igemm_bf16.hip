@@ -923,11 +923,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_chain_bf16_kernel(ChainArgsH p
 // idle for the dispatch of the next workgroup (1.6-1.7 us) plus the first chunk's flight (1.2-1.9 us) -- 15-20 % of a 1x1
 // expansion's tile.  Here the next tile's first chunk is requested right after the k loop, into stage 0, and lands while the
 // epilogue runs out of a slab at the TOP of the 160 KiB (over stage 1 and the 32 KiB above it).  Same arithmetic, same bits.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false, bool PERSIST = false>
+// TR: data-gradient mode of the strided convs (one stride-parity class of dX pixels per launch, per-class tap lists and packing,
+// see the 4-wave kernel); bf16 gradients only.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false, bool PERSIST = false, bool TR = false>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
 {
     static_assert(WAVES_M * WAVES_N == 8, "8 waves per workgroup");
     static_assert(!(PERSIST && STATS), "the persistent form is an inference kernel");
+    static_assert(!(TR && (OUT_F32 || STATS)), "data-gradient mode: bf16 gradients, no statistics");
     constexpr int NW = 8;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     const int lcol = lslot ^ ((lrow >> 1) & 7);
 
     const int NT = p.Cout / BN;
-    const int hw_out = p.Ho * p.Wo;
+    const int hw_out = TR ? p.cHo * p.cWo : p.Ho * p.Wo;
     const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
     const int total = PERSIST ? ((p.M + BM - 1) / BM) * NT : (int)gridDim.x;
 
@@ -970,11 +973,23 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     auto tap_offsets = [&](int th, int tw) {
 #pragma unroll
         for (int q = 0; q < AP; ++q) {
-            const int hi = a_hi0[q] + th;
-            int wi = a_wi0[q] + tw;
-            wi = wi < 0 ? wi + p.Wi : wi;
-            wi = wi >= p.Wi ? wi - p.Wi : wi;
-            const bool ok = a_pix0[q] >= 0 && ((unsigned)hi < (unsigned)p.Hi);
+            int hi, wi;
+            bool ok = a_pix0[q] >= 0;
+            if (TR) {                                            // th / tw index the class's tap lists
+                const int t_h = a_hi0[q] - p.tdh[th];
+                int t_w = a_wi0[q] - p.tdw[tw];
+                t_w = t_w < 0 ? t_w + p.Wo : t_w;                 // circular on the dX grid (width Wo)
+                t_w = t_w >= p.Wo ? t_w - p.Wo : t_w;
+                hi = t_h >> p.sh_log2;
+                wi = t_w >> p.sw_log2;
+                ok = ok && t_h >= 0 && hi < p.Hi;
+            } else {
+                hi = a_hi0[q] + th;
+                wi = a_wi0[q] + tw;
+                wi = wi < 0 ? wi + p.Wi : wi;
+                wi = wi >= p.Wi ? wi - p.Wi : wi;
+                ok = ok && ((unsigned)hi < (unsigned)p.Hi);
+            }
             const unsigned pix = (unsigned)(a_pix0[q] + hi * p.Wi + wi);
             a_off[q] = ok ? (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u : OOB;
         }
@@ -997,13 +1012,14 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
         for (int q = 0; q < AP; ++q) {
             const int m = m0 + lrow + 64 * q;
             if (m < p.M) {
-                const int wo = m % p.Wo;
-                const int t = m / p.Wo;
-                const int ho = t % p.Ho;
-                const int b = t / p.Ho;
+                const int gw = TR ? p.cWo : p.Wo, gh = TR ? p.cHo : p.Ho;
+                const int wo = m % gw;
+                const int t = m / gw;
+                const int ho = t % gh;
+                const int b = t / gh;
                 a_pix0[q] = (b - b_first) * p.Hi * p.Wi;
-                a_hi0[q] = ho * p.sh - p.ph;
-                a_wi0[q] = wo * p.sw - p.pw;
+                a_hi0[q] = TR ? p.ca + p.sh * ho + p.ph : ho * p.sh - p.ph;
+                a_wi0[q] = TR ? p.cb + p.sw * wo + p.pw : wo * p.sw - p.pw;
             } else {
                 a_pix0[q] = -1;
                 a_hi0[q] = 0;
@@ -1013,6 +1029,15 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
         dh = 0; dw = 0; c0 = 0;
         tap_offsets(0, 0);
     };
+    // output pixel of GEMM row m: dense, except in data-gradient mode where the rows enumerate one parity class
+    auto out_pix = [&](int m) -> size_t {
+        if (!TR) return (size_t)m;
+        const int wo = m % p.cWo;
+        const int t = m / p.cWo;
+        const int ho = t % p.cHo;
+        const int b = t / p.cHo;
+        return ((size_t)b * p.Ho + (p.ca + p.sh * ho)) * p.Wo + (p.cb + p.sw * wo);
+    };
 
     auto fetch = [&](int kc) {       // chunk kc -> LDS stage (kc & 1)
         char* a_s = smem + (kc & 1) * STAGE_BYTES;
@@ -1021,11 +1046,20 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
         for (int q = 0; q < AP; ++q) dma16(rsrc_a, a_s + (q * NW + wave) * 1024, a_off[q], (unsigned)c0 * 2u);
 #pragma unroll
         for (int q = 0; q < BP; ++q) dma16(rsrc_w, b_s + (q * NW + wave) * 1024, w_off[q], (unsigned)kc * (unsigned)ROWB);
-        if (++dw == p.KW) {              // taps inner, 64-channel chunks outer (see the 4-wave kernel's fetch)
-            dw = 0;
-            if (++dh == p.KH) { dh = 0; c0 += BKE; }
+        if (TR) {                        // data gradient: taps outer, channels inner (its own per-class packing)
+            c0 += BKE;
+            if (c0 == p.Cin) {
+                c0 = 0;
+                if (++dw == p.ntdw) { dw = 0; ++dh; }
+                if (dh < p.ntdh) tap_offsets(dh, dw);
+            }
+        } else {
+            if (++dw == p.KW) {          // taps inner, 64-channel chunks outer (see the 4-wave kernel's fetch)
+                dw = 0;
+                if (++dh == p.KH) { dh = 0; c0 += BKE; }
+            }
+            if (p.KH * p.KW > 1) tap_offsets(dh, dw);
         }
-        if (p.KH * p.KW > 1) tap_offsets(dh, dw);
     };
 
     const int fr = lane & 31;
@@ -1131,7 +1165,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
                     const int sr = crow + ps * RPP;             // 0 .. WAVES_M*32-1: slab sr / 32, row sr % 32
                     const int m = em0 + (sr >> 5) * WM + i * 32 + (sr & 31);
                     const int mc = m < p.M ? m : p.M - 1;
-                    rres[ps] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + en0 + ccol);
+                    rres[ps] = *reinterpret_cast<const u32x4*>(p.res + out_pix(mc) * p.Cout + en0 + ccol);
                 }
             }
             if (i > 0) __syncthreads();
@@ -1167,14 +1201,14 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
                         st2a += v0 * v0; st2b += v1 * v1;
                     }
                     if (OUT_F32) {
-                        float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + en0 + ccol;
+                        float* yo = reinterpret_cast<float*>(p.y) + out_pix(m) * p.ldy + en0 + ccol;
                         *reinterpret_cast<f32x4*>(yo) = v0;
                         *reinterpret_cast<f32x4*>(yo + 4) = v1;
                     } else {
                         u32x4 o;
                         o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                         o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + en0 + ccol) = o;
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + out_pix(m) * p.ldy + en0 + ccol) = o;
                     }
                 }
             }
@@ -1204,11 +1238,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false, bool PERSIST = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_F32, bool STATS = false, bool PERSIST = false, bool TR = false>
 int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
 {
     const size_t lds = PERSIST ? (size_t)160 * 1024 : 2 * (size_t)(BM + BN) * ROWB;
-    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32, STATS, PERSIST>;
+    auto kern = conv_igemm_bf16_w8_kernel<BM, BN, WAVES_M, WAVES_N, OUT_F32, STATS, PERSIST, TR>;
     static bool attr_done[64] = {};   // per instantiation, per device
     static int n_cu[64] = {};
     int dev = 0;
@@ -1300,6 +1334,16 @@ template <bool OUT_F32, bool TR = false>
 int dispatch(const ConvArgsH& a, int Cout, hipStream_t s)
 {
     const long M = a.M;
+    if constexpr (TR && !OUT_F32) {
+        // data gradient of a strided conv with bf16 gradients: the 256x256 8-wave kernel under the forward dispatcher's rule
+        // (the height-compression convs' data gradients are 0.3-0.6 TFLOP each); HN_DGRAD_W8=0 for A/B runs
+        const char* de = getenv("HN_DGRAD_W8");                 // read per call: the stage test flips it between launches
+        const long t256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
+        if (!(de && atoi(de) == 0) && a.nk > 0 && t256 >= 224) {
+            if (t256 > 256) return launch_cfg_w8<256, 256, 2, 4, false, false, true, true>(a, s);
+            return launch_cfg_w8<256, 256, 2, 4, false, false, false, true>(a, s);
+        }
+    }
     if (Cout % 128 == 0) {
         const long blocks128 = (long)hn_cdiv(M, 128) * (Cout / 128);
         if (blocks128 >= 512) return launch_cfg_h<128, 128, 2, 2, false, OUT_F32, TR>(a, s);
@@ -1653,7 +1697,7 @@ int hn_launch_conv_dgrad_bf16(const ConvDesc& d, const void* dz_h, const float* 
             }
             a.w = wp;
             {
-                const double span = 128.0 / ((double)a.cHo * a.cWo) + 2.0;
+                const double span = 256.0 / ((double)a.cHo * a.cWo) + 2.0;
                 HN_REQUIRE(span * a.Hi * a.Wi * (double)a.xstride * 2.0 < 2147483648.0, "conv dgrad bf16: image too large for 32-bit tile offsets");
                 HN_REQUIRE(128.0 * a.K * 2.0 < 2147483648.0, "conv dgrad bf16: K too large");
             }

@@ -753,6 +753,38 @@ extern "C" int hn_conv2d_dgrad_nhwc_bf16(const float* dz, const float* w_oihw, c
     return hn_launch_conv_dgrad_bf16(d, dz_h, w_oihw, add, dx, w_scratch, ones, zeros, s);
 }
 
+// The form the bf16 training step actually runs: dz, the identity-branch gradient AND dx are bf16 tensors (train.hip keeps the
+// gradients between conv units in bf16) -- stride-1 convs through the forward kernels with flipped taps, strided ones through the
+// per-class data-gradient kernels (128x128, or the 256x256 8-wave kernel when the class has >= 224 tiles).  Host-facing buffers
+// stay float32: dz / add are rounded to bf16 into the scratch, dx comes back converted.
+// w_scratch: Cout*Cin*KH*KW + 8192 floats, then B*Ho*Wo*Cout/2 + 64 floats (dz), then 2 * (B*Hx*Wx*Cin/2 + 64) floats (add, dx).
+extern "C" int hn_conv2d_dgrad_nhwc_bf16g(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
+                                          int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream)
+{
+    HN_REQUIRE(dz && w_oihw && dx && w_scratch, "hn_conv2d_dgrad_nhwc_bf16g: null pointer");
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_dgrad_nhwc_bf16g: kernel %dx%d unsupported", KH, KW);
+    HN_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 4096 && Cout <= 4096, "hn_conv2d_dgrad_nhwc_bf16g: Cin %% 32, Cout %% 64, <= 4096");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    float* ones = w_scratch + (size_t)Cout * Cin * KH * KW;
+    float* zeros = ones + 4096;
+    if ((rc = hn_launch_fold_bn(nullptr, nullptr, nullptr, nullptr, nullptr, ones, zeros, 4096, s))) return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = B; d.Hi = Hx; d.Wi = Wx; d.Cin = Cin; d.Cout = Cout; d.KH = KH; d.KW = KW; d.sh = sh; d.sw = sw; d.ph = KH / 2; d.pw = KW / 2;
+    d.Ho = (Hx + 2 * d.ph - KH) / sh + 1;
+    d.Wo = (Wx + 2 * d.pw - KW) / sw + 1;
+    const long nz = (long)B * d.Ho * d.Wo * Cout, nx = (long)B * Hx * Wx * Cin;
+    HN_REQUIRE(nz % 8 == 0 && nx % 8 == 0, "hn_conv2d_dgrad_nhwc_bf16g: tensor sizes must be multiples of 8");
+    float* dz_h = zeros + 4096;
+    float* add_h = dz_h + nz / 2 + 64;
+    float* dx_h = add_h + nx / 2 + 64;
+    if ((rc = hn_launch_f32_to_bf16(dz, dz_h, nz, s))) return rc;
+    if (add && (rc = hn_launch_f32_to_bf16(add, add_h, nx, s))) return rc;
+    if ((rc = hn_launch_conv_dgrad_bf16(d, dz_h, w_oihw, add ? add_h : nullptr, dx_h, w_scratch, ones, zeros, s, /*grad_bf16=*/1))) return rc;
+    return hn_launch_bf16_to_f32(dx_h, dx, nx, s);
+}
+
 // bf16-MFMA form of the weight gradient: x and dz are rounded to bf16 into the scratch, accumulation and dw stay float32.
 // scratch: Cout*KH*KW*Cin floats (packed dw) followed by (B*Hi*Wi*Cin + B*Ho*Wo*Cout) / 2 floats.
 extern "C" int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,

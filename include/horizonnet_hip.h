@@ -387,6 +387,13 @@ int hn_conv2d_dgrad_nhwc(const float* dz, const float* w_oihw, const float* add,
 int hn_conv2d_dgrad_nhwc_bf16(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
                               int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
 
+/* The data gradient as the bf16 training step runs it: dz, add and dx are bf16 tensors inside (rounded from / converted to the
+ * float32 host-facing buffers here); stride-1 convs go through the forward kernels with flipped taps, strided ones through the
+ * per-class data-gradient kernels (environment HN_DGRAD_W8=0: 128x128 tiles only).  w_scratch: Cout*Cin*KH*KW + 8192 floats,
+ * then B*Ho*Wo*Cout/2 + 64, then 2 * (B*Hx*Wx*Cin/2 + 64) floats. */
+int hn_conv2d_dgrad_nhwc_bf16g(const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch, int B,
+                               int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
+
 /* The weight gradient on the bf16 matrix cores: x and dz are rounded to bf16, products exact, accumulation and dw float32.
  * Cin %% 64 == 0, Cout %% 64 == 0.  scratch: Cout*KH*KW*Cin floats followed by (B*Hi*Wi*Cin + B*Ho*Wo*Cout) / 2 + 128 floats. */
 int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,

@@ -600,3 +600,52 @@ def test_two_rank_data_parallel_gradients(tmp_path):
     print("[parity] deferred mean (sum left for FusedAdam):", sums, " bf16 wire:", halves)
     assert max(sums) < 1e-5
     assert all(h < 0 or 1e-5 < h < 1e-2 for h in halves)          # bf16 rounding of the summed ranges: ~2^-9 relative; -1 = backend lacks bf16
+
+
+def _dgrad_bf16g(dz, w, add, B, H, W, cin, cout, k, sh, sw):
+    dx = torch.full((B, H, W, cin), float("nan"), device=DEV)
+    scr = torch.empty(cout * cin * k * k + 8192 + dz.numel() // 2 + 64 + 2 * (B * H * W * cin // 2 + 64), device=DEV)
+    _lib.check(lib().hn_conv2d_dgrad_nhwc_bf16g(P(dz), P(w), P(add), P(dx), P(scr), B, H, W, cin, cout, k, k, sh, sw, sp()), "dgrad bf16g")
+    torch.cuda.synchronize()
+    return dx
+
+
+@pytest.mark.parametrize("case", [c for c in GRAD_CASES if c[5] % 64 == 0], ids=[c[0] for c in GRAD_CASES if c[5] % 64 == 0])
+def test_conv_dgrad_bf16_gradients_stage(case):
+    """The data gradient in the form the bf16 training step runs (bf16 dz / identity gradient / dx; stride 1 = a forward conv with
+    flipped taps, strided = per-class kernels) == torch autograd on the bf16-rounded operands, up to the bf16 rounding of the
+    identity input and of the result."""
+    name, B, H, W, cin, cout, k, stride = case
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    r16 = lambda t: t.bfloat16().float()                                                    # noqa: E731
+    x = _rand((B, H, W, cin), 1).requires_grad_(True)
+    w = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    w16 = r16(w).requires_grad_(True)
+    y = _conv_ref(x, w16, (sh, sw))
+    dz = _rand(tuple(y.shape), 3)
+    add = _rand((B, H, W, cin), 4)
+    y.backward(r16(dz))
+    dx = _dgrad_bf16g(dz.contiguous().to(DEV), w.to(DEV), add.to(DEV), B, H, W, cin, cout, k, sh, sw)
+    want = x.grad + r16(add)
+    assert report("dgrad bf16 gradients " + name, dx.cpu().numpy(), want.numpy(), 2.0 ** -8 * max(1.0, float(want.abs().max())))
+
+
+def test_strided_dgrad_bf16_8wave_equals_4wave():
+    """Data gradient of a strided conv on the 256x256 8-wave kernel (plain at 256 tiles, persistent above) against the 128x128
+    data-gradient kernel: same per-class packing and k order -> bit-identical; the 128x128 form is checked against autograd in
+    test_conv_dgrad_bf16_gradients_stage."""
+    import os
+    gen = torch.Generator().manual_seed(91)
+    for (B, H, W, cin, cout, sh, sw) in ((4, 128, 256, 256, 128, 2, 1), (6, 128, 256, 256, 128, 2, 1), (8, 128, 256, 256, 64, 2, 2)):
+        k = 3
+        Ho, Wo = H // sh, W // sw
+        dz = (torch.rand(B, Ho, Wo, cout, generator=gen) - 0.5).to(DEV)
+        w = ((torch.rand(cout, cin, k, k, generator=gen) - 0.5) / np.sqrt(cin * k * k)).to(DEV)
+        add = (torch.rand(B, H, W, cin, generator=gen) - 0.5).to(DEV)
+        out = {}
+        for mode in ("0", "1"):
+            os.environ["HN_DGRAD_W8"] = mode
+            out[mode] = _dgrad_bf16g(dz, w, add, B, H, W, cin, cout, k, sh, sw)
+        os.environ.pop("HN_DGRAD_W8", None)
+        assert torch.isfinite(out["1"]).all()
+        assert torch.equal(out["0"], out["1"]), "B=%d: 8-wave data gradient differs, max %g" % (B, float((out["0"] - out["1"]).abs().max()))
