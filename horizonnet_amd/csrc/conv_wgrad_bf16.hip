@@ -70,10 +70,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int l
 // 2.1 MFLOP = 64 flop per byte, which caps it near 0.65 PFLOP/s at the ~10 TB/s the L2 -> CU path delivers chip-wide (the 61
 // launches of the training step ran at 0.6); 256x256 doubles that (one workgroup per CU, 147 KB of LDS, 128 accumulator
 // registers per wave).
-template <int TN, int TK, int WCHB, int NW = 4>
+// STEM: the 7x7 / 2 stem (TN = 64 output channels, TK = 256 = the stem's packed K: 8 filter rows x 8 window pixels x 4 channels,
+// row 7 / window pixel 0 / channel 3 are padding): the A image row of output pixel (ho, wo) is, per filter row dh, the 64
+// contiguous bytes of the NHWC4 input at row 2 ho - 3 + dh, pixels 2 wo - 4 .. 2 wo + 3 (circular) -- four 16-byte pieces; window
+// pixel t holds filter tap dw = t - 1 (the bf16 forward's stem layout), so callers un-pack from dw_packed + 4 floats.
+template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 {
     static_assert(NW == 4 || NW == 8, "waves");
+    static_assert(!STEM || (TN == 64 && TK == 256), "stem tile");
     constexpr int THREADS = NW * 64;
     constexpr int WAVES_N = NW / 2;                  // waves along n; 2 along k'
     constexpr int WN = TN / WAVES_N, WK = TK / 2;    // wave tile
@@ -153,13 +158,22 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 #pragma unroll
         for (int q = 0; q < K_PS; ++q) {
             const int m = mc + k_row + q * K_RPP;
-            const int hi = r_ho[q] * p.sh - p.ph + dh;
-            int wi = r_wo[q] * p.sw - p.pw + dw;
+            int hi, wi;
+            bool ok = m < mhi;
+            if (STEM) {                          // piece k_col / 8: filter row (piece >> 2), window pixels 2 (piece & 3), + 1
+                const int pc = k_col >> 3;
+                hi = r_ho[q] * 2 - 3 + (pc >> 2);
+                wi = r_wo[q] * 2 - 4 + 2 * (pc & 3);     // even origin: a 2-pixel piece never straddles the circular wrap
+                ok = ok && pc < 28;              // filter row 7 does not exist
+            } else {
+                hi = r_ho[q] * p.sh - p.ph + dh;
+                wi = r_wo[q] * p.sw - p.pw + dw;
+            }
             wi = wi < 0 ? wi + p.Wi : wi;
             wi = wi >= p.Wi ? wi - p.Wi : wi;
             const unsigned pix = (unsigned)(r_b[q] * hw_in + hi * p.Wi + wi);
-            const unsigned in_off = (pix * (unsigned)p.xstride + (unsigned)(c0 + k_col)) * 2u;
-            ra[q] = hbuf_load16(rsrc_x, (m < mhi && (unsigned)hi < (unsigned)p.Hi) ? in_off : OOB);
+            const unsigned in_off = STEM ? pix * 8u : (pix * (unsigned)p.xstride + (unsigned)(c0 + k_col)) * 2u;
+            ra[q] = hbuf_load16(rsrc_x, (ok && (unsigned)hi < (unsigned)p.Hi) ? in_off : OOB);
             if (wide) {
                 int wn = r_wo[q] + WCHB;
                 const bool wrap_w = wn >= p.Wo;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
             }
 }
 
-template <int TN, int TK, int WCHB, int NW = 4>
+template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false>
 int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
 {
     const int NT = a.Cout / TN, KT = a.K / TK;
@@ -247,7 +261,7 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
     split = (a.M + mchunk - 1) / mchunk;
     a.mchunk = (int)mchunk;
     const size_t lds = 2 * (size_t)WCHB * (pitch_of(TN) + pitch_of(TK));
-    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW>;
+    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW, STEM>;
     if (lds > 65536) {
         static bool attr_done[64] = {};   // per instantiation, per device
         int dev = 0;
@@ -316,4 +330,25 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     if (Cout % 128 == 0) return launch_wgrad_h<128, 64>(a, s);
     if (Cin % 128 == 0) return launch_wgrad_h<64, 128>(a, s);
     return launch_wgrad_h<64, 64>(a, s);
+}
+
+// The stem's weight gradient on the bf16 matrix cores (train_precision bf16): x4_h = the NHWC4 bf16 input the bf16 forward read
+// ([B][Hi][Wi][4]), dz_h = bf16 gradient w.r.t. the stem conv output ([B][Hi/2][Wi/2][64]), dw_packed = [64][256] floats in the
+// stem's packed K order (8 filter rows x 8 window pixels x 4 channels; tap dw sits at window pixel dw + 1: un-pack with
+// hn_launch_unpack_conv(dw_packed + 4, ..., packed_rows = 8)), zeroed here unless `prezeroed`.  The float32 form (conv_wgrad_kernel<64, 64, true>) read 2.1 GB of float32 dz + 1 GB of float32 input per
+// step at B = 64 and took 2.6 ms.
+int hn_launch_stem_wgrad_bf16(const void* x4_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, hipStream_t s, int prezeroed)
+{
+    HN_REQUIRE(Hi % 2 == 0 && Wi % 2 == 0, "stem wgrad bf16: even image sizes");
+    WgradArgsH a;
+    a.x = reinterpret_cast<const u16*>(x4_h); a.dz = reinterpret_cast<const u16*>(dz_h); a.dw = dw_packed;
+    a.Hi = Hi; a.Wi = Wi; a.Cin = 4; a.Cout = 64; a.KW = 7; a.sh = 2; a.sw = 2; a.ph = 3; a.pw = 3;
+    a.Ho = Hi / 2; a.Wo = Wi / 2;
+    a.M = B * a.Ho * a.Wo;
+    a.K = 256;
+    a.mchunk = 0;
+    a.xstride = 4; a.dzstride = 64;
+    HN_REQUIRE((double)B * Hi * Wi * 8.0 < 2147483648.0 && (double)a.M * 128.0 < 4294967296.0, "stem wgrad bf16: batch too large for 32-bit tile offsets");
+    if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)64 * 256 * sizeof(float), s));
+    return launch_wgrad_h_w<64, 256, 32, 4, true>(a, s, 512);
 }

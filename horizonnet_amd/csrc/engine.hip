@@ -791,8 +791,18 @@ extern "C" int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float*
                                          int Cout, int KH, int KW, int sh, int sw, void* stream)
 {
     HN_REQUIRE(x && dz && dw_oihw && scratch, "hn_conv2d_wgrad_nhwc_bf16: null pointer");
-    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_wgrad_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
     hipStream_t s = (hipStream_t)stream;
+    if (KH == 7) {      // the stem: x is the NHWC4 float32 input [B][Hi][Wi][4] (channel 3 = 0), Cin = 3, Cout = 64, stride 2
+        HN_REQUIRE(KW == 7 && Cin == 3 && Cout == 64 && sh == 2 && sw == 2, "hn_conv2d_wgrad_nhwc_bf16: the 7x7 form is the stem only");
+        const long nx4 = (long)B * Hi * Wi * 4, nz4 = (long)B * (Hi / 2) * (Wi / 2) * 64;
+        float* xh4 = scratch + 64 * 256;
+        float* zh4 = xh4 + nx4 / 2 + 64;
+        int rc4;
+        if ((rc4 = hn_launch_f32_to_bf16(x, xh4, nx4, s)) || (rc4 = hn_launch_f32_to_bf16(dz, zh4, nz4, s))) return rc4;
+        if ((rc4 = hn_launch_stem_wgrad_bf16(xh4, zh4, scratch, B, Hi, Wi, s, 0))) return rc4;
+        return hn_launch_unpack_conv(scratch + 4, dw_oihw, 64, 3, 7, 7, 8, s);      // tap dw sits at window pixel dw + 1
+    }
+    HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_wgrad_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
     const int Ho = (Hi + 2 * (KH / 2) - KH) / sh + 1, Wo = (Wi + 2 * (KW / 2) - KW) / sw + 1;
     const long nx = (long)B * Hi * Wi * Cin, nz = (long)B * Ho * Wo * Cout;
     float* xh = scratch + (size_t)Cout * KH * KW * Cin;

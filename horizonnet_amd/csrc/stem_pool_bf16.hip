@@ -31,7 +31,6 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int IMG_H = 512, IMG_W = 1024;
-constexpr int CONV_H = 256, CONV_W = 512;
 constexpr int POOL_H = 128, POOL_W = 256;
 constexpr int ROW_BYTES = IMG_W * 8;                 // one NHWC4 bf16 input row
 constexpr int RING_ROWS = 8;

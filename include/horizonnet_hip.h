@@ -395,7 +395,8 @@ int hn_conv2d_dgrad_nhwc_bf16g(const float* dz, const float* w_oihw, const float
                                int Hx, int Wx, int Cin, int Cout, int KH, int KW, int sh, int sw, void* stream);
 
 /* The weight gradient on the bf16 matrix cores: x and dz are rounded to bf16, products exact, accumulation and dw float32.
- * Cin %% 64 == 0, Cout %% 64 == 0.  scratch: Cout*KH*KW*Cin floats followed by (B*Hi*Wi*Cin + B*Ho*Wo*Cout) / 2 + 128 floats. */
+ * Cin %% 64 == 0, Cout %% 64 == 0.  scratch: Cout*KH*KW*Cin floats followed by (B*Hi*Wi*Cin + B*Ho*Wo*Cout) / 2 + 128 floats.
+ * KH == KW == 7: the stem (Cin 3, Cout 64, stride 2), x = the NHWC4 input [B][Hi][Wi][4]; scratch 64*256 + (B*Hi*Wi*4 + B*Hi*Wi*16) / 2 + 128. */
 int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
                               int Cout, int KH, int KW, int sh, int sw, void* stream);
 

@@ -140,6 +140,28 @@ def test_stem_wgrad_stage():
     assert report("wgrad stem 7x7", dw.cpu().numpy(), w.grad.numpy(), 2e-5 * float(w.grad.abs().max()))
 
 
+def test_stem_wgrad_bf16_stage():
+    """The stem's weight gradient on the bf16 matrix cores (train_precision bf16): bf16-rounded NHWC4 input and dz, exact products,
+    float32 accumulation == autograd on the rounded operands (only the summation order differs); two sizes so that the m split
+    and the row stepping of the loader are both exercised."""
+    r16 = lambda t: t.bfloat16().float()                                                    # noqa: E731
+    for B, H, W in ((2, 32, 64), (3, 128, 256)):
+        x = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5))
+        xn = r16(horizonnet_ref.prepare_x(x))
+        w = _rand((64, 3, 7, 7), 6, 0.1).requires_grad_(True)
+        y = F.conv2d(horizonnet_ref.lr_pad(xn, 3), w, None, stride=2, padding=(3, 0)).permute(0, 2, 3, 1)
+        dz = _rand(tuple(y.shape), 7)
+        y.backward(r16(dz))
+        x4 = torch.zeros((B, H, W, 4))
+        x4[..., :3] = xn.permute(0, 2, 3, 1)
+        dw = torch.full((64, 3, 7, 7), float("nan"), device=DEV)
+        scr = torch.empty(64 * 256 + (B * H * W * 4 + B * H * W * 16) // 2 + 256, device=DEV)
+        x4d, dzd = x4.to(DEV), dz.contiguous().to(DEV)
+        _lib.check(lib().hn_conv2d_wgrad_nhwc_bf16(P(x4d), P(dzd), P(dw), P(scr), B, H, W, 3, 64, 7, 7, 2, 2, sp()), "stem wgrad bf16")
+        torch.cuda.synchronize()
+        assert report("wgrad stem 7x7 bf16 B=%d" % B, dw.cpu().numpy(), w.grad.numpy(), 3e-5 * float(w.grad.abs().max()))
+
+
 def _oracle_grads(sd, x, wb, wc, dtype):
     ref = {k: (v.clone().to(dtype) if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}   # never alias sd
     for k, v in ref.items():
