@@ -218,6 +218,11 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     if (dy_bf16 < 0) dy_bf16 = c.gh() ? 1 : 0;
     // bf16 mode: dz is also written as bf16 (slot 0 / 1 of the staging buffers) for this unit's data-gradient GEMM
     void* dz_h = (c.e->train_bf16 && dzh_slot >= 0 && c.a.convs[u.ci].cout % 64 == 0) ? c.W + c.pl.dzh[dzh_slot] : nullptr;
+    // the stem in bf16 mode with a bf16 dy (from the max-pool adjoint): all-bf16 BatchNorm adjoint like every other unit, dz only as
+    // bf16 -- into the caller's `dz` buffer, which nothing else reads (the stem has no data gradient) -- and the weight gradient on
+    // the matrix cores (hn_launch_stem_wgrad_bf16).  The float32 form moved 2.1 GB of dy, 2.1 GB of dz and 1 GB of input per step.
+    const bool stem_bf16 = u.stem && c.e->train_bf16 && dy_bf16 == 1 && dz != nullptr;
+    if (stem_bf16) dz_h = dz;
     const ConvLayer& cl = c.a.convs[u.ci];
     const int C = cl.cout;
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + u.sb;    // zeroed once per backward pass
@@ -243,7 +248,7 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     // debug tap), it is not written at all (4 of the pass's ~16 bytes per element)
     const bool tapped = (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) ||
                         (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]);
-    const bool bf16_gemms = dz_h && !u.stem && cl.cin % 64 == 0;
+    const bool bf16_gemms = stem_bf16 || (dz_h && !u.stem && cl.cin % 64 == 0);
     // ... and the conv bias gradient (height-compression convs) is summed inside the all-bf16 apply kernel
     const bool fused_db = cl.has_bias && bf16_gemms && dy_bf16 && !tapped && C % 8 == 0;
     const bool f32_dz_needed = !bf16_gemms || (cl.has_bias && !fused_db) || tapped;
@@ -275,6 +280,15 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     // the segment's batched un-pack
     float* scratch = c.jobs ? c.W + u.wg : c.W + c.pl.wsA;
     const int prezeroed = c.jobs ? 1 : 0;
+    if (stem_bf16 && !tapped) {
+        if ((rc = hn_launch_stem_wgrad_bf16(c.W + u.xh, dz_h, scratch, c.B, u.Hi, u.Wi, c.s, prezeroed))) return rc;
+        // tap dw sits at window pixel dw + 1 of the packed scratch (the bf16 stem layout): un-pack from 4 floats in
+        if (c.jobs) {
+            c.jobs->push_back(mj_unpack(scratch + 4, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, 8));
+            return 0;
+        }
+        return hn_launch_unpack_conv(scratch + 4, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, 8, c.s);
+    }
     if (dz_h && !u.stem && cl.cin % 64 == 0) {     // bf16 mode: both operands exist as bf16 copies (input: u.xh, dz: staging slot)
         if ((rc = hn_launch_conv_wgrad_bf16(c.W + u.xh, dz_h, scratch, c.B, u.Hi, u.Wi, cl.cin, cl.cout, cl.k, cl.k, u.sh, u.sw, c.s, prezeroed)))
             return rc;
@@ -709,8 +723,12 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     // ---- max-pool + stem ----
     {
         const Unit& u = pl.units[0];
-        if (LIVE && (rc = hn_launch_maxpool_bwd_idx(W + pl.pidx, Ga, Gb, B, 256, 512, 64, c.gh(), s))) return rc;     // d(stem y) -> Gb (float32)
-        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/0))) return rc;
+        // bf16 mode: d(stem y) leaves the max-pool adjoint as bf16 and the stem's adjoint runs all-bf16 (unit_backward: stem_bf16);
+        // with a debug tap on the stem (parity tests read float32 dy / dz) the float32 form is kept
+        const bool stem_tapped = (e->debug_unit >= 0 && &u == &pl.units[e->debug_unit]) || (e->debug_unit2 >= 0 && &u == &pl.units[e->debug_unit2]);
+        const int stem_h = (e->train_bf16 && c.gh() && !stem_tapped) ? 1 : 0;
+        if (LIVE && (rc = hn_launch_maxpool_bwd_idx(W + pl.pidx, Ga, Gb, B, 256, 512, 64, c.gh(), s, stem_h))) return rc;     // d(stem y) -> Gb
+        if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/stem_h))) return rc;
     }
     if ((rc = flush(seg))) return rc;
 #undef LIVE

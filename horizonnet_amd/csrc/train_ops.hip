@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned* __restrict__ idx, const float* __restrict__ dout,
                                                               float* __restrict__ din, int Hi, int Wi, int Ho, int Wo, int C4, long total,
-                                                              int dout_bf16)
+                                                              int dout_bf16, int din_bf16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -536,7 +536,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned* __
                     if (((a >> (8 * k)) & 255u) == me) g[k] += d[k];
             }
         }
-        *reinterpret_cast<f32x4*>(din + i * 4) = g;
+        if (din_bf16) {          // the bf16 training step: the stem's BatchNorm adjoint reads bf16 like every other unit's
+            unsigned lo, hi;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(g[0]), "v"(g[1]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(g[2]), "v"(g[3]));
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(din) + i * 4) = make_uint2(lo, hi);
+        } else {
+            *reinterpret_cast<f32x4*>(din + i * 4) = g;
+        }
     }
 }
 
@@ -956,12 +963,13 @@ int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi,
     return 0;
 }
 
-int hn_launch_maxpool_bwd_idx(const void* idx, const float* dout, float* din, int B, int Hi, int Wi, int C, int dout_bf16, hipStream_t s)
+int hn_launch_maxpool_bwd_idx(const void* idx, const float* dout, float* din, int B, int Hi, int Wi, int C, int dout_bf16, hipStream_t s,
+                              int din_bf16)
 {
     HN_REQUIRE(C % 4 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "maxpool_bwd_idx: C %% 4, even sizes");
     const long total = (long)B * Hi * Wi * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, reinterpret_cast<const unsigned*>(idx), dout,
-                       din, Hi, Wi, Hi / 2, Wi / 2, C / 4, total, dout_bf16);
+                       din, Hi, Wi, Hi / 2, Wi / 2, C / 4, total, dout_bf16, din_bf16);
     HN_LAUNCH_CHECK();
     return 0;
 }
