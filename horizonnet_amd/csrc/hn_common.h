@@ -118,7 +118,8 @@ int hn_launch_d2f(const double* in, float* out, int n, hipStream_t s);
 int hn_launch_axpy(const float* x, float* y, long n, hipStream_t s);
 int hn_launch_axpy_bf16(const void* x, void* y, long n, hipStream_t s);
 int hn_launch_bf16_to_f32(const void* in, float* out, long n, hipStream_t s);
-int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi, int Wi, int C, hipStream_t s);
+int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi, int Wi, int C, hipStream_t s, int in_bf16 = 0,
+                          void* out_h = nullptr);
 int hn_launch_maxpool_bwd_idx(const void* idx, const float* dout, float* din, int B, int Hi, int Wi, int C, int dout_bf16, hipStream_t s,
                               int din_bf16 = 0);
 int hn_launch_upsample_flatten_bwd(const float* dseq, float* din, int B, int hq, int Wq, int cq, int col0, int out_bf16, hipStream_t s);

@@ -195,7 +195,7 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
     float* st = c.W + u.st;
     int rc;
     // bf16 mode: the float32 y is written only where a float32 consumer exists (u.keep_y32): 4 of the pass's bytes per element
-    float* y32 = (c.e->train_bf16 && !u.keep_y32) ? nullptr : c.W + u.y;
+    float* y32 = (c.e->train_bf16 && (!u.keep_y32 || u.stem)) ? nullptr : c.W + u.y;      // (the stem's max-pool reads the bf16 copy)
     void* yh = c.e->train_bf16 ? c.W + u.yh : nullptr;
     unsigned char* mk = reinterpret_cast<unsigned char*>(c.W + u.mk);
     if (!c.bn_eval(u))        // statistics -> affine (+ running-stat update) inside the element pass's launch
@@ -465,8 +465,11 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
         const Unit& u = pl.units[0];
         if ((rc = conv_z(c, u))) return rc;
         if ((rc = bn_forward(c, u, nullptr, 1, bn_momentum))) return rc;
-        if ((rc = hn_launch_maxpool_idx(W + u.y, W + pl.pool, W + pl.pidx, B, 256, 512, 64, s))) return rc;
-        if (e->train_bf16 && (rc = hn_launch_f32_to_bf16(W + pl.pool, W + pl.poolh, (long)B * 128 * 256 * 64, s))) return rc;
+        if (e->train_bf16) {
+            // the stem's activation exists as bf16 only (bn_forward: no float32 y for the stem in bf16 mode) and is pooled as bf16
+            // straight into the bf16 block input of layer1: 2.1 GB of float32 y written + read and a conversion pass less per step
+            if ((rc = hn_launch_maxpool_idx(W + u.yh, nullptr, W + pl.pidx, B, 256, 512, 64, s, /*in_bf16=*/1, W + pl.poolh))) return rc;
+        } else if ((rc = hn_launch_maxpool_idx(W + u.y, W + pl.pool, W + pl.pidx, B, 256, 512, 64, s))) return rc;
     }
     // backbone + height compression
     for (int li = 0; li < 4; ++li) {

@@ -480,8 +480,11 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const unsigned short* 
 // pass also records WHICH of the 9 window positions won (first maximum in row-major window order, as torch: one byte per
 // output), so the adjoint is ONE deterministic gather pass with 16-byte stores: per input pixel, the <= 4 windows that contain
 // it.  (It used to be an arg-max pass over the 1 GB float32 stem output plus a scalar gather: 0.70 + 1.41 ms of a 60 ms step.)
+// in_bf16: `in` is a bf16 tensor; out_h (optional): the pooled tensor as bf16 (out may then be null) -- the bf16 training step
+// pools the stem's bf16 activation directly (same pooled values as rounding the float32 maximum: rounding is monotonic)
 __global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                              unsigned* __restrict__ idx, int Hi, int Wi, int Ho, int Wo, int C4, long total)
+                                                              unsigned* __restrict__ idx, int Hi, int Wi, int Ho, int Wo, int C4, long total,
+                                                              int in_bf16, unsigned short* __restrict__ out_h)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -500,13 +503,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const float* __res
             for (int dw = 0; dw < 3; ++dw) {
                 const int wi = wo * 2 - 1 + dw;
                 if ((unsigned)wi >= (unsigned)Wi) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((b * Hi + hi) * Wi + wi) * (long)C4 + c4) * 4);
+                const f32x4 v = load_z4(in, (((b * Hi + hi) * Wi + wi) * (long)C4 + c4) * 4, in_bf16);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (v[k] > m[k]) { m[k] = v[k]; pos[k] = (unsigned)(dh * 3 + dw); }
             }
         }
-        *reinterpret_cast<f32x4*>(out + i * 4) = m;
+        if (out) *reinterpret_cast<f32x4*>(out + i * 4) = m;
+        if (out_h) {
+            unsigned lo, hi;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(m[0]), "v"(m[1]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(m[2]), "v"(m[3]));
+            *reinterpret_cast<uint2*>(out_h + i * 4) = make_uint2(lo, hi);
+        }
         idx[i] = pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24);
     }
 }
@@ -953,12 +962,13 @@ int hn_launch_bf16_to_f32(const void* in, float* out, long n, hipStream_t s)
     return 0;
 }
 
-int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi, int Wi, int C, hipStream_t s)
+int hn_launch_maxpool_idx(const float* in, float* out, void* idx, int B, int Hi, int Wi, int C, hipStream_t s, int in_bf16, void* out_h)
 {
     HN_REQUIRE(C % 4 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "maxpool_idx: C %% 4, even sizes");
+    HN_REQUIRE(out || out_h, "maxpool_idx: no output");
     const long total = (long)B * (Hi / 2) * (Wi / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_idx_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 0, s, in, out, reinterpret_cast<unsigned*>(idx), Hi,
-                       Wi, Hi / 2, Wi / 2, C / 4, total);
+                       Wi, Hi / 2, Wi / 2, C / 4, total, in_bf16, reinterpret_cast<unsigned short*>(out_h));
     HN_LAUNCH_CHECK();
     return 0;
 }
