@@ -710,17 +710,15 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             if (j == 0) {
                 const Unit& ud = pl.units[pl.dsu[li]];
                 if (LIVE && (rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr, 1))) return rc;   // dz_ds -> Ga (bf16 slot 1: slot 0 still holds dz1)
-                if (LIVE && (rc = unit_dgrad(c, ud, Ga, nullptr, Gb, 1))) return rc;             // ds path -> Gb
+                // (+ the height-compression branch's gradient of this block input, C_{li-1}: it rides as the data gradient's
+                //  identity input instead of a separate read-modify-write pass over the largest gradient tensors)
+                const float* dc_add = li > 0 ? W + pl.DC[li - 1] : nullptr;
+                if (LIVE && (rc = unit_dgrad(c, ud, Ga, dc_add, Gb, 1))) return rc;              // ds path (+ d(C_{li-1})) -> Gb
                 if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gb, Gc))) return rc;                    // + conv1 path -> Gc
                 float* t = Ga; Ga = Gc; Gc = t;
             } else {
                 if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gc, Ga))) return rc;                    // conv1 path + identity -> Ga
             }
-        }
-        if (li > 0) {   // the block input of layer li is C_{li-1}: add the height-compression branch's gradient
-            if (LIVE && (rc = c.gh() ? hn_launch_axpy_bf16(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s)
-                                     : hn_launch_axpy(W + pl.DC[li - 1], Ga, (long)csz[li - 1], s)))
-                return rc;
         }
     }
     // ---- max-pool + stem ----
