@@ -198,6 +198,7 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
     const u16* H = reinterpret_cast<const u16*>(e->packed_h);
     int rc;
 
+    bool stem_c1 = false;            // layer1.0.conv1 already computed by the fused stem kernel
     {   // stem: normalise -> NHWC4 bf16, 7x7/2 conv + BN + ReLU, max-pool
         const ConvLayer& c = a.convs[a.stem];
         ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
@@ -212,7 +213,13 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
         if (fused) {
             // normalise + conv + BN + ReLU + max-pool in one kernel (stem_pool_bf16.hip): neither the NHWC4 copy of the input nor
             // the 537 MB stem activation exists
-            if ((rc = hn_launch_stem_pool_bf16(x, C_in, H + h.conv[a.stem], d.scale, d.shift, W + pl.pool, B, s))) return rc;
+            // ... and layer1.0.conv1 (1x1, 64 -> 64) on every pooled half row while it is still in LDS ("fuse_stem_conv1")
+            stem_c1 = e->fuse_stem_conv1 && !e->profiling;
+            const int ic1 = a.block_first[0][0];
+            const ConvLayer& c1 = a.convs[ic1];
+            if ((rc = hn_launch_stem_pool_bf16(x, C_in, H + h.conv[a.stem], d.scale, d.shift, W + pl.pool, B, s,
+                                               stem_c1 ? H + h.conv[ic1] : nullptr, P + c1.scale_off, P + c1.shift_off, W + pl.t1)))
+                return rc;
         } else {
             if ((rc = hn_launch_conv_bf16(d, 0, s))) return rc;
             if ((rc = hn_launch_maxpool_bf16(W + pl.stem, W + pl.pool, B, 256, 512, 64, s))) return rc;
@@ -242,7 +249,8 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
             const bool chain_on = e->chain_layer1 && !e->profiling;
             const bool chain_out = chain_on && li == 0 && (j >= 1 || e->fuse_downsample);
             const bool chained_in = chain_on && ((li == 0 && (j == 2 || (j == 1 && e->fuse_downsample))) || (li == 1 && j == 0));
-            if (!chained_in && (rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
+            const bool c1_done = chained_in || (stem_c1 && li == 0 && j == 0);
+            if (!c1_done && (rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
             if (chain_out) {
                 const ConvLayer& c3 = a.convs[i1 + 2];

@@ -41,6 +41,13 @@ constexpr int W_OFF = RING_OFF + RING_ROWS * ROW_BYTES;            // 65536
 constexpr int SC_OFF = W_OFF + 64 * W_STRIDE;                      // + 29696
 constexpr int H_OFF = SC_OFF + 512;                                // scale[64], shift[64] float32
 constexpr int LDS_BYTES = H_OFF + 257 * H_STRIDE;                  // + 37008 = 132752
+// optional tail: layer1.0.conv1 (1x1, 64 -> 64, BN, ReLU) on every pooled half row while it is still in LDS
+constexpr int W1_STRIDE = 144;                                     // 64 k x 2 B + 16
+constexpr int W1_OFF = LDS_BYTES;                                  // [64][W1_STRIDE]
+constexpr int SC1_OFF = W1_OFF + 64 * W1_STRIDE;                   // scale[64], shift[64] float32
+constexpr int P_OFF = SC1_OFF + 512;                               // pooled half row [128][H_STRIDE] bf16: the 1x1 conv's B operand
+constexpr int LDS_BYTES_C1 = P_OFF + 128 * H_STRIDE;               // 160912
+static_assert(LDS_BYTES_C1 <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 {
@@ -59,7 +66,9 @@ __device__ __forceinline__ u32x4 pk_max4(u32x4 a, u32x4 b)
 // grid = B * (128 / pseg) workgroups of 512 threads; workgroup -> image b, pooled rows [py0, py0 + pseg)
 __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __restrict__ x, int C_in, const u16* __restrict__ wpk,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             u16* __restrict__ y, int pseg)
+                                                             u16* __restrict__ y, int pseg, const u16* __restrict__ w1,
+                                                             const float* __restrict__ scale1, const float* __restrict__ shift1,
+                                                             u16* __restrict__ t1)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -81,6 +90,17 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
     if (tid < 64) {
         reinterpret_cast<float*>(smem + SC_OFF)[tid] = scale[tid];
         reinterpret_cast<float*>(smem + SC_OFF)[64 + tid] = shift[tid];
+    }
+    const bool fuse_c1 = w1 != nullptr;                     // (launch-uniform; the launch then carries LDS_BYTES_C1)
+    if (fuse_c1) {
+        {                                                   // 64 rows x 8 sixteen-byte pieces = 512 threads
+            const int o = tid >> 3, pc = tid & 7;
+            *reinterpret_cast<u32x4*>(smem + W1_OFF + o * W1_STRIDE + pc * 16) = *reinterpret_cast<const u32x4*>(w1 + o * 64 + pc * 8);
+        }
+        if (tid < 64) {
+            reinterpret_cast<float*>(smem + SC1_OFF)[tid] = scale1[tid];
+            reinterpret_cast<float*>(smem + SC1_OFF)[64 + tid] = shift1[tid];
+        }
     }
 
     // input row `row`: thread t holds pixels 2t, 2t + 1 of the three planes (load_row), later writes them normalised as NHWC4
@@ -239,9 +259,50 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
                 const u32x4 a0 = *reinterpret_cast<const u32x4*>(hp);
                 const u32x4 a1 = *reinterpret_cast<const u32x4*>(hp + H_STRIDE);
                 const u32x4 a2 = *reinterpret_cast<const u32x4*>(hp + 2 * H_STRIDE);
-                *reinterpret_cast<u32x4*>(yrow + (size_t)(128 * hf + q) * 64 + cg * 8) = pk_max4(pk_max4(a0, a1), a2);
+                const u32x4 pv = pk_max4(pk_max4(a0, a1), a2);
+                *reinterpret_cast<u32x4*>(yrow + (size_t)(128 * hf + q) * 64 + cg * 8) = pv;
+                if (fuse_c1) *reinterpret_cast<u32x4*>(smem + P_OFF + q * H_STRIDE + cg * 16) = pv;
             }
             __syncthreads();
+            if (fuse_c1) {
+                // layer1.0.conv1 on the 128 pooled pixels: wave = (32 pixels, 32 output channels), K = 64 = four MFMA steps in the
+                // separate kernel's order; weights A, pixels B, so the BN / ReLU / rounding again happen on (pixel, 32 channels)
+                // lanes; the result leaves through the (now free) pooling strip as 128-byte pixels
+                const int pt = wave & 3, ct = wave >> 2;
+                f32x16 a1;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+                const char* wp = smem + W1_OFF + (ct * 32 + fr) * W1_STRIDE + half * 16;
+                const char* xp = smem + P_OFF + (pt * 32 + fr) * H_STRIDE + half * 16;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const u32x4 wa = *reinterpret_cast<const u32x4*>(wp + kk * 32);
+                    const u32x4 xb = *reinterpret_cast<const u32x4*>(xp + kk * 32);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb), a1, 0, 0, 0);
+                }
+                char* tp = smem + H_OFF + (pt * 32 + fr) * H_STRIDE + (ct * 32) * 2 + 8 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + SC1_OFF + (32 * ct + 8 * g + 4 * half) * 4);
+                    const f32x4 sf = *reinterpret_cast<const f32x4*>(smem + SC1_OFF + 256 + (32 * ct + 8 * g + 4 * half) * 4);
+                    f32x4 v = {a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
+                    v = v * sc + sf;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                    const u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(tp + 16 * g) = o;
+                }
+                __syncthreads();
+                u16* trow = t1 + ((size_t)(b * POOL_H + py) * POOL_W) * 64;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int id = tid + 512 * it;
+                    const int q = id >> 3, cg = id & 7;
+                    *reinterpret_cast<u32x4*>(trow + (size_t)(128 * hf + q) * 64 + cg * 8) =
+                        *reinterpret_cast<const u32x4*>(smem + H_OFF + q * H_STRIDE + cg * 16);
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -249,22 +310,26 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
 }  // namespace
 
 // x: [B][C_in >= 3][512][1024] float32 (the first three planes are used), wpk: the packed stem matrix [64][256] bf16
-// (hn_launch_pack_conv_bf16, stem), scale / shift: folded BatchNorm [64], y: [B][128][256][64] bf16
-int hn_launch_stem_pool_bf16(const float* x, int C_in, const void* wpk, const float* scale, const float* shift, void* y, int B, hipStream_t s)
+// (hn_launch_pack_conv_bf16, stem), scale / shift: folded BatchNorm [64], y: [B][128][256][64] bf16.
+// w1 (optional): layer1.0.conv1's packed [64][64] bf16 weights with its folded BatchNorm -> t1 [B][128][256][64] bf16 is written too.
+int hn_launch_stem_pool_bf16(const float* x, int C_in, const void* wpk, const float* scale, const float* shift, void* y, int B, hipStream_t s,
+                             const void* w1, const float* scale1, const float* shift1, void* t1)
 {
     HN_REQUIRE(B >= 1 && C_in >= 3, "stem_pool bf16: empty batch / fewer than 3 input planes");
+    HN_REQUIRE(!w1 || (scale1 && shift1 && t1), "stem_pool bf16: the fused 1x1 conv needs its scale / shift / output");
     static bool attr_done[64] = {};
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_done[dev]) {
-        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_C1));
         attr_done[dev] = true;
     }
     // pooled rows per workgroup: as many as still give ~256 workgroups (a band recomputes one convolution row in 2 * pseg + 1)
     int pseg = 16;
     while (pseg > 1 && (long)B * (POOL_H / pseg) < 256) pseg >>= 1;
-    hipLaunchKernelGGL(stem_pool_bf16_kernel, dim3((unsigned)(B * (POOL_H / pseg))), dim3(512), LDS_BYTES, s, x, C_in,
-                       reinterpret_cast<const u16*>(wpk), scale, shift, reinterpret_cast<u16*>(y), pseg);
+    hipLaunchKernelGGL(stem_pool_bf16_kernel, dim3((unsigned)(B * (POOL_H / pseg))), dim3(512), w1 ? LDS_BYTES_C1 : LDS_BYTES, s, x, C_in,
+                       reinterpret_cast<const u16*>(wpk), scale, shift, reinterpret_cast<u16*>(y), pseg, reinterpret_cast<const u16*>(w1), scale1,
+                       shift1, reinterpret_cast<u16*>(t1));
     HN_LAUNCH_CHECK();
     return 0;
 }

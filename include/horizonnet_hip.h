@@ -104,6 +104,8 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * from HBM; bit-identical).
  * "fuse_stem_pool" (default 1): hn_forward_bf16 runs (x - mean) / std, the 7x7/2 stem conv + BN + ReLU and the 3x3/2 max-pool
  * as ONE kernel (stem_pool_bf16.hip; bit-identical to the three-kernel form, which hn_set_forward_tap calls still use).
+ * "fuse_stem_conv1" (default 1): that kernel also runs layer1.0.conv1 (1x1 + BN + ReLU) on every pooled half row while it is
+ * still in LDS (bit-identical to the separate launch).
  * "lstm_wide_rows" (16 | 8, default 16) / "lstm_wide_xcds" (1 | 2, default 2): geometry of the wide recurrence kernel of
  * hn_forward_bf16_submit (speed only).
  * "bf16_lstm" (default 1): hn_forward_bf16 runs the LSTM recurrence with bf16 W_hh / bf16 h_{t-1} on the matrix cores

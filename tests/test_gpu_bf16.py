@@ -485,9 +485,17 @@ def test_fused_stem_forward_bit_identical():
         net.set_engine_option("fuse_stem_pool", 0)
         b0, c0 = net(x)
         net.set_engine_option("fuse_stem_pool", 1)
-        b1, c1 = net(x)
+        b1, c1 = net(x)                                  # + layer1.0.conv1 inside the stem kernel (default)
         b2, c2 = net.forward_async(x).result()
+        net.set_engine_option("fuse_stem_conv1", 0)
+        b3, c3 = net(x)
+        net.set_engine_option("fuse_stem_conv1", 1)
+        net.set_engine_option("chain_layer1", 0)         # the fused conv1 must not depend on the chained launches
+        b4, c4 = net(x)
+        net.set_engine_option("chain_layer1", 1)
     torch.cuda.synchronize()
     assert net.hip_status(DEV) == 0
     assert torch.equal(b0, b1) and torch.equal(c0, c1)
     assert torch.equal(b0, b2) and torch.equal(c0, c2)
+    assert torch.equal(b0, b3) and torch.equal(c0, c3)
+    assert torch.equal(b0, b4) and torch.equal(c0, c4)
