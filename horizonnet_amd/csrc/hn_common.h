@@ -136,6 +136,7 @@ int hn_launch_fold_bn(const float* gamma, const float* beta, const float* mean, 
 int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
                          int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed = 0);
 int hn_launch_unpack_conv(const float* wp, float* w_oihw, int Cout, int Cin, int KH, int KW, int packed_rows, hipStream_t s);
+int hn_launch_stem_conv_train_bf16(const float* x, int C_in, const void* wpk, void* z, double* stat_sum, double* stat_sq, int B, hipStream_t s);
 int hn_launch_stem_wgrad_bf16(const void* x4_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, hipStream_t s, int prezeroed);
 int hn_launch_pack_conv_dgrad(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 // bf16 family (conv_igemm_bf16.hip): buffers are bf16 unless noted

@@ -64,11 +64,15 @@ __device__ __forceinline__ u32x4 pk_max4(u32x4 a, u32x4 b)
     return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(u16x8, a), __builtin_bit_cast(u16x8, b)));
 }
 // grid = B * (128 / pseg) workgroups of 512 threads; workgroup -> image b, pooled rows [py0, py0 + pseg)
+// TRAIN: the training step's stem conv -- convolution rows [2 py0, 2 (py0 + pseg)) written as z (bf16, no affine / ReLU / pooling: the
+// BatchNorm of a training step needs the batch statistics first) into y [B][256][512][64], with the per-channel sum / sum of squares
+// of the float32 accumulators added to stat_sum / stat_sq (the implicit-GEMM stem's STATS epilogue, 1.5 ms at B = 64).
+template <bool TRAIN>
 __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __restrict__ x, int C_in, const u16* __restrict__ wpk,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              u16* __restrict__ y, int pseg, const u16* __restrict__ w1,
                                                              const float* __restrict__ scale1, const float* __restrict__ shift1,
-                                                             u16* __restrict__ t1)
+                                                             u16* __restrict__ t1, double* __restrict__ stat_sum, double* __restrict__ stat_sq)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -88,10 +92,10 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
         *reinterpret_cast<u32x4*>(smem + W_OFF + o * W_STRIDE + pc * 16) = *reinterpret_cast<const u32x4*>(wpk + o * 256 + pc * 8);
     }
     if (tid < 64) {
-        reinterpret_cast<float*>(smem + SC_OFF)[tid] = scale[tid];
-        reinterpret_cast<float*>(smem + SC_OFF)[64 + tid] = shift[tid];
+        reinterpret_cast<float*>(smem + SC_OFF)[tid] = TRAIN ? 0.f : scale[tid];       // TRAIN: the statistics' reduction scratch
+        reinterpret_cast<float*>(smem + SC_OFF)[64 + tid] = TRAIN ? 0.f : shift[tid];
     }
-    const bool fuse_c1 = w1 != nullptr;                     // (launch-uniform; the launch then carries LDS_BYTES_C1)
+    const bool fuse_c1 = !TRAIN && w1 != nullptr;           // (launch-uniform; the launch then carries LDS_BYTES_C1)
     if (fuse_c1) {
         {                                                   // 64 rows x 8 sixteen-byte pieces = 512 threads
             const int o = tid >> 3, pc = tid & 7;
@@ -132,10 +136,15 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
         }
     const char* wbase = smem + W_OFF + fr * W_STRIDE + half * 16;      // + j * 32 * W_STRIDE + s * 32
 
-    int r = 2 * py0 - 1;                                    // first convolution row of the band (row -1 does not exist: its maxima are 0)
+    int r = TRAIN ? 2 * py0 : 2 * py0 - 1;                  // first convolution row of the band (row -1 does not exist: its maxima are 0)
     const int r_last = 2 * (py0 + pseg) - 1;
-    const bool seed_row = r >= 0;                           // the band's first row only seeds the running maximum
+    const bool seed_row = !TRAIN && r >= 0;                 // the band's first row only seeds the running maximum
     if (r < 0) r = 0;
+    float ssum[2][16], ssq[2][16];                          // TRAIN: this lane's pixels, channel 32 j + 8 (q >> 2) + 4 half + (q & 3)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ssum[j][q] = 0.f; ssq[j][q] = 0.f; }
     float2 st[2][3] = {};                                   // the two rows in flight (registers are the ring's ninth and tenth slot)
     for (int row = 2 * r - 3; row <= 2 * r + 2; ++row) {
         load_row(row, st[0]);
@@ -194,6 +203,45 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
             mma(s & 1);
         }
 
+        if (TRAIN) {
+            // statistics of the float32 accumulators; z row r as bf16 through the strip, half a row (256 pixels) at a time
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        ssum[j][q] += acc[t][j][q];
+                        ssq[j][q] += acc[t][j][q] * acc[t][j][q];
+                    }
+            u16* zrow = y + ((size_t)(b * 256 + r) * 512) * 64;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if ((wave >> 2) == hf) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        char* hp = smem + H_OFF + (64 * (wave & 3) + 32 * t + fr) * H_STRIDE + 8 * half;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const u32x2 v = {pack_bf16(acc[t][j][4 * g], acc[t][j][4 * g + 1]), pack_bf16(acc[t][j][4 * g + 2], acc[t][j][4 * g + 3])};
+                                *reinterpret_cast<u32x2*>(hp + (32 * j + 8 * g) * 2) = v;
+                            }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int id = tid + 512 * it;
+                    const int q = id >> 3, cg = id & 7;
+                    *reinterpret_cast<u32x4*>(zrow + (size_t)(256 * hf + q) * 64 + cg * 8) =
+                        *reinterpret_cast<const u32x4*>(smem + H_OFF + q * H_STRIDE + cg * 16);
+                }
+                __syncthreads();
+            }
+            continue;
+        }
         // ---- scale / shift / ReLU / bf16, running maximum; lane = pixel, register q -> channel 32 j + 8 (q >> 2) + 4 half + (q & 3) ----
         const bool emit = (r & 1) && (r > r_first || !seed_row);
         unsigned outp[2][2][8];
@@ -305,6 +353,32 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
             }
         }
     }
+    if (TRAIN) {
+        // per channel: the 32 pixel lanes of a half wave (xor butterfly), then one LDS atomic per (wave, half, channel), then one
+        // float64 atomic per channel and workgroup
+        float* red = reinterpret_cast<float*>(smem + SC_OFF);            // [64] sums, [64] sums of squares (zeroed at the start)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float a = ssum[j][q], c2 = ssq[j][q];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) {
+                    a += __shfl_xor(a, m, 64);
+                    c2 += __shfl_xor(c2, m, 64);
+                }
+                if (fr == 0) {
+                    const int ch = 32 * j + 8 * (q >> 2) + 4 * half + (q & 3);
+                    atomicAdd(red + ch, a);
+                    atomicAdd(red + 64 + ch, c2);
+                }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            atomicAdd(stat_sum + tid, (double)red[tid]);
+            atomicAdd(stat_sq + tid, (double)red[64 + tid]);
+        }
+    }
 }
 
 }  // namespace
@@ -321,15 +395,36 @@ int hn_launch_stem_pool_bf16(const float* x, int C_in, const void* wpk, const fl
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_done[dev]) {
-        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_C1));
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_C1));
         attr_done[dev] = true;
     }
     // pooled rows per workgroup: as many as still give ~256 workgroups (a band recomputes one convolution row in 2 * pseg + 1)
     int pseg = 16;
     while (pseg > 1 && (long)B * (POOL_H / pseg) < 256) pseg >>= 1;
-    hipLaunchKernelGGL(stem_pool_bf16_kernel, dim3((unsigned)(B * (POOL_H / pseg))), dim3(512), w1 ? LDS_BYTES_C1 : LDS_BYTES, s, x, C_in,
+    hipLaunchKernelGGL(stem_pool_bf16_kernel<false>, dim3((unsigned)(B * (POOL_H / pseg))), dim3(512), w1 ? LDS_BYTES_C1 : LDS_BYTES, s, x, C_in,
                        reinterpret_cast<const u16*>(wpk), scale, shift, reinterpret_cast<u16*>(y), pseg, reinterpret_cast<const u16*>(w1), scale1,
-                       shift1, reinterpret_cast<u16*>(t1));
+                       shift1, reinterpret_cast<u16*>(t1), (double*)nullptr, (double*)nullptr);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The training step's stem conv (train_precision bf16): z [B][256][512][64] bf16 = conv7x7/2 of the normalised input (no affine), with
+// the per-channel sum / sum of squares of the float32 accumulators ADDED to stat_sum / stat_sq [64] (zeroed by the caller).
+int hn_launch_stem_conv_train_bf16(const float* x, int C_in, const void* wpk, void* z, double* stat_sum, double* stat_sq, int B, hipStream_t s)
+{
+    HN_REQUIRE(B >= 1 && C_in >= 3 && stat_sum && stat_sq, "stem conv (train) bf16: bad arguments");
+    static bool attr_done[64] = {};
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done[dev] = true;
+    }
+    int pseg = 16;
+    while (pseg > 1 && (long)B * (POOL_H / pseg) < 256) pseg >>= 1;
+    hipLaunchKernelGGL(stem_pool_bf16_kernel<true>, dim3((unsigned)(B * (POOL_H / pseg))), dim3(512), LDS_BYTES, s, x, C_in,
+                       reinterpret_cast<const u16*>(wpk), (const float*)nullptr, (const float*)nullptr, reinterpret_cast<u16*>(z), pseg,
+                       (const u16*)nullptr, (const float*)nullptr, (const float*)nullptr, (u16*)nullptr, stat_sum, stat_sq);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -463,7 +463,13 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     }
     {
         const Unit& u = pl.units[0];
-        if ((rc = conv_z(c, u))) return rc;
+        if (e->train_bf16 && e->fuse_stem_pool && !c.bn_eval(u)) {
+            // the stem conv straight from the float32 planes through an LDS ring of input rows (stem_pool_bf16.hip, TRAIN mode): z as
+            // bf16 + the batch statistics of the float32 accumulators, without the implicit GEMM's 12x im2col expansion
+            double* ds = reinterpret_cast<double*>(W + pl.dstat) + u.sf;
+            const void* wpk = reinterpret_cast<const unsigned short*>(e->packed_h) + hn_bf16_conv_offset(u.ci);
+            if ((rc = hn_launch_stem_conv_train_bf16(x, C_in, wpk, W + u.z, ds, ds + a.convs[u.ci].cout, B, s))) return rc;
+        } else if ((rc = conv_z(c, u))) return rc;
         if ((rc = bn_forward(c, u, nullptr, 1, bn_momentum))) return rc;
         if (e->train_bf16) {
             // the stem's activation exists as bf16 only (bn_forward: no float32 y for the stem in bf16 mode) and is pooled as bf16

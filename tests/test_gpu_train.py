@@ -671,3 +671,27 @@ def test_strided_dgrad_bf16_8wave_equals_4wave():
         os.environ.pop("HN_DGRAD_W8", None)
         assert torch.isfinite(out["1"]).all()
         assert torch.equal(out["0"], out["1"]), "B=%d: 8-wave data gradient differs, max %g" % (B, float((out["0"] - out["1"]).abs().max()))
+
+
+def test_train_stem_conv_direct_matches_implicit_gemm():
+    """train_precision bf16: the stem conv of the training forward as the direct kernel (LDS ring of input rows, z + batch statistics)
+    against the implicit-GEMM stem: same k order -> the bf16 z is bit-identical, so a whole training forward differs only through
+    the summation order of the statistics (float atomics either way): outputs within 1e-3 of each other's scale."""
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(11, "random"))
+    net = net.to(DEV).train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    net.train_precision = "bf16"
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(21)).to(DEV)
+    outs = []
+    for opt in (0, 1):
+        net.set_engine_option("fuse_stem_pool", opt)
+        bon, cor = net(x)
+        torch.cuda.synchronize()
+        outs.append((bon.detach().clone(), cor.detach().clone()))
+    net.set_engine_option("fuse_stem_pool", 1)
+    assert net.hip_status(DEV) == 0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
