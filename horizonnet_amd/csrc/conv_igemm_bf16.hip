@@ -2,8 +2,8 @@
 //
 // Same algorithm, data flow and boundary semantics as conv_igemm_f32.hip (see the header there):
 //   y[m][n] = act( scale[n] * sum_k A[m][k] * W[n][k] + shift[n] (+ res[m][n]) )
-// with NHWC bf16 activations, packed bf16 weights [Cout][kh][kw][Cin], f32 scale/shift (folded BN), bf16
-// (or f32) output.  It serves the bf16 inference mode that BASELINE configs 3-5 name (the reference trains
+// with NHWC bf16 activations, packed bf16 weights [Cout][Cin / 64][kh][kw][64] (the filter taps are the INNER loop of a
+// 64-channel chunk, see fetch()), f32 scale/shift (folded BN), bf16 (or f32) output.  It serves the bf16 inference mode that BASELINE configs 3-5 name (the reference trains
 // and infers under autocast, train.py:51,273).  What changes against the f32 kernel:
 //   * BK = 64 elements, so a tile row is again ONE 128-byte line = 8 chunks of 16 bytes; the LDS-DMA
 //     staging, the source-side slot swizzle c ^ ((r >> 1) & 7) and the buffer-load addressing are
