@@ -16,71 +16,13 @@
 // zero weights) so every 16-byte DMA piece is an aligned pixel pair; 7 filter rows -> 4 chunks, K = 256 (the NHWC8 /
 // one-row-per-chunk form of round 1 spent K = 448 on the same 147 real products).
 #include "hn_common.h"
+#include "conv_bf16_args.h"
 
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
 namespace {
-
-constexpr int BKE = 64;                  // K chunk in elements (128 bytes)
-constexpr int ROWB = 128;                // bytes per LDS tile row
-constexpr unsigned OOB = 0x80000000u;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
-
-struct ConvArgsH {
-    const u16* x;
-    const u16* w;
-    const float* scale;
-    const float* shift;
-    const u16* res;
-    void* y;
-    int Hi, Wi, Cin, Ho, Wo, Cout;
-    int KH, KW, sh, sw, ph, pw;   // K order of the forward kernels: (64-channel chunk, filter tap, channel in chunk) -- see fetch()
-    int M, K, nk, relu, ldy;
-    int xstride;
-    int xcd_swizzle;
-    int ksplit;          // > 1: split-K -- blockIdx.y = K slice, float32 partial tiles to y + slice * M * ldy (forward, OUT_F32 only)
-    double* stat_sum;    // optional per-channel sum / sum of squares of the stored rows (train-mode BatchNorm statistics)
-    double* stat_sq;
-    // data-gradient mode (template TR), see conv_igemm_f32.hip: one launch = one stride-parity class of dX pixels
-    int sh_log2, sw_log2;
-    int ca, cb, cHo, cWo;
-    int tdh[3], tdw[3], ntdh, ntdw;
-#ifdef HN_CONV_TRACE
-    unsigned long long* trace = nullptr;   // throw-away measurement builds only (tools/conv_trace.py): 8 stamps per workgroup / tile
-#endif
-};
-
-// Measurement builds (-DHN_CONV_TRACE, tools/conv_trace.py): s_memrealtime stamps per workgroup (per tile in the persistent
-// kernel) at entry, first chunk landed, k loop done, after every epilogue band; HW_ID / XCC_ID in slot 7.  Compiled out otherwise.
-#ifdef HN_CONV_TRACE
-#define HN_TR_STAMP(wg, k) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)(wg) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define HN_TR_HWID(wg) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)(wg) * 8 + 7] = \
-    (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); } while (0)
-#else
-#define HN_TR_STAMP(wg, k) do {} while (0)
-#define HN_TR_HWID(wg) do {} while (0)
-#endif
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, unsigned voff, unsigned soff)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
-#endif
-}
-
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
-{
-    unsigned r;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 
 // OUT_F32: the output AND the residual are float32 (train-mode z / dX (+ identity gradient), LSTM gate pre-activations).
 // TR: data-gradient mode (x = dY bf16 on the (Hi,Wi) grid, y = dX on the (Ho,Wo) grid, per-class tap lists).
@@ -1266,7 +1208,8 @@ int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
 }
 
 // Tile choice for the inference forward: a large tile only where it still fills the 256 CUs and K is deep enough to
-// amortise its prologue / epilogue.  HN_BF16_W8 = 0 disables the 8-wave kernels, 1 = 256x256, 2 = 256x128, 3 = 128x256
+// amortise its prologue / epilogue.  HN_BF16_W8 = 0 disables the 8-wave kernels, 1 = 256x256, 2 = 256x128, 3 = 128x256,
+// 4 / 5 = the ping-pong persistent 256x256 kernel without / with s_setprio
 // force one (A/B runs, tests).
 template <bool OUT_F32>
 int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
@@ -1287,6 +1230,7 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     const long t256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
     const long t128x256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 128) * (Cout / 256) : 0;
     const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
+    if ((force == 4 || force == 5) && t256 && a.nk >= 2) return hn_launch_conv_bf16_pp(a, OUT_F32 ? 1 : 0, force - 4, s);
     if (force == 1 && t256) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
     if (force == 2 && t256x128) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
     if (force == 3 && t128x256) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
@@ -1295,6 +1239,10 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     // also on the HBM-bound 1x1 convs; with 128 workgroups (layer4 3x3, ghc3.0) half the CUs idle and it loses; the
     // 256x128 / 128x256 shapes (64x64 wave tiles) never beat the 4-wave 128x128 kernel and are kept for A/B runs only
     if (force < 0 && t256 >= 224) {
+        // ping-pong persistent kernel (conv_igemm_bf16_pp.hip); HN_BF16_PP=0 for A/B runs, 2 = with s_setprio
+        const char* ppe = getenv("HN_BF16_PP");
+        const int pp = ppe ? atoi(ppe) : 1;
+        if (pp > 0 && a.nk >= 2) return hn_launch_conv_bf16_pp(a, OUT_F32 ? 1 : 0, pp - 1, s);
         // more than one tile per CU: the persistent form (next tile's first chunk in flight under the epilogue, no workgroup
         // dispatch between tiles); HN_W8_PERSIST=0 for A/B runs
         const char* pe = getenv("HN_W8_PERSIST");

@@ -1,0 +1,406 @@
+// Ping-pong persistent implicit-GEMM convolution for gfx950: bf16 operands, f32 accumulation, 256x256 tiles, 8 waves.
+//
+// Same arithmetic as conv_igemm_bf16.hip (y = act(scale * sum_k A W + shift (+ res)), v_mfma_f32_32x32x16_bf16, k ascending,
+// NHWC bf16 activations, weights packed [Cout][Cin / 64][kh][kw][64], circular W padding by index arithmetic) and therefore the
+// same bits; what changes is the schedule of the k loop -- the part the two-stage kernels lose 40 % of the matrix pipe on
+// (reference call sites: model.py:78-81 ResNet bottlenecks, model.py:123-135 ConvCompressH; the LSTM input projections).
+//
+//   * Two wave GROUPS (waves 0-3 / 4-7: one wave of each on every SIMD) run the same phase sequence ONE BARRIER APART: while a
+//     group issues the 8 MFMAs of a phase (a 64x32 quadrant of its wave's 128x64 tile over the 64-deep K chunk), its SIMD
+//     partner issues the NEXT phase's fragment reads and LDS-DMA pieces.  The matrix pipe of a SIMD always has one wave feeding
+//     it and neither wave waits for its own loads in front of its own MFMAs.
+//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt), ONE counted
+//     s_waitcnt vmcnt(6) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (upper / lower 64 rows of every
+//     wave's 128), B0 / B1 (left / right 32 columns of every wave's 64) -- so that a region is read in ONE phase only and is
+//     re-filled in the next one with the chunk after next: every piece has 3-7 phases (>= 1.5 us) to land, two pieces per wave
+//     and phase instead of eight at the chunk head.
+//   * The chunk stream does not stop at a tile boundary: the persistent workgroup's loader runs two chunks ahead of its MFMAs,
+//     INTO THE NEXT TILE (no prologue bubble per tile; the last tile's surplus pieces are out-of-range loads = zero fill).
+//   * Epilogue without workgroup barriers: every wave transposes its own accumulators through a private 4 KiB slab (16 rows x
+//     64 columns f32, XOR-swizzled 16-byte blocks: conflict-free ds_write_b32 / ds_read_b128), all 16 residual rows of the
+//     wave requested up front, whole 128-byte lines stored.  The two groups re-align for it (both epilogues at once) and
+//     re-stagger behind it.
+//
+// LDS (160 KiB): chunk buffer 0 | chunk buffer 1 (A0 A1 B0 B1 each) | 8 slabs.  Loader rows, the source-side slot swizzle
+// c ^ ((r >> 1) & 7) and the fragment reads are the two-stage kernels' (conflict-free, SQ_LDS_BANK_CONFLICT = 0 there).
+//
+// Ordering rules the schedule below is built on (MI355X guide, "LDS-DMA stays in flight across s_barrier"):
+//   RAW  a region is read one phase after the barrier that follows BOTH groups' counted waits for its pieces;
+//   WAR  a region is re-filled after a barrier that follows every reader's lgkmcnt(0) (issued before the reader's own barrier).
+#include "hn_common.h"
+#include "conv_bf16_args.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int PP_BUF = 65536;         // one K chunk: A0 | A1 | B0 | B1
+constexpr int PP_REGION = 16384;      // 128 rows x 128 bytes
+constexpr int PP_BOFF = 32768;
+constexpr int PP_SLAB = 131072;       // 8 wave-private epilogue slabs of 4 KiB
+constexpr int PP_LDS = 163840;
+
+// LDS-DMA piece issued from inline asm: INVISIBLE to hipcc's waitcnt pass on purpose.  With the builtin, the pass makes every
+// ds_read wait for every LDS-DMA it believes outstanding (at the loop head: vmcnt(5) ... vmcnt(0) in front of the phase-1 fragment
+// reads), which drains exactly the queue this kernel keeps in flight across its barriers.  Hidden, the queue is counted by hand
+// (one s_waitcnt vmcnt(6) per chunk); hipcc's own counted waits for ordinary loads / spills only ever see FEWER outstanding
+// operations than there are, i.e. they over-wait, never under-wait (memory operations return in order).
+__device__ __forceinline__ void pp_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");       // (m0 is not used by anything else in this kernel: gfx950 DS instructions do not read it)
+}
+
+__device__ __forceinline__ u32x4 pp_rsrc(const void* base)
+{
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));      // stride 0
+    r[2] = 0x7fffffffu;                                                                       // num_records (bytes)
+    r[3] = 0x00020000u;
+    return r;
+}
+
+__device__ __forceinline__ void pp_bar()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// PRIO: s_setprio(1) around the MFMA block of a phase (the partner wave is in its load block meanwhile)
+template <bool OUT_F32, bool PRIO>
+__global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2;                                // wave group = row half of the tile
+    const int wn = wave & 3;                                // 64-column slice
+    const int lrow = tid >> 3;                              // loader: row 0..63 of a 64-row pass
+    const int lslot = tid & 7;
+    const int lcol = lslot ^ ((lrow >> 1) & 7);
+    const int fr = lane & 31;
+    const int half = lane >> 5;
+    const int fswz = (fr >> 1) & 7;
+
+    // LDS byte address of the dynamic segment (M0 of the LDS-DMA pieces)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int NT = p.Cout >> 8;
+    const int total = ((p.M + 255) >> 8) * NT;
+    const int hw_out = p.Ho * p.Wo;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
+    const int nwg = (int)gridDim.x;
+
+    auto tile_coords = [&](int vb, int& m0, int& n0) {
+        int bid = vb;
+        if (p.xcd_swizzle) {
+            const int q = total >> 3, r = total & 7;
+            const int xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const int nt = bid % NT;
+        const int mt = bid / NT;
+        m0 = __builtin_amdgcn_readfirstlane(mt * 256);      // (the division expands to VALU code: pin the results back to SGPRs, or every
+        n0 = __builtin_amdgcn_readfirstlane(nt * 256);      //  buffer descriptor derived from them needs a waterfall loop around its DMA)
+    };
+
+    // ---- loader state: the tile / chunk the NEXT LDS-DMA pieces belong to (runs two chunks ahead of the MFMAs) ----
+    // A rows of this thread: tile rows lrow + 64 k, k = 2 pass + region (region A0: k even, A1: k odd)
+    // B rows (output channels): tile columns 128 pass + 32 region + 64 (lrow >> 5) + (lrow & 31), k = 2 pass + region
+    int ivb = (int)blockIdx.x;
+    bool ivalid = true;
+    int ikc = 0;
+    int dh = 0, dw = 0, c0 = 0;
+    u32x4 rsrc_a, rsrc_w;
+    int a_pix0[4], a_hi0[4], a_wi0[4];
+    unsigned a_off[4], w_off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 128 * (k >> 1) + 32 * (k & 1) + 64 * (lrow >> 5) + (lrow & 31);
+        w_off[k] = (unsigned)(c * p.K + lcol * 8) * 2u;
+    }
+    auto tap_offsets = [&](int th, int tw) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int hi = a_hi0[k] + th;
+            int wi = a_wi0[k] + tw;
+            wi = wi < 0 ? wi + p.Wi : wi;
+            wi = wi >= p.Wi ? wi - p.Wi : wi;
+            const bool ok = a_pix0[k] >= 0 && ((unsigned)hi < (unsigned)p.Hi);
+            const unsigned pix = (unsigned)(a_pix0[k] + hi * p.Wi + wi);
+            a_off[k] = ok ? (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u : OOB;
+        }
+    };
+    auto setup = [&](int vb) {
+        int m0, n0;
+        tile_coords(vb, m0, n0);
+        const int b_first = __builtin_amdgcn_readfirstlane(m0 / hw_out);
+        rsrc_a = pp_rsrc(p.x + (size_t)b_first * img_elems);
+        rsrc_w = pp_rsrc(p.w + (size_t)n0 * p.K);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + lrow + 64 * k;
+            if (m < p.M) {
+                const int wo = m % p.Wo;
+                const int t = m / p.Wo;
+                const int ho = t % p.Ho;
+                const int b = t / p.Ho;
+                a_pix0[k] = (b - b_first) * p.Hi * p.Wi;
+                a_hi0[k] = ho * p.sh - p.ph;
+                a_wi0[k] = wo * p.sw - p.pw;
+            } else {
+                a_pix0[k] = -1;
+                a_hi0[k] = 0;
+                a_wi0[k] = 0;
+            }
+        }
+        dh = 0; dw = 0; c0 = 0;
+    };
+    auto next_issue_chunk = [&]() {
+        bool retap = p.KH * p.KW > 1;
+        if (++ikc == p.nk) {
+            ikc = 0;
+            ivb += nwg;
+            ivalid = ivb < total;
+            if (ivalid) setup(ivb);
+            retap = true;
+        } else {
+            if (++dw == p.KW) {          // taps inner, 64-channel chunks outer (conv_igemm_bf16.hip fetch())
+                dw = 0;
+                if (++dh == p.KH) { dh = 0; c0 += BKE; }
+            }
+        }
+        // (ONE call site behind the join: with tap_offsets at the end of both branches hipcc treats the loader's scalars as
+        //  divergent and wraps every LDS-DMA in a waterfall loop)
+        if (retap) tap_offsets(dh, dw);
+    };
+    // region `reg` (0 / 1) of the loader's current chunk -> chunk buffer `buf`: two 1 KiB pieces per wave
+    auto issue_a = [&](int buf, int reg) {
+        const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + reg * PP_REGION + wave * 1024);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const unsigned o0 = ivalid ? a_off[0 + 2 * ps] : OOB, o1 = ivalid ? a_off[1 + 2 * ps] : OOB;
+            pp_dma16(rsrc_a, dst + ps * 8192, reg ? o1 : o0, (unsigned)c0 * 2u);
+        }
+    };
+    auto issue_b = [&](int buf, int reg) {
+        const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + PP_BOFF + reg * PP_REGION + wave * 1024);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const unsigned o0 = ivalid ? w_off[0 + 2 * ps] : OOB, o1 = ivalid ? w_off[1 + 2 * ps] : OOB;
+            pp_dma16(rsrc_w, dst + ps * 8192, reg ? o1 : o0, (unsigned)ikc * (unsigned)ROWB);
+        }
+    };
+
+    // ---- MFMA side ----
+    int cvb = (int)blockIdx.x, cm0, cn0, ckc = 0;
+    tile_coords(cvb, cm0, cn0);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 fa[2][4], fb0[4], fb1[4];
+    // fragment read offsets inside the CURRENT chunk buffer (toggled by PP_BUF per chunk): k step s -> slot (2 s + half) ^ fswz
+    unsigned rd_a[4], rd_b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned ks = (unsigned)(((2 * s + half) ^ fswz) * 16);
+        rd_a[s] = (unsigned)((64 * g + fr) * ROWB) + ks;
+        rd_b[s] = (unsigned)(PP_BOFF + (32 * wn + fr) * ROWB) + ks;
+    }
+    auto read_a = [&](int reg) {        // the 64 rows of region A<reg> that belong to this wave: 2 row tiles x 4 k steps
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fa[i2][s] = *reinterpret_cast<const u32x4*>(smem + rd_a[s] + reg * PP_REGION + i2 * 32 * ROWB);
+    };
+    auto read_b = [&](int reg, u32x4 (&fb)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const u32x4*>(smem + rd_b[s] + reg * PP_REGION);
+    };
+    auto mm = [&](int qi, int qj, const u32x4 (&fb)[4]) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+                acc[2 * qi + i2][qj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i2][s]), __builtin_bit_cast(bf16x8, fb[s]),
+                                                                              acc[2 * qi + i2][qj], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- epilogue of the wave's 128 x 64 tile: 8 rounds of 16 rows through the wave's slab ----
+    auto epilogue = [&](int em0, int en0, auto has_res_c) {
+        // (HAS_RES is a compile-time copy of the body: with a runtime `if` around the residual loads AND around their uses hipcc
+        //  assumes loads that were never consumed and makes the next chunk's fragment reads wait for them -- vmcnt(0), i.e. for the
+        //  whole LDS-DMA queue)
+        constexpr bool HAS_RES = decltype(has_res_c)::value;
+        float* slab = reinterpret_cast<float*>(smem + PP_SLAB + wave * 4096);
+        const int er = lane >> 3;                       // row (and row + 8) inside a round
+        const int ec = (lane & 7) * 8;                  // 8 consecutive channels of the wave's 64
+        const int colg = en0 + 64 * wn + ec;
+        const int mrow0 = em0 + 128 * g + er;
+        float sc[2], sf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sc[j] = p.scale[en0 + 64 * wn + 32 * j + fr];
+            sf[j] = p.shift[en0 + 64 * wn + 32 * j + fr];
+        }
+        // residual rows: a ring of 8 requests (4 rounds) ahead of their use
+        u32x4 rres[HAS_RES ? 8 : 1];
+        auto res_load = [&](int q) {
+            const int m = mrow0 + 8 * q;
+            const int mc = m < p.M ? m : p.M - 1;
+            rres[q & 7] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.Cout + colg);
+        };
+        if (HAS_RES) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) res_load(q);
+        }
+        const int b0 = (2 * (lane & 7)) ^ (er & 3), b1 = (2 * (lane & 7) + 1) ^ (er & 3);   // swizzled 16-byte blocks of this lane's 8 channels
+#pragma unroll
+        for (int rd = 0; rd < 8; ++rd) {
+            const int i = rd >> 1, hb = rd & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int lr16 = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+                    const int blk = (8 * j + (fr >> 2)) ^ (rr & 3);
+                    slab[lr16 * 64 + blk * 4 + (fr & 3)] = acc[i][j][8 * hb + rr] * sc[j] + sf[j];
+                }
+#pragma unroll
+            for (int sr = 0; sr < 2; ++sr) {
+                const int row16 = 8 * sr + er;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + row16 * 64 + b0 * 4);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + row16 * 64 + b1 * 4);
+                const int m = mrow0 + 16 * rd + 8 * sr;
+                if (HAS_RES) {
+                    const u32x4 rr = rres[(2 * rd + sr) & 7];
+                    v0[0] += bf16_lo(rr[0]); v0[1] += bf16_hi(rr[0]); v0[2] += bf16_lo(rr[1]); v0[3] += bf16_hi(rr[1]);
+                    v1[0] += bf16_lo(rr[2]); v1[1] += bf16_hi(rr[2]); v1[2] += bf16_lo(rr[3]); v1[3] += bf16_hi(rr[3]);
+                    if (2 * rd + sr + 8 < 16) res_load(2 * rd + sr + 8);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+                }
+                if (m < p.M) {
+                    if (OUT_F32) {
+                        float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + colg;
+                        *reinterpret_cast<f32x4*>(yo) = v0;
+                        *reinterpret_cast<f32x4*>(yo + 4) = v1;
+                    } else {
+                        u32x4 o;
+                        o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
+                        o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + colg) = o;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- prologue: chunk 0 completely, chunk 1 without its A1 (phase 1 of chunk 0 brings that) ----
+    setup(ivb);
+    tap_offsets(0, 0);
+    issue_a(0, 0); issue_b(0, 0); issue_b(0, 1); issue_a(0, 1);
+    next_issue_chunk();
+    issue_a(1, 0); issue_b(1, 0); issue_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // chunk 0 has landed (this wave's pieces); chunk 1's six stay in flight
+    pp_bar();
+    if (g == 1) pp_bar();                                  // group 1 runs one barrier behind group 0 from here on
+
+    int buf = 0;
+    while (true) {
+        // ---- phase 1: quadrant (A0, B0) ----
+        read_a(0);
+        read_b(0, fb0);
+        issue_a(buf ^ 1, 1);                               // A1 of the next chunk (its other three regions went out during the previous chunk)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_bar();
+        mm(0, 0, fb0);
+        pp_bar();
+        // ---- phase 2: quadrant (A0, B1); the loader moves on to the chunk after next ----
+        read_b(1, fb1);
+        next_issue_chunk();
+        issue_a(buf, 0);                                   // A0 of this buffer was last read in phase 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_bar();
+        mm(0, 1, fb1);
+        pp_bar();
+        // ---- phase 3: quadrant (A1, B1) ----
+        read_a(1);
+        issue_b(buf, 0);                                   // B0: last read in phase 1 (its fragments stay in registers for phase 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_bar();
+        mm(1, 1, fb1);
+        pp_bar();
+        // ---- phase 4: quadrant (A1, B0); the chunk's one counted wait ----
+        issue_b(buf, 1);                                   // B1: last read in phase 2
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three newest regions: the next chunk is complete
+        pp_bar();
+        mm(1, 0, fb0);
+        pp_bar();
+
+        buf ^= 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { rd_a[s] ^= (unsigned)PP_BUF; rd_b[s] ^= (unsigned)PP_BUF; }
+        if (++ckc == p.nk) {                               // tile finished
+            ckc = 0;
+            if (g == 0) pp_bar();                          // wait for group 1's last MFMA block: both epilogues run at once
+            if (!OUT_F32 && p.res != nullptr) epilogue(cm0, cn0, std::true_type{}); else epilogue(cm0, cn0, std::false_type{});
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            cvb += nwg;
+            if (cvb >= total) break;
+            tile_coords(cvb, cm0, cn0);
+            if (g == 1) pp_bar();                          // re-stagger
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus (out-of-range) pieces of the loader
+}
+
+template <bool OUT_F32, bool PRIO>
+int launch_pp(const ConvArgsH& a, hipStream_t s)
+{
+    auto kern = conv_igemm_bf16_pp_kernel<OUT_F32, PRIO>;
+    static bool attr_done[64] = {};   // per instantiation, per device
+    static int n_cu[64] = {};
+    int dev = 0;
+    HN_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_done[dev]) {
+        HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+        HN_HIP(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done[dev] = true;
+    }
+    const int tiles = hn_cdiv(a.M, 256) * (a.Cout / 256);
+    const int cus = dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
+    const int grid = tiles < cus ? tiles : cus;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), PP_LDS, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// variant bit 0: s_setprio around the MFMA blocks
+int hn_launch_conv_bf16_pp(const ConvArgsH& a, int out_f32, int variant, hipStream_t s)
+{
+    HN_REQUIRE(a.Cout % 256 == 0 && a.nk >= 2 && a.ksplit <= 1 && a.stat_sum == nullptr, "conv bf16 (ping-pong): Cout %% 256, K >= 128, forward only");
+    HN_REQUIRE(!out_f32 || a.res == nullptr, "conv bf16 (ping-pong): no residual with float32 output");
+    if (out_f32) return (variant & 1) ? launch_pp<true, true>(a, s) : launch_pp<true, false>(a, s);
+    return (variant & 1) ? launch_pp<false, true>(a, s) : launch_pp<false, false>(a, s);
+}

@@ -499,3 +499,52 @@ def test_fused_stem_forward_bit_identical():
     assert torch.equal(b0, b2) and torch.equal(c0, c2)
     assert torch.equal(b0, b3) and torch.equal(c0, c3)
     assert torch.equal(b0, b4) and torch.equal(c0, c4)
+
+
+PP_CASES = [
+    # name, B, H, W, cin, cout, k, stride, residual, out_f32
+    ("1x1 K=128 ragged M", 3, 37, 41, 128, 256, 1, 1, False, False),
+    ("3x3 s1 residual", 2, 24, 32, 64, 256, 3, 1, True, False),
+    ("3x3 s(2,1) two column tiles", 3, 16, 64, 128, 512, 3, (2, 1), False, False),
+    ("3x3 s2 deep K", 2, 32, 64, 256, 256, 3, 2, False, False),
+    ("1x1 persistent 1096 tiles residual", 7, 100, 100, 256, 1024, 1, 1, True, False),
+    ("3x3 persistent 512 tiles", 4, 128, 256, 64, 256, 3, 1, False, False),
+    ("gemm f32 out ragged", 1, 1, 8292, 1024, 512, 1, 1, False, True),
+]
+
+
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_pingpong_conv_bit_identical(case, monkeypatch):
+    """conv_igemm_bf16_pp_kernel (two wave groups one barrier apart, LDS-DMA in flight across the barriers, the loader running
+    into the next tile, per-wave epilogue) against the plain 4-wave kernel on the same operands: same k order, same rounding
+    points -> the same bits; with and without s_setprio; ragged tails, circular taps, strides, residual, tile switches of a
+    persistent workgroup, float32 output."""
+    name, B, H, W, cin, cout, k, stride, has_res, out_f32 = case
+    L = lib()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    Ho = (H + 2 * (k // 2) - k) // sh + 1
+    Wo = (W + 2 * (k // 2) - k) // sw + 1
+    xd = _rand((B, H, W, cin), 11).to(DEV).bfloat16().contiguous()
+    wd = _rand((cout, cin, k, k), 12, 1.0 / np.sqrt(cin * k * k)).to(DEV).contiguous()
+    scr = torch.empty(cout * cin * k * k, dtype=torch.bfloat16, device=DEV)
+    sd_ = (torch.rand(cout, generator=torch.Generator().manual_seed(13)) + 0.5).to(DEV)
+    fd_ = _rand((cout,), 14, 0.2).to(DEV)
+    rd = _rand((B, Ho, Wo, cout), 15).to(DEV).bfloat16().contiguous() if has_res else None
+    outs = {}
+    for variant in ("0", "4", "5", "4"):          # (variant 4 twice: a second launch on warm caches / re-used LDS state)
+        monkeypatch.setenv("HN_BF16_W8", variant)
+        y = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV)
+        _lib.check(L.hn_conv2d_nhwc_bf16(P(xd), P(wd), P(scr), P(sd_), P(fd_), P(rd), P(y), B, H, W, cin, cout, k, k, sh, sw, 1,
+                                         int(out_f32), sp()), "conv bf16")
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(y.float()).any()), (name, variant)
+        if variant in outs:
+            assert torch.equal(outs[variant].view(torch.int32 if out_f32 else torch.int16), y.view(torch.int32 if out_f32 else torch.int16)), name
+        outs[variant] = y
+    for variant in ("4", "5"):
+        same = torch.equal(outs["0"].view(torch.int32 if out_f32 else torch.int16), outs[variant].view(torch.int32 if out_f32 else torch.int16))
+        if not same:
+            d = (outs["0"].float() - outs[variant].float()).abs()
+            bad = torch.nonzero(d.reshape(-1, cout) > 0)
+            print("first mismatches (row, col):", bad[:8].tolist(), "max", float(d.max()), "count", int((d > 0).sum()))
+        assert same, (name, variant)

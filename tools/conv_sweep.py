@@ -1,7 +1,7 @@
 """Per-layer tile sweep of the bf16 implicit-GEMM convolution on the network's real shapes (MEASUREMENT TOOL).
 
 For every distinct conv shape of the B=32 forward it times hn_conv2d_nhwc_bf16 with the 4-wave kernels (HN_BF16_W8=0)
-and each legal 8-wave tile (1: 256x256, 2: 256x128, 3: 128x256), HIP events around `iters` back-to-back launches, and prints
+and each legal 8-wave tile (1: 256x256, 2: 256x128, 3: 128x256; 4 / 5: the ping-pong persistent 256x256 kernel), HIP events around `iters` back-to-back launches, and prints
 TF/s + the winner -- the data behind the dispatch heuristic in conv_igemm_bf16.hip.  SWEEP_VARIANTS / SWEEP_ONLY select
 columns / layers.  (Variants 4-7 of profiles/r2_conv_tile_sweep.txt were the phased kernels of commit 053652b, since removed.)
 """
@@ -88,7 +88,8 @@ def main():
             continue
         row, best, ref = [], None, None
         for v in variants:
-            legal = v in (0, -1) or (v in (1, 3) and cout % 256 == 0) or (v == 2 and cout % 128 == 0)
+            legal = v in (0, -1) or (v in (1, 3) and cout % 256 == 0) or (v == 2 and cout % 128 == 0) or \
+                (v in (4, 5) and cout % 256 == 0 and cin * k * k >= 128)      # 4 / 5: ping-pong persistent kernel without / with s_setprio
             if not legal:
                 row.append("      -      ")
                 continue
@@ -98,7 +99,10 @@ def main():
                 tot[0] += ms
             elif ref is not None:        # every other variant, the dispatch heuristic (-1: persistent 8-wave form) included
                 err = float((y.float() - ref).abs().max())
-                assert err == 0.0 or os.environ.get("HN_W8_ABL", "0") != "0", (name, v, err)   # same k order -> bit-identical to the 4-wave kernel
+                if os.environ.get("SWEEP_NOASSERT") and err != 0.0:
+                    print("MISMATCH %s variant %d max-abs %.4g" % (name, v, err))
+                else:
+                    assert err == 0.0 or os.environ.get("HN_W8_ABL", "0") != "0", (name, v, err)   # same k order -> bit-identical to the 4-wave kernel
             if v == -1:
                 tot["auto"] += ms
             elif best is None or ms < best[0]:
