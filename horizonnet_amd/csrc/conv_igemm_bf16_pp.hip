@@ -6,14 +6,16 @@
 // (reference call sites: model.py:78-81 ResNet bottlenecks, model.py:123-135 ConvCompressH; the LSTM input projections).
 //
 //   * Two wave GROUPS (waves 0-3 / 4-7: one wave of each on every SIMD) run the same phase sequence ONE BARRIER APART: while a
-//     group issues the 8 MFMAs of a phase (a 64x32 quadrant of its wave's 128x64 tile over the 64-deep K chunk), its SIMD
-//     partner issues the NEXT phase's fragment reads and LDS-DMA pieces.  The matrix pipe of a SIMD always has one wave feeding
-//     it and neither wave waits for its own loads in front of its own MFMAs.
-//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt), ONE counted
-//     s_waitcnt vmcnt(6) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (upper / lower 64 rows of every
-//     wave's 128), B0 / B1 (left / right 32 columns of every wave's 64) -- so that a region is read in ONE phase only and is
-//     re-filled in the next one with the chunk after next: every piece has 3-7 phases (>= 1.5 us) to land, two pieces per wave
-//     and phase instead of eight at the chunk head.
+//     group issues the 8 MFMAs of a phase, its SIMD partner issues the NEXT phase's fragment reads and LDS-DMA pieces.  The
+//     matrix pipe of a SIMD always has one wave feeding it and neither wave waits for its own loads in front of its own MFMAs.
+//     A phase = one 32-column half (j) of the wave's 128x64 tile over one half (h) of the 64-deep K chunk: 4 row tiles x 2 k
+//     steps = 8 MFMAs on FOUR independent accumulators; order (j0,h0) (j1,h0) (j0,h1) (j1,h1) keeps k ascending per
+//     accumulator.  Fragment reads per phase: 8 A + 2 B, 2 B, 8 A + 2 B, 2 B (the A fragments of a K half serve both j).
+//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt) and two counted
+//     s_waitcnt vmcnt(4) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (the rows of wave group 0 / 1),
+//     B0 / B1 (left / right 32 columns of every wave's 64) -- and every phase re-fills ONE region (two 1 KiB pieces per wave):
+//     A1, B0, B1 of the next chunk in phases 1-3 (into the other buffer), A0 of the chunk after next in phase 4 (this buffer's
+//     A0 had its last read in phase 3).  Activation pieces have 3-4 phases to land, weight pieces (L2 hits) 2.
 //   * The chunk stream does not stop at a tile boundary: the persistent workgroup's loader runs two chunks ahead of its MFMAs,
 //     INTO THE NEXT TILE (no prologue bubble per tile; the last tile's surplus pieces are out-of-range loads = zero fill).
 //   * Epilogue without workgroup barriers: every wave transposes its own accumulators through a private 4 KiB slab (16 rows x
@@ -62,18 +64,26 @@ __device__ __forceinline__ u32x4 pp_rsrc(const void* base)
     return r;
 }
 
-__device__ __forceinline__ void pp_bar()
+__device__ __forceinline__ void pp_bar_raw()
 {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
+#define pp_bar() do { if (!(abl & 4)) pp_bar_raw(); else __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // PRIO: s_setprio(1) around the MFMA block of a phase (the partner wave is in its load block meanwhile)
 template <bool OUT_F32, bool PRIO>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef HN_PP_ABL
+    // measurement builds (-DHN_PP_ABL=mask, tools/pp_ablate.sh): parts of the loop switched off (WRONG results) to price them --
+    // 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no barriers, 8 no MFMAs, 16 no counted waits
+    constexpr int abl = HN_PP_ABL;
+#else
+    constexpr int abl = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     };
 
     // ---- loader state: the tile / chunk the NEXT LDS-DMA pieces belong to (runs two chunks ahead of the MFMAs) ----
-    // A rows of this thread: tile rows lrow + 64 k, k = 2 pass + region (region A0: k even, A1: k odd)
+    // A rows of this thread: tile rows lrow + 64 k, k = 2 region + pass (region A0 = rows 0..127 = wave group 0, A1 = group 1)
     // B rows (output channels): tile columns 128 pass + 32 region + 64 (lrow >> 5) + (lrow & 31), k = 2 pass + region
     int ivb = (int)blockIdx.x;
     bool ivalid = true;
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + reg * PP_REGION + wave * 1024);
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const unsigned o0 = ivalid ? a_off[0 + 2 * ps] : OOB, o1 = ivalid ? a_off[1 + 2 * ps] : OOB;
+            const unsigned o0 = ivalid ? a_off[0 + ps] : OOB, o1 = ivalid ? a_off[2 + ps] : OOB;
             pp_dma16(rsrc_a, dst + ps * 8192, reg ? o1 : o0, (unsigned)c0 * 2u);
         }
     };
@@ -207,33 +217,44 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    u32x4 fa[2][4], fb0[4], fb1[4];
+    u32x4 fa[4][2], fb[2];
+#ifdef HN_PP_ABL
+    for (int i = 0; i < 4; ++i) { fa[i][0] = fa[i][1] = u32x4{0, 0, 0, 0}; }
+    fb[0] = fb[1] = u32x4{0, 0, 0, 0};
+#endif
     // fragment read offsets inside the CURRENT chunk buffer (toggled by PP_BUF per chunk): k step s -> slot (2 s + half) ^ fswz
     unsigned rd_a[4], rd_b[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const unsigned ks = (unsigned)(((2 * s + half) ^ fswz) * 16);
-        rd_a[s] = (unsigned)((64 * g + fr) * ROWB) + ks;
+        rd_a[s] = (unsigned)(g * PP_REGION + fr * ROWB) + ks;
         rd_b[s] = (unsigned)(PP_BOFF + (32 * wn + fr) * ROWB) + ks;
     }
-    auto read_a = [&](int reg) {        // the 64 rows of region A<reg> that belong to this wave: 2 row tiles x 4 k steps
+    auto read_a = [&](int h) {          // K half h of the wave's four row tiles
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) fa[i2][s] = *reinterpret_cast<const u32x4*>(smem + rd_a[s] + reg * PP_REGION + i2 * 32 * ROWB);
+            for (int sh = 0; sh < 2; ++sh) fa[i][sh] = *reinterpret_cast<const u32x4*>(smem + rd_a[2 * h + sh] + i * 32 * ROWB);
     };
-    auto read_b = [&](int reg, u32x4 (&fb)[4]) {
+    auto read_b = [&](int j, int h) {   // K half h of column half j
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const u32x4*>(smem + rd_b[s] + reg * PP_REGION);
+        for (int sh = 0; sh < 2; ++sh) fb[sh] = *reinterpret_cast<const u32x4*>(smem + rd_b[2 * h + sh] + j * PP_REGION);
     };
-    auto mm = [&](int qi, int qj, const u32x4 (&fb)[4]) {
+    auto mm = [&](int j) {
         if (PRIO) __builtin_amdgcn_s_setprio(1);
+#ifdef HN_PP_MMORD          // measurement builds: the two k steps of an accumulator back to back instead of four MFMAs apart
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
-                acc[2 * qi + i2][qj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i2][s]), __builtin_bit_cast(bf16x8, fb[s]),
-                                                                              acc[2 * qi + i2][qj], 0, 0, 0);
+            for (int sh = 0; sh < 2; ++sh)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][sh]), __builtin_bit_cast(bf16x8, fb[sh]), acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][sh]), __builtin_bit_cast(bf16x8, fb[sh]), acc[i][j], 0, 0, 0);
+#endif
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -309,46 +330,47 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         }
     };
 
-    // ---- prologue: chunk 0 completely, chunk 1 without its A1 (phase 1 of chunk 0 brings that) ----
+    // ---- prologue: chunk 0 completely, A0 of chunk 1 (phases 1-3 of chunk 0 bring its other regions) ----
     setup(ivb);
     tap_offsets(0, 0);
-    issue_a(0, 0); issue_b(0, 0); issue_b(0, 1); issue_a(0, 1);
+    issue_a(0, 0); issue_a(0, 1); issue_b(0, 0); issue_b(0, 1);
     next_issue_chunk();
-    issue_a(1, 0); issue_b(1, 0); issue_b(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // chunk 0 has landed (this wave's pieces); chunk 1's six stay in flight
+    issue_a(1, 0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
     pp_bar();
     if (g == 1) pp_bar();                                  // group 1 runs one barrier behind group 0 from here on
 
     int buf = 0;
     while (true) {
-        // ---- phase 1: quadrant (A0, B0) ----
-        read_a(0);
-        read_b(0, fb0);
-        issue_a(buf ^ 1, 1);                               // A1 of the next chunk (its other three regions went out during the previous chunk)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- phase 1: (j 0, K half 0) ----
+        if (!(abl & 2)) read_a(0);
+        if (!(abl & 2)) read_b(0, 0);
+        if (!(abl & 1)) issue_a(buf ^ 1, 1);                               // A1 of the next chunk
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the two newest regions: B1 of THIS chunk is complete (read in phase 2)
+        pp_bar();                                          // (the fragment reads return behind the barrier, while the partner issues its loads)
+        if (!(abl & 8)) mm(0);
         pp_bar();
-        mm(0, 0, fb0);
+        // ---- phase 2: (j 1, K half 0) ----
+        if (!(abl & 2)) read_b(1, 0);
+        if (!(abl & 1)) issue_b(buf ^ 1, 0);                               // B0 of the next chunk
         pp_bar();
-        // ---- phase 2: quadrant (A0, B1); the loader moves on to the chunk after next ----
-        read_b(1, fb1);
+        if (!(abl & 8)) mm(1);
+        pp_bar();
+        // ---- phase 3: (j 0, K half 1): last reads of A0, A1, B0 ----
+        if (!(abl & 2)) read_a(1);
+        if (!(abl & 2)) read_b(0, 1);
+        if (!(abl & 1)) issue_b(buf ^ 1, 1);                               // B1 of the next chunk
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 is re-filled right behind it
+        pp_bar();
+        if (!(abl & 8)) mm(0);
+        pp_bar();
+        // ---- phase 4: (j 1, K half 1); the loader moves on to the chunk after next ----
+        if (!(abl & 2)) read_b(1, 1);
         next_issue_chunk();
-        issue_a(buf, 0);                                   // A0 of this buffer was last read in phase 1
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(abl & 1)) issue_a(buf, 0);                                   // A0 of the chunk after next into THIS buffer
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A0, A1, B0 of the next chunk are complete (read in its phase 1)
         pp_bar();
-        mm(0, 1, fb1);
-        pp_bar();
-        // ---- phase 3: quadrant (A1, B1) ----
-        read_a(1);
-        issue_b(buf, 0);                                   // B0: last read in phase 1 (its fragments stay in registers for phase 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        pp_bar();
-        mm(1, 1, fb1);
-        pp_bar();
-        // ---- phase 4: quadrant (A1, B0); the chunk's one counted wait ----
-        issue_b(buf, 1);                                   // B1: last read in phase 2
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three newest regions: the next chunk is complete
-        pp_bar();
-        mm(1, 0, fb0);
+        if (!(abl & 8)) mm(1);
         pp_bar();
 
         buf ^= 1;

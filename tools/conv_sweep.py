@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from horizonnet_amd import _lib  # noqa: E402
 
+if os.environ.get("SWEEP_LIB"):      # a measurement build of the library (tools/pp_ablate.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["SWEEP_LIB"])
 DEV = torch.device("cuda:0")
 B = int(os.environ.get("SWEEP_B", "32"))
 

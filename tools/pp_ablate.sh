@@ -1,0 +1,20 @@
+#!/bin/bash
+# Measurement builds of the library with parts of the ping-pong conv loop switched off (-DHN_PP_ABL=mask: 1 no LDS-DMA, 2 no
+# fragment reads, 4 no barriers, 8 no MFMAs, 16 no counted waits; results are WRONG, only the timing means something) or with
+# another MFMA order (-DHN_PP_MMORD).  Only conv_igemm_bf16_pp.hip is recompiled.  usage: tools/pp_ablate.sh build "0 1 2 4 ..."
+cd "$(dirname "$0")/.."
+if [ "$1" = "build" ]; then
+  mkdir -p tools/probe
+  for A in $2; do
+    rm -rf build/obj_abl && cp -r build/obj build/obj_abl && rm -f build/obj_abl/conv_igemm_bf16_pp.o
+    if [ "$A" = "ord" ]; then FL="-DHN_PP_MMORD"; else FL="-DHN_PP_ABL=$A"; fi
+    HN_BUILD_OUT=$PWD/tools/probe/pp_abl_$A.so HN_BUILD_OBJ=$PWD/build/obj_abl HN_BUILD_FLAGS="$FL" bash horizonnet_amd/csrc/build.sh 2>&1 | grep -v warning | tail -1
+  done
+  rm -rf build/obj_abl
+  exit 0
+fi
+# on the GPU box: tools/pp_ablate.sh run "0 1 2 ..." SHAPES
+for A in $2; do
+  echo "## ablation $A"
+  SWEEP_LIB=tools/probe/pp_abl_$A.so SWEEP_NOASSERT=1 SWEEP_ONLY=$3 SWEEP_VARIANTS=4 timeout -k 5 120 python tools/conv_sweep.py 2>&1 | grep -v "^#\|MISMATCH\|amdgpu.ids"
+done
