@@ -11,11 +11,13 @@
 //     A phase = one 32-column half (j) of the wave's 128x64 tile over one half (h) of the 64-deep K chunk: 4 row tiles x 2 k
 //     steps = 8 MFMAs on FOUR independent accumulators; order (j0,h0) (j1,h0) (j0,h1) (j1,h1) keeps k ascending per
 //     accumulator.  Fragment reads per phase: 8 A + 2 B, 2 B, 8 A + 2 B, 2 B (the A fragments of a K half serve both j).
-//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt) and two counted
+//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt) and ONE counted
 //     s_waitcnt vmcnt(4) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (the rows of wave group 0 / 1),
-//     B0 / B1 (left / right 32 columns of every wave's 64) -- and every phase re-fills ONE region (two 1 KiB pieces per wave):
-//     A1, B0, B1 of the next chunk in phases 1-3 (into the other buffer), A0 of the chunk after next in phase 4 (this buffer's
-//     A0 had its last read in phase 3).  Activation pieces have 3-4 phases to land, weight pieces (L2 hits) 2.
+//     B0 / B1 (left / right 32 columns of every wave's 64).  The two load blocks with ten fragment reads issue nothing else; the
+//     two with two reads issue the LDS-DMA (four 1 KiB pieces per wave): phase 2 the weights of the next chunk (other buffer),
+//     phase 4 the activations of the chunk after next (this buffer: their last reads were in phase 3).  Activation pieces have
+//     five phases to land, weight pieces (L2 hits) two to three.  The tap arithmetic of the activation cursor (circular W
+//     padding, H range check) rides in the shadow of the MFMA blocks of phases 2 and 3, not in a load block.
 //   * The chunk stream does not stop at a tile boundary: the persistent workgroup's loader runs two chunks ahead of its MFMAs,
 //     INTO THE NEXT TILE (no prologue bubble per tile; the last tile's surplus pieces are out-of-range loads = zero fill).
 //   * Epilogue without workgroup barriers: every wave transposes its own accumulators through a private 4 KiB slab (16 rows x
@@ -70,6 +72,22 @@ __device__ __forceinline__ void pp_bar_raw()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
+// measurement builds (-DHN_PP_STAMP, tools/pp_stamps.py): s_memtime at the start / end of every load block and MFMA block of the first
+// PP_STAMP_CHUNKS chunks of a workgroup's stream; the counter read is asynchronous (SMEM) and is only consumed behind the MFMA
+// block, after the lgkmcnt(0) that block needs anyway; 16 stamps per chunk leave through the wave's (idle) epilogue slab.
+#ifdef HN_PP_STAMP
+constexpr int PP_STAMP_CHUNKS = 24;
+#define PP_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(var) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_STAMP_FLUSH(ph) do { \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (lane == 0 && gchunk < PP_STAMP_CHUNKS) { \
+            unsigned long long* sl = reinterpret_cast<unsigned long long*>(smem + PP_SLAB + wave * 4096); \
+            sl[4 * (ph) + 0] = st_c; sl[4 * (ph) + 1] = st_d; sl[4 * (ph) + 2] = st_a; sl[4 * (ph) + 3] = st_b; } } while (0)
+#else
+#define PP_STAMP(var) do {} while (0)
+#define PP_STAMP_FLUSH(ph) do {} while (0)
+#endif
+
 #define pp_bar() do { if (!(abl & 4)) pp_bar_raw(); else __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // PRIO: s_setprio(1) around the MFMA block of a phase (the partner wave is in its load block meanwhile)
@@ -106,6 +124,10 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
     const int nwg = (int)gridDim.x;
 
+    // power-of-two fast paths of the index arithmetic (every grid of this network; anything else takes the divisions)
+    const int wo_sh = (p.Wo & (p.Wo - 1)) == 0 ? __builtin_ctz(p.Wo) : -1;
+    const int ho_sh = (p.Ho & (p.Ho - 1)) == 0 ? __builtin_ctz(p.Ho) : -1;
+    const int nt_sh = (NT & (NT - 1)) == 0 ? __builtin_ctz(NT) : -1;
     auto tile_coords = [&](int vb, int& m0, int& n0) {
         int bid = vb;
         if (p.xcd_swizzle) {
@@ -113,98 +135,113 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
             const int xcd = bid & 7, idx = bid >> 3;
             bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-        const int nt = bid % NT;
-        const int mt = bid / NT;
-        m0 = __builtin_amdgcn_readfirstlane(mt * 256);      // (the division expands to VALU code: pin the results back to SGPRs, or every
+        const int mt = nt_sh >= 0 ? bid >> nt_sh : bid / NT;
+        const int nt = bid - mt * NT;
+        m0 = __builtin_amdgcn_readfirstlane(mt * 256);      // (a division expands to VALU code: pin the results back to SGPRs, or every
         n0 = __builtin_amdgcn_readfirstlane(nt * 256);      //  buffer descriptor derived from them needs a waterfall loop around its DMA)
     };
 
-    // ---- loader state: the tile / chunk the NEXT LDS-DMA pieces belong to (runs two chunks ahead of the MFMAs) ----
-    // A rows of this thread: tile rows lrow + 64 k, k = 2 region + pass (region A0 = rows 0..127 = wave group 0, A1 = group 1)
-    // B rows (output channels): tile columns 128 pass + 32 region + 64 (lrow >> 5) + (lrow & 31), k = 2 pass + region
-    int ivb = (int)blockIdx.x;
-    bool ivalid = true;
-    int ikc = 0;
+    // ---- loader state: two cursors that run ahead of the MFMAs, INTO THE NEXT TILE ----
+    // A cursor (activations): rows of this thread = tile rows lrow + 64 k, k = 2 region + pass (region A0 = rows 0..127 = wave
+    //   group 0, A1 = group 1); advanced in phase 2 (between A1 of chunk G+1 in phase 1 and A0 of chunk G+2 in phase 4)
+    // B cursor (weights): tile columns 128 pass + 32 region + 64 (lrow >> 5) + (lrow & 31), k = 2 pass + region; advanced in
+    //   phase 4 (behind B1 of chunk G+1 in phase 3)
+    constexpr int ROW_DEAD = -(1 << 24);                    // a_hi0 of a row beyond M (or beyond the last tile): every tap is out of range
+    const unsigned xs2 = (unsigned)p.xstride * 2u;
+    int avb = (int)blockIdx.x, akc = 0;
     int dh = 0, dw = 0, c0 = 0;
     u32x4 rsrc_a, rsrc_w;
-    int a_pix0[4], a_hi0[4], a_wi0[4];
+    unsigned a_base[4];                                     // byte offset of (image, pixel 0, this lane's 16-byte piece) behind rsrc_a
+    int a_hi0[4], a_wi0[4];
     unsigned a_off[4], w_off[4];
+    int bvb = (int)blockIdx.x, bkc = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = 128 * (k >> 1) + 32 * (k & 1) + 64 * (lrow >> 5) + (lrow & 31);
         w_off[k] = (unsigned)(c * p.K + lcol * 8) * 2u;
     }
-    auto tap_offsets = [&](int th, int tw) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int hi = a_hi0[k] + th;
-            int wi = a_wi0[k] + tw;
-            wi = wi < 0 ? wi + p.Wi : wi;
-            wi = wi >= p.Wi ? wi - p.Wi : wi;
-            const bool ok = a_pix0[k] >= 0 && ((unsigned)hi < (unsigned)p.Hi);
-            const unsigned pix = (unsigned)(a_pix0[k] + hi * p.Wi + wi);
-            a_off[k] = ok ? (pix * (unsigned)p.xstride + (unsigned)lcol * 8u) * 2u : OOB;
+    auto tap_rows = [&](int k0) {                           // rows k0, k0 + 1 at the cursor's tap (dh, dw): branch-free, full-rate VALU only
+#pragma unroll                                             // (this runs in the shadow of an MFMA block)
+        for (int k = k0; k < k0 + 2; ++k) {
+            const int h = a_hi0[k] + dh;
+            int t = a_wi0[k] + dw;
+            t += t < 0 ? p.Wi : 0;
+            t -= t >= p.Wi ? p.Wi : 0;
+            const unsigned pix = __umul24((unsigned)h, (unsigned)p.Wi) + (unsigned)t;       // < 2^24 for a valid row (checked by the launcher)
+            const unsigned off = __umul24(pix, xs2) + a_base[k];
+            a_off[k] = (unsigned)h < (unsigned)p.Hi ? off : OOB;
         }
     };
-    auto setup = [&](int vb) {
+    auto setup_a = [&](int vb) {
         int m0, n0;
         tile_coords(vb, m0, n0);
-        const int b_first = __builtin_amdgcn_readfirstlane(m0 / hw_out);
+        const int b_first = __builtin_amdgcn_readfirstlane(wo_sh >= 0 && ho_sh >= 0 ? m0 >> (wo_sh + ho_sh) : m0 / hw_out);
         rsrc_a = pp_rsrc(p.x + (size_t)b_first * img_elems);
-        rsrc_w = pp_rsrc(p.w + (size_t)n0 * p.K);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int m = m0 + lrow + 64 * k;
-            if (m < p.M) {
-                const int wo = m % p.Wo;
-                const int t = m / p.Wo;
-                const int ho = t % p.Ho;
-                const int b = t / p.Ho;
-                a_pix0[k] = (b - b_first) * p.Hi * p.Wi;
-                a_hi0[k] = ho * p.sh - p.ph;
-                a_wi0[k] = wo * p.sw - p.pw;
+            int wo, ho, b;
+            if (wo_sh >= 0 && ho_sh >= 0) {
+                wo = m & (p.Wo - 1);
+                const int t = m >> wo_sh;
+                ho = t & (p.Ho - 1);
+                b = t >> ho_sh;
             } else {
-                a_pix0[k] = -1;
-                a_hi0[k] = 0;
-                a_wi0[k] = 0;
+                wo = m % p.Wo;
+                const int t = m / p.Wo;
+                ho = t % p.Ho;
+                b = t / p.Ho;
             }
+            a_base[k] = (unsigned)((b - b_first) * p.Hi * p.Wi) * xs2 + (unsigned)lcol * 16u;
+            a_hi0[k] = m < p.M ? ho * p.sh - p.ph : ROW_DEAD;
+            a_wi0[k] = wo * p.sw - p.pw;
         }
         dh = 0; dw = 0; c0 = 0;
     };
-    auto next_issue_chunk = [&]() {
-        bool retap = p.KH * p.KW > 1;
-        if (++ikc == p.nk) {
-            ikc = 0;
-            ivb += nwg;
-            ivalid = ivb < total;
-            if (ivalid) setup(ivb);
-            retap = true;
+    auto advance_a = [&]() {                                // scalar part; tap_rows() follows in the shadow of the next two MFMA blocks
+        if (++akc == p.nk) {
+            akc = 0;
+            avb += nwg;
+            if (avb < total) {
+                setup_a(avb);
+            } else {                     // past the workgroup's last tile: the surplus pieces are out-of-range loads (zero fill)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a_hi0[k] = ROW_DEAD;
+            }
         } else {
             if (++dw == p.KW) {          // taps inner, 64-channel chunks outer (conv_igemm_bf16.hip fetch())
                 dw = 0;
                 if (++dh == p.KH) { dh = 0; c0 += BKE; }
             }
         }
-        // (ONE call site behind the join: with tap_offsets at the end of both branches hipcc treats the loader's scalars as
-        //  divergent and wraps every LDS-DMA in a waterfall loop)
-        if (retap) tap_offsets(dh, dw);
     };
-    // region `reg` (0 / 1) of the loader's current chunk -> chunk buffer `buf`: two 1 KiB pieces per wave
+    auto setup_b = [&](int vb) {
+        int m0, n0;
+        tile_coords(vb, m0, n0);
+        rsrc_w = pp_rsrc(p.w + (size_t)n0 * p.K);
+    };
+    auto advance_b = [&]() {
+        if (++bkc == p.nk) {
+            bkc = 0;
+            bvb += nwg;
+            if (bvb < total) {
+                setup_b(bvb);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w_off[k] = OOB;
+            }
+        }
+    };
+    // region `reg` (0 / 1) of the cursor's chunk -> chunk buffer `buf`: two 1 KiB pieces per wave
     auto issue_a = [&](int buf, int reg) {
         const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + reg * PP_REGION + wave * 1024);
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const unsigned o0 = ivalid ? a_off[0 + ps] : OOB, o1 = ivalid ? a_off[2 + ps] : OOB;
-            pp_dma16(rsrc_a, dst + ps * 8192, reg ? o1 : o0, (unsigned)c0 * 2u);
-        }
+        for (int ps = 0; ps < 2; ++ps) pp_dma16(rsrc_a, dst + ps * 8192, reg ? a_off[2 + ps] : a_off[ps], (unsigned)c0 * 2u);
     };
     auto issue_b = [&](int buf, int reg) {
         const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + PP_BOFF + reg * PP_REGION + wave * 1024);
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const unsigned o0 = ivalid ? w_off[0 + 2 * ps] : OOB, o1 = ivalid ? w_off[1 + 2 * ps] : OOB;
-            pp_dma16(rsrc_w, dst + ps * 8192, reg ? o1 : o0, (unsigned)ikc * (unsigned)ROWB);
-        }
+        for (int ps = 0; ps < 2; ++ps) pp_dma16(rsrc_w, dst + ps * 8192, reg ? w_off[1 + 2 * ps] : w_off[2 * ps], (unsigned)bkc * (unsigned)ROWB);
     };
 
     // ---- MFMA side ----
@@ -240,7 +277,10 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh) fb[sh] = *reinterpret_cast<const u32x4*>(smem + rd_b[2 * h + sh] + j * PP_REGION);
     };
-    auto mm = [&](int j) {
+    // one MFMA block: column half j, the K half in fa / fb.  TAPS >= 0: two rows of the A cursor's tap arithmetic ride in the shadow
+    // of the MFMAs (one MFMA, then up to four VALU instructions, ...) instead of lengthening a load block
+    auto mm = [&](int j, auto taps_c) {
+        constexpr int TAPS = decltype(taps_c)::value;
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #ifdef HN_PP_MMORD          // measurement builds: the two k steps of an accumulator back to back instead of four MFMAs apart
 #pragma unroll
@@ -255,8 +295,17 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
             for (int i = 0; i < 4; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][sh]), __builtin_bit_cast(bf16x8, fb[sh]), acc[i][j], 0, 0, 0);
 #endif
+        if constexpr (TAPS >= 0) {
+            tap_rows(TAPS);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // up to four VALU
+            }
+        }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
+    using NoTaps = std::integral_constant<int, -1>;
 
     // ---- epilogue of the wave's 128 x 64 tile: 8 rounds of 16 rows through the wave's slab ----
     auto epilogue = [&](int em0, int en0, auto has_res_c) {
@@ -330,52 +379,86 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         }
     };
 
-    // ---- prologue: chunk 0 completely, A0 of chunk 1 (phases 1-3 of chunk 0 bring its other regions) ----
-    setup(ivb);
-    tap_offsets(0, 0);
+    // ---- prologue: chunk 0 completely, the activations of chunk 1 (phase 2 of chunk 0 brings its weights) ----
+    setup_a(avb);
+    setup_b(bvb);
+    tap_rows(0); tap_rows(2);
     issue_a(0, 0); issue_a(0, 1); issue_b(0, 0); issue_b(0, 1);
-    next_issue_chunk();
-    issue_a(1, 0);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
+    advance_a();
+    tap_rows(0); tap_rows(2);
+    advance_b();
+    issue_a(1, 0); issue_a(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
     pp_bar();
     if (g == 1) pp_bar();                                  // group 1 runs one barrier behind group 0 from here on
 
     int buf = 0;
+#ifdef HN_PP_STAMP
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0;
+    int gchunk = 0;
+#endif
     while (true) {
-        // ---- phase 1: (j 0, K half 0) ----
+        // ---- phase 1: (j 0, K half 0): ten fragment reads, nothing else ----
+        PP_STAMP(st_c);
         if (!(abl & 2)) read_a(0);
         if (!(abl & 2)) read_b(0, 0);
-        if (!(abl & 1)) issue_a(buf ^ 1, 1);                               // A1 of the next chunk
-        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the two newest regions: B1 of THIS chunk is complete (read in phase 2)
+        PP_STAMP(st_d);
         pp_bar();                                          // (the fragment reads return behind the barrier, while the partner issues its loads)
-        if (!(abl & 8)) mm(0);
+        PP_STAMP(st_a);
+        if (!(abl & 8)) mm(0, NoTaps{});
+        PP_STAMP(st_b);
+        PP_STAMP_FLUSH(0);
         pp_bar();
-        // ---- phase 2: (j 1, K half 0) ----
+        // ---- phase 2: (j 1, K half 0): the weights of the next chunk; the A cursor moves on to the chunk after next ----
+        PP_STAMP(st_c);
         if (!(abl & 2)) read_b(1, 0);
-        if (!(abl & 1)) issue_b(buf ^ 1, 0);                               // B0 of the next chunk
+        if (!(abl & 1)) { issue_b(buf ^ 1, 0); issue_b(buf ^ 1, 1); }
+        advance_b();
+        advance_a();
+        PP_STAMP(st_d);
         pp_bar();
-        if (!(abl & 8)) mm(1);
+        PP_STAMP(st_a);
+        if (!(abl & 8)) mm(1, std::integral_constant<int, 0>{});           // + tap arithmetic of rows 0, 1
+        PP_STAMP(st_b);
+        PP_STAMP_FLUSH(1);
         pp_bar();
         // ---- phase 3: (j 0, K half 1): last reads of A0, A1, B0 ----
+        PP_STAMP(st_c);
         if (!(abl & 2)) read_a(1);
         if (!(abl & 2)) read_b(0, 1);
-        if (!(abl & 1)) issue_b(buf ^ 1, 1);                               // B1 of the next chunk
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 is re-filled right behind it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 / A1 are re-filled right behind it
+        PP_STAMP(st_d);
         pp_bar();
-        if (!(abl & 8)) mm(0);
+        PP_STAMP(st_a);
+        if (!(abl & 8)) mm(0, std::integral_constant<int, 2>{});           // + tap arithmetic of rows 2, 3
+        PP_STAMP(st_b);
+        PP_STAMP_FLUSH(2);
         pp_bar();
-        // ---- phase 4: (j 1, K half 1); the loader moves on to the chunk after next ----
+        // ---- phase 4: (j 1, K half 1): the activations of the chunk after next into THIS buffer; the chunk's one counted wait ----
+        PP_STAMP(st_c);
         if (!(abl & 2)) read_b(1, 1);
-        next_issue_chunk();
-        if (!(abl & 1)) issue_a(buf, 0);                                   // A0 of the chunk after next into THIS buffer
-        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A0, A1, B0 of the next chunk are complete (read in its phase 1)
+        if (!(abl & 1)) { issue_a(buf, 0); issue_a(buf, 1); }
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but these four pieces: the next chunk is complete (read from its phase 1 on)
+        PP_STAMP(st_d);
         pp_bar();
-        if (!(abl & 8)) mm(1);
+        PP_STAMP(st_a);
+        if (!(abl & 8)) mm(1, NoTaps{});
+        PP_STAMP(st_b);
+        PP_STAMP_FLUSH(3);
         pp_bar();
 
         buf ^= 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) { rd_a[s] ^= (unsigned)PP_BUF; rd_b[s] ^= (unsigned)PP_BUF; }
+#ifdef HN_PP_STAMP
+        if (p.trace && gchunk < PP_STAMP_CHUNKS && blockIdx.x < 64) {
+            if (lane < 16) {
+                const unsigned long long* sl = reinterpret_cast<const unsigned long long*>(smem + PP_SLAB + wave * 4096);
+                p.trace[(((size_t)blockIdx.x * 8 + wave) * PP_STAMP_CHUNKS + gchunk) * 16 + lane] = sl[lane];
+            }
+        }
+        ++gchunk;
+#endif
         if (++ckc == p.nk) {                               // tile finished
             ckc = 0;
             if (g == 0) pp_bar();                          // wait for group 1's last MFMA block: both epilogues run at once
