@@ -11,13 +11,14 @@
 //     A phase = one 32-column half (j) of the wave's 128x64 tile over one half (h) of the 64-deep K chunk: 4 row tiles x 2 k
 //     steps = 8 MFMAs on FOUR independent accumulators; order (j0,h0) (j1,h0) (j0,h1) (j1,h1) keeps k ascending per
 //     accumulator.  Fragment reads per phase: 8 A + 2 B, 2 B, 8 A + 2 B, 2 B (the A fragments of a K half serve both j).
-//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt) and ONE counted
+//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt) and two counted
 //     s_waitcnt vmcnt(4) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (the rows of wave group 0 / 1),
-//     B0 / B1 (left / right 32 columns of every wave's 64).  The two load blocks with ten fragment reads issue nothing else; the
-//     two with two reads issue the LDS-DMA (four 1 KiB pieces per wave): phase 2 the weights of the next chunk (other buffer),
-//     phase 4 the activations of the chunk after next (this buffer: their last reads were in phase 3).  Activation pieces have
-//     five phases to land, weight pieces (L2 hits) two to three.  The tap arithmetic of the activation cursor (circular W
-//     padding, H range check) rides in the shadow of the MFMA blocks of phases 2 and 3, not in a load block.
+//     B0 / B1 (left / right 32 columns of every wave's 64) -- and every load block re-fills ONE region (two 1 KiB pieces per
+//     wave; measured with tools/pp_stamps.py: a piece costs its wave ~50 cycles, a load block with four of them outlasts the
+//     partner's MFMA block): A1, B0, B1 of the next chunk in phases 1-3 (other buffer), A0 of the chunk after next in phase 4
+//     (this buffer's A0 had its last read in phase 3).  Activation pieces have 3-4 phases to land, weight pieces (L2 hits) 2.
+//     The tap arithmetic of the activation cursor (circular W padding, H range check) rides in the shadow of the MFMA blocks
+//     of phases 2 and 3, not in a load block.
 //   * The chunk stream does not stop at a tile boundary: the persistent workgroup's loader runs two chunks ahead of its MFMAs,
 //     INTO THE NEXT TILE (no prologue bubble per tile; the last tile's surplus pieces are out-of-range loads = zero fill).
 //   * Epilogue without workgroup barriers: every wave transposes its own accumulators through a private 4 KiB slab (16 rows x
@@ -72,20 +73,14 @@ __device__ __forceinline__ void pp_bar_raw()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
-// measurement builds (-DHN_PP_STAMP, tools/pp_stamps.py): s_memtime at the start / end of every load block and MFMA block of the first
-// PP_STAMP_CHUNKS chunks of a workgroup's stream; the counter read is asynchronous (SMEM) and is only consumed behind the MFMA
-// block, after the lgkmcnt(0) that block needs anyway; 16 stamps per chunk leave through the wave's (idle) epilogue slab.
+// measurement builds (-DHN_PP_STAMP=1|2, tools/pp_stamps.py): s_memtime at every barrier RELEASE (1: the starts of the four load blocks
+// and the four MFMA blocks of a chunk) or at every barrier ARRIVAL (2: their ends), for the first PP_STAMP_CHUNKS chunks of a
+// workgroup's stream.  The counter read is asynchronous (SMEM): the eight values stay in SGPRs and are consumed ONCE per chunk.
 #ifdef HN_PP_STAMP
 constexpr int PP_STAMP_CHUNKS = 24;
-#define PP_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(var) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_STAMP_FLUSH(ph) do { \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        if (lane == 0 && gchunk < PP_STAMP_CHUNKS) { \
-            unsigned long long* sl = reinterpret_cast<unsigned long long*>(smem + PP_SLAB + wave * 4096); \
-            sl[4 * (ph) + 0] = st_c; sl[4 * (ph) + 1] = st_d; sl[4 * (ph) + 2] = st_a; sl[4 * (ph) + 3] = st_b; } } while (0)
+#define PP_STAMP_AT(kind, idx) do { if (HN_PP_STAMP == (kind)) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(st[idx]) : : "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
-#define PP_STAMP(var) do {} while (0)
-#define PP_STAMP_FLUSH(ph) do {} while (0)
+#define PP_STAMP_AT(kind, idx) do {} while (0)
 #endif
 
 #define pp_bar() do { if (!(abl & 4)) pp_bar_raw(); else __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -208,11 +203,14 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a_hi0[k] = ROW_DEAD;
             }
-        } else {
-            if (++dw == p.KW) {          // taps inner, 64-channel chunks outer (conv_igemm_bf16.hip fetch())
-                dw = 0;
-                if (++dh == p.KH) { dh = 0; c0 += BKE; }
-            }
+        } else {                         // taps inner, 64-channel chunks outer (conv_igemm_bf16.hip fetch()); selects, not branches
+            const int dw1 = dw + 1;
+            const bool ww = dw1 == p.KW;
+            dw = ww ? 0 : dw1;
+            const int dh1 = dh + (ww ? 1 : 0);
+            const bool wh = dh1 == p.KH;
+            dh = wh ? 0 : dh1;
+            c0 += wh ? BKE : 0;
         }
     };
     auto setup_b = [&](int vb) {
@@ -379,7 +377,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         }
     };
 
-    // ---- prologue: chunk 0 completely, the activations of chunk 1 (phase 2 of chunk 0 brings its weights) ----
+    // ---- prologue: chunk 0 completely, A0 of chunk 1 (phases 1-3 of chunk 0 bring its other regions) ----
     setup_a(avb);
     setup_b(bvb);
     tap_rows(0); tap_rows(2);
@@ -387,75 +385,84 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     advance_a();
     tap_rows(0); tap_rows(2);
     advance_b();
-    issue_a(1, 0); issue_a(1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
+    issue_a(1, 0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
     pp_bar();
     if (g == 1) pp_bar();                                  // group 1 runs one barrier behind group 0 from here on
 
     int buf = 0;
 #ifdef HN_PP_STAMP
-    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0;
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int gchunk = 0;
 #endif
     while (true) {
-        // ---- phase 1: (j 0, K half 0): ten fragment reads, nothing else ----
-        PP_STAMP(st_c);
+        // ---- phase 1: (j 0, K half 0) ----
+        PP_STAMP_AT(1, 0);
         if (!(abl & 2)) read_a(0);
         if (!(abl & 2)) read_b(0, 0);
-        PP_STAMP(st_d);
+        if (!(abl & 1)) issue_a(buf ^ 1, 1);                               // A1 of the next chunk
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the two newest regions: B1 of THIS chunk is complete (read in phase 2)
+#ifdef HN_PP_LGKB          // measurement builds: every phase waits for its fragment reads in front of its barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP_AT(2, 0);
         pp_bar();                                          // (the fragment reads return behind the barrier, while the partner issues its loads)
-        PP_STAMP(st_a);
+        PP_STAMP_AT(1, 1);
         if (!(abl & 8)) mm(0, NoTaps{});
-        PP_STAMP(st_b);
-        PP_STAMP_FLUSH(0);
+        PP_STAMP_AT(2, 1);
         pp_bar();
-        // ---- phase 2: (j 1, K half 0): the weights of the next chunk; the A cursor moves on to the chunk after next ----
-        PP_STAMP(st_c);
+        // ---- phase 2: (j 1, K half 0); the A cursor moves on to the chunk after next ----
+        PP_STAMP_AT(1, 2);
         if (!(abl & 2)) read_b(1, 0);
-        if (!(abl & 1)) { issue_b(buf ^ 1, 0); issue_b(buf ^ 1, 1); }
-        advance_b();
-        advance_a();
-        PP_STAMP(st_d);
+        if (!(abl & 1)) issue_b(buf ^ 1, 0);                               // B0 of the next chunk
+        advance_a();                                       // (scalars; the tap arithmetic follows in the shadow of the next two MFMA blocks)
+#ifdef HN_PP_LGKB
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP_AT(2, 2);
         pp_bar();
-        PP_STAMP(st_a);
+        PP_STAMP_AT(1, 3);
         if (!(abl & 8)) mm(1, std::integral_constant<int, 0>{});           // + tap arithmetic of rows 0, 1
-        PP_STAMP(st_b);
-        PP_STAMP_FLUSH(1);
+        PP_STAMP_AT(2, 3);
         pp_bar();
         // ---- phase 3: (j 0, K half 1): last reads of A0, A1, B0 ----
-        PP_STAMP(st_c);
+        PP_STAMP_AT(1, 4);
         if (!(abl & 2)) read_a(1);
         if (!(abl & 2)) read_b(0, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 / A1 are re-filled right behind it
-        PP_STAMP(st_d);
+        if (!(abl & 1)) issue_b(buf ^ 1, 1);                               // B1 of the next chunk
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 is re-filled right behind it
+        PP_STAMP_AT(2, 4);
         pp_bar();
-        PP_STAMP(st_a);
+        PP_STAMP_AT(1, 5);
         if (!(abl & 8)) mm(0, std::integral_constant<int, 2>{});           // + tap arithmetic of rows 2, 3
-        PP_STAMP(st_b);
-        PP_STAMP_FLUSH(2);
+        PP_STAMP_AT(2, 5);
         pp_bar();
-        // ---- phase 4: (j 1, K half 1): the activations of the chunk after next into THIS buffer; the chunk's one counted wait ----
-        PP_STAMP(st_c);
+        // ---- phase 4: (j 1, K half 1) ----
+        PP_STAMP_AT(1, 6);
         if (!(abl & 2)) read_b(1, 1);
-        if (!(abl & 1)) { issue_a(buf, 0); issue_a(buf, 1); }
-        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but these four pieces: the next chunk is complete (read from its phase 1 on)
-        PP_STAMP(st_d);
+        if (!(abl & 1)) issue_a(buf, 0);                                   // A0 of the chunk after next into THIS buffer
+        advance_b();
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A0, A1, B0 of the next chunk are complete (read in its phase 1)
+#ifdef HN_PP_LGKB
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP_AT(2, 6);
         pp_bar();
-        PP_STAMP(st_a);
+        PP_STAMP_AT(1, 7);
         if (!(abl & 8)) mm(1, NoTaps{});
-        PP_STAMP(st_b);
-        PP_STAMP_FLUSH(3);
+        PP_STAMP_AT(2, 7);
         pp_bar();
 
         buf ^= 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) { rd_a[s] ^= (unsigned)PP_BUF; rd_b[s] ^= (unsigned)PP_BUF; }
 #ifdef HN_PP_STAMP
-        if (p.trace && gchunk < PP_STAMP_CHUNKS && blockIdx.x < 64) {
-            if (lane < 16) {
-                const unsigned long long* sl = reinterpret_cast<const unsigned long long*>(smem + PP_SLAB + wave * 4096);
-                p.trace[(((size_t)blockIdx.x * 8 + wave) * PP_STAMP_CHUNKS + gchunk) * 16 + lane] = sl[lane];
-            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (p.trace && gchunk < PP_STAMP_CHUNKS && blockIdx.x < 64 && lane < 8) {
+            unsigned long long v = st[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v = lane == q ? st[q] : v;
+            p.trace[(((size_t)blockIdx.x * 8 + wave) * PP_STAMP_CHUNKS + gchunk) * 8 + lane] = v;
         }
         ++gchunk;
 #endif
