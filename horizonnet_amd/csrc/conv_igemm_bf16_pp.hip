@@ -12,13 +12,13 @@
 //     steps = 8 MFMAs on FOUR independent accumulators; order (j0,h0) (j1,h0) (j0,h1) (j1,h1) keeps k ascending per
 //     accumulator.  Fragment reads per phase: 8 A + 2 B, 2 B, 8 A + 2 B, 2 B (the A fragments of a K half serve both j).
 //   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier (no __syncthreads, whose fence drains vmcnt) and two counted
-//     s_waitcnt vmcnt(4) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (the rows of wave group 0 / 1),
-//     B0 / B1 (left / right 32 columns of every wave's 64) -- and every load block re-fills ONE region (two 1 KiB pieces per
-//     wave; measured with tools/pp_stamps.py: a piece costs its wave ~50 cycles, a load block with four of them outlasts the
-//     partner's MFMA block): A1, B0, B1 of the next chunk in phases 1-3 (other buffer), A0 of the chunk after next in phase 4
-//     (this buffer's A0 had its last read in phase 3).  Activation pieces have 3-4 phases to land, weight pieces (L2 hits) 2.
-//     The tap arithmetic of the activation cursor (circular W padding, H range check) rides in the shadow of the MFMA blocks
-//     of phases 2 and 3, not in a load block.
+//     s_waitcnt vmcnt(6) per chunk.  A chunk's operands live in four 16 KiB regions -- A0 / A1 (the rows of wave group 0 / 1),
+//     B0 / B1 (left / right 32 columns of every wave's 64).  Measured with tools/pp_stamps.py: a piece costs its wave ~50 cycles
+//     of issue and needs ~1 us (1700-1800 cycles at the sustained clock, L2 hit or not) from issue to landed, i.e. ~3 phases.  So
+//     every region goes out as early as its buffer allows and is waited for as late as the read allows: phase 4 issues the
+//     activations (A0, A1) of the chunk AFTER next into this buffer (last read in phase 3; waited for four phases later),
+//     phases 1 and 2 the weights B0 / B1 of the next chunk (waited for three phases later).  The tap arithmetic of the
+//     activation cursor (circular W padding, H range check) rides in the shadow of the MFMA blocks of phases 2 and 3.
 //   * The chunk stream does not stop at a tile boundary: the persistent workgroup's loader runs two chunks ahead of its MFMAs,
 //     INTO THE NEXT TILE (no prologue bubble per tile; the last tile's surplus pieces are out-of-range loads = zero fill).
 //   * Epilogue without workgroup barriers: every wave transposes its own accumulators through a private 4 KiB slab (16 rows x
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         }
     };
 
-    // ---- prologue: chunk 0 completely, A0 of chunk 1 (phases 1-3 of chunk 0 bring its other regions) ----
+    // ---- prologue: chunk 0 completely, the activations of chunk 1 (phases 1 and 2 of chunk 0 bring its weights) ----
     setup_a(avb);
     setup_b(bvb);
     tap_rows(0); tap_rows(2);
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     advance_a();
     tap_rows(0); tap_rows(2);
     advance_b();
-    issue_a(1, 0);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
+    issue_a(1, 0); issue_a(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // chunk 0 has landed (this wave's pieces)
     pp_bar();
     if (g == 1) pp_bar();                                  // group 1 runs one barrier behind group 0 from here on
 
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         PP_STAMP_AT(1, 0);
         if (!(abl & 2)) read_a(0);
         if (!(abl & 2)) read_b(0, 0);
-        if (!(abl & 1)) issue_a(buf ^ 1, 1);                               // A1 of the next chunk
-        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the two newest regions: B1 of THIS chunk is complete (read in phase 2)
+        if (!(abl & 1)) issue_b(buf ^ 1, 0);                               // B0 of the next chunk
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three newest regions: B1 of THIS chunk is complete (read in phase 2)
 #ifdef HN_PP_LGKB          // measurement builds: every phase waits for its fragment reads in front of its barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         // ---- phase 2: (j 1, K half 0); the A cursor moves on to the chunk after next ----
         PP_STAMP_AT(1, 2);
         if (!(abl & 2)) read_b(1, 0);
-        if (!(abl & 1)) issue_b(buf ^ 1, 0);                               // B0 of the next chunk
+        if (!(abl & 1)) issue_b(buf ^ 1, 1);                               // B1 of the next chunk
         advance_a();                                       // (scalars; the tap arithmetic follows in the shadow of the next two MFMA blocks)
 #ifdef HN_PP_LGKB
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         PP_STAMP_AT(1, 4);
         if (!(abl & 2)) read_a(1);
         if (!(abl & 2)) read_b(0, 1);
-        if (!(abl & 1)) issue_b(buf ^ 1, 1);                               // B1 of the next chunk
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 is re-filled right behind it
+        advance_b();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // returned BEFORE the barrier: A0 / A1 are re-filled right behind it
         PP_STAMP_AT(2, 4);
         pp_bar();
         PP_STAMP_AT(1, 5);
@@ -440,9 +440,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         // ---- phase 4: (j 1, K half 1) ----
         PP_STAMP_AT(1, 6);
         if (!(abl & 2)) read_b(1, 1);
-        if (!(abl & 1)) issue_a(buf, 0);                                   // A0 of the chunk after next into THIS buffer
-        advance_b();
-        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A0, A1, B0 of the next chunk are complete (read in its phase 1)
+        if (!(abl & 1)) { issue_a(buf, 0); issue_a(buf, 1); }               // the activations of the chunk after next into THIS buffer
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but B1 of the next chunk and these four pieces: its A0, A1, B0 are complete
 #ifdef HN_PP_LGKB
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
