@@ -1209,7 +1209,7 @@ int launch_cfg_w8(const ConvArgsH& a, hipStream_t s)
 
 // Tile choice for the inference forward: a large tile only where it still fills the 256 CUs and K is deep enough to
 // amortise its prologue / epilogue.  HN_BF16_W8 = 0 disables the 8-wave kernels, 1 = 256x256, 2 = 256x128, 3 = 128x256,
-// 4 / 5 = the ping-pong persistent 256x256 kernel without / with s_setprio
+// 4 / 5 = the ping-pong persistent 256x256 kernel without / with s_setprio, 6 / 7 = the dw-reuse 3x3 kernel with 256x256 / 512x128 tiles
 // force one (A/B runs, tests).
 template <bool OUT_F32>
 int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
@@ -1231,6 +1231,7 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     const long t128x256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 128) * (Cout / 256) : 0;
     const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
     if ((force == 4 || force == 5) && t256 && a.nk >= 2) return hn_launch_conv_bf16_pp(a, OUT_F32 ? 1 : 0, force - 4, s);
+    if ((force == 6 || force == 7) && hn_conv_bf16_dwr_ok(a, force - 6)) return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, force - 6, s);
     if (force == 1 && t256) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
     if (force == 2 && t256x128) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
     if (force == 3 && t128x256) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
@@ -1238,6 +1239,12 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     // 256x256 tile wins by 10-25 % wherever it yields >= 224 workgroups (1.0-1.16 PF on the deep-K convs vs 0.8-0.96),
     // also on the HBM-bound 1x1 convs; with 128 workgroups (layer4 3x3, ghc3.0) half the CUs idle and it loses; the
     // 256x128 / 128x256 shapes (64x64 wave tiles) never beat the 4-wave 128x128 kernel and are kept for A/B runs only
+    // 3x3 convs with stride 1 along W: the activations of a filter row loaded once (conv3x3_dwr_bf16.hip); HN_BF16_DWR=0 for A/B runs
+    const char* dwe = getenv("HN_BF16_DWR");
+    const bool dwr = !(dwe && atoi(dwe) == 0);
+    if (force < 0 && dwr && t256 >= 224 && hn_conv_bf16_dwr_ok(a, 0)) return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 0, s);
+    if (force < 0 && dwr && t256 < 224 && (long)hn_cdiv(M, 512) * (Cout / 128) >= 224 && hn_conv_bf16_dwr_ok(a, 1))
+        return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 1, s);
     if (force < 0 && t256 >= 224) {
         // ping-pong persistent kernel (conv_igemm_bf16_pp.hip); HN_BF16_PP=0 for A/B runs, 2 = with s_setprio
         const char* ppe = getenv("HN_BF16_PP");

@@ -34,6 +34,7 @@
 //   WAR  a region is re-filled after a barrier that follows every reader's lgkmcnt(0) (issued before the reader's own barrier).
 #include "hn_common.h"
 #include "conv_bf16_args.h"
+#include "conv_bf16_pp.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -46,33 +47,6 @@ constexpr int PP_BOFF = 32768;
 constexpr int PP_SLAB = 131072;       // 8 wave-private epilogue slabs of 4 KiB
 constexpr int PP_LDS = 163840;
 
-// LDS-DMA piece issued from inline asm: INVISIBLE to hipcc's waitcnt pass on purpose.  With the builtin, the pass makes every
-// ds_read wait for every LDS-DMA it believes outstanding (at the loop head: vmcnt(5) ... vmcnt(0) in front of the phase-1 fragment
-// reads), which drains exactly the queue this kernel keeps in flight across its barriers.  Hidden, the queue is counted by hand
-// (one s_waitcnt vmcnt(6) per chunk); hipcc's own counted waits for ordinary loads / spills only ever see FEWER outstanding
-// operations than there are, i.e. they over-wait, never under-wait (memory operations return in order).
-__device__ __forceinline__ void pp_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff)
-{
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");       // (m0 is not used by anything else in this kernel: gfx950 DS instructions do not read it)
-}
-
-__device__ __forceinline__ u32x4 pp_rsrc(const void* base)
-{
-    const unsigned long long a = (unsigned long long)base;
-    u32x4 r;
-    r[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));      // stride 0
-    r[2] = 0x7fffffffu;                                                                       // num_records (bytes)
-    r[3] = 0x00020000u;
-    return r;
-}
-
-__device__ __forceinline__ void pp_bar_raw()
-{
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
 // measurement builds (-DHN_PP_STAMP=1|2, tools/pp_stamps.py): s_memtime at every barrier RELEASE (1: the starts of the four load blocks
 // and the four MFMA blocks of a chunk) or at every barrier ARRIVAL (2: their ends), for the first PP_STAMP_CHUNKS chunks of a
 // workgroup's stream.  The counter read is asynchronous (SMEM): the eight values stay in SGPRs and are consumed ONCE per chunk.
@@ -234,12 +208,12 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     auto issue_a = [&](int buf, int reg) {
         const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + reg * PP_REGION + wave * 1024);
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) pp_dma16(rsrc_a, dst + ps * 8192, reg ? a_off[2 + ps] : a_off[ps], (unsigned)c0 * 2u);
+        for (int ps = 0; ps < 2; ++ps) pp_dma16<HN_PP_POLICY_A>(rsrc_a, dst + ps * 8192, reg ? a_off[2 + ps] : a_off[ps], (unsigned)c0 * 2u);
     };
     auto issue_b = [&](int buf, int reg) {
         const unsigned dst = lds0 + (unsigned)(buf * PP_BUF + PP_BOFF + reg * PP_REGION + wave * 1024);
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) pp_dma16(rsrc_w, dst + ps * 8192, reg ? w_off[1 + 2 * ps] : w_off[2 * ps], (unsigned)bkc * (unsigned)ROWB);
+        for (int ps = 0; ps < 2; ++ps) pp_dma16<HN_PP_POLICY_B>(rsrc_w, dst + ps * 8192, reg ? w_off[1 + 2 * ps] : w_off[2 * ps], (unsigned)bkc * (unsigned)ROWB);
     };
 
     // ---- MFMA side ----

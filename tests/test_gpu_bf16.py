@@ -548,3 +548,48 @@ def test_pingpong_conv_bit_identical(case, monkeypatch):
             bad = torch.nonzero(d.reshape(-1, cout) > 0)
             print("first mismatches (row, col):", bad[:8].tolist(), "max", float(d.max()), "count", int((d > 0).sum()))
         assert same, (name, variant)
+
+
+DWR_CASES = [
+    # name, variant (6: 256 x 256 tiles, 7: 512 x 128), B, H, W, cin, cout, stride, residual
+    ("256sq Wo=32 every row tile is a seam", "6", 3, 16, 32, 64, 256, 1, False),
+    ("256sq Wo=64 s(2,1) ragged M", "6", 3, 10, 64, 128, 256, (2, 1), False),
+    ("256sq Wo=128 residual two column tiles", "6", 2, 8, 128, 64, 512, 1, True),
+    ("256sq persistent 384 tiles", "6", 6, 128, 128, 64, 256, 1, False),
+    ("512x128 Wo=256 s(2,1)", "7", 2, 16, 256, 64, 128, (2, 1), False),
+    ("512x128 Wo=128 residual ragged M", "7", 3, 7, 128, 128, 128, 1, True),
+    ("512x128 Wo=32 two column tiles", "7", 4, 32, 32, 64, 256, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", DWR_CASES, ids=[c[0] for c in DWR_CASES])
+def test_dw_reuse_conv_bit_identical(case, monkeypatch):
+    """conv3x3_dwr_bf16_kernel (the activations of a filter row loaded once, the dw = 0 / 2 fragments read one LDS row up / down with the
+    circular seam handled per lane; 256 x 256 and 512 x 128 tiles) against the plain 4-wave kernel: same k order -> the same bits."""
+    name, variant, B, H, W, cin, cout, stride, has_res = case
+    L = lib()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    Ho = (H + 2 - 3) // sh + 1
+    Wo = (W + 2 - 3) // sw + 1
+    xd = _rand((B, H, W, cin), 21).to(DEV).bfloat16().contiguous()
+    wd = _rand((cout, cin, 3, 3), 22, 1.0 / np.sqrt(cin * 9)).to(DEV).contiguous()
+    scr = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device=DEV)
+    sd_ = (torch.rand(cout, generator=torch.Generator().manual_seed(23)) + 0.5).to(DEV)
+    fd_ = _rand((cout,), 24, 0.2).to(DEV)
+    rd = _rand((B, Ho, Wo, cout), 25).to(DEV).bfloat16().contiguous() if has_res else None
+    outs = []
+    for v in ("0", variant, variant):
+        monkeypatch.setenv("HN_BF16_W8", v)
+        y = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.hn_conv2d_nhwc_bf16(P(xd), P(wd), P(scr), P(sd_), P(fd_), P(rd), P(y), B, H, W, cin, cout, 3, 3, sh, sw, 1, 0, sp()), "conv bf16")
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(y.float()).any()), (name, v)
+        outs.append(y)
+    for y in outs[1:]:
+        same = torch.equal(outs[0].view(torch.int16), y.view(torch.int16))
+        if not same:
+            d = (outs[0].float() - y.float()).abs().reshape(-1, cout)
+            bad = torch.nonzero(d > 0)
+            rows = torch.unique(bad[:, 0])
+            print("mismatching rows (first 16):", rows[:16].tolist(), "of", d.shape[0], "| wo of those:", (rows[:16] % Wo).tolist(), "| max", float(d.max()), "count", int((d > 0).sum()))
+        assert same, name

@@ -91,7 +91,9 @@ def main():
         row, best, ref = [], None, None
         for v in variants:
             legal = v in (0, -1) or (v in (1, 3) and cout % 256 == 0) or (v == 2 and cout % 128 == 0) or \
-                (v in (4, 5) and cout % 256 == 0 and cin * k * k >= 128)      # 4 / 5: ping-pong persistent kernel without / with s_setprio
+                (v in (4, 5) and cout % 256 == 0 and cin * k * k >= 128) or \
+                (v == 6 and k == 3 and sw == 1 and cout % 256 == 0 and 32 <= Wi <= 128) or \
+                (v == 7 and k == 3 and sw == 1 and cout % 128 == 0 and 32 <= Wi <= 256)      # 4 / 5: ping-pong kernel; 6 / 7: dw-reuse 3x3 kernel, 256x256 / 512x128 tiles
             if not legal:
                 row.append("      -      ")
                 continue

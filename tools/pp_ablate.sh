@@ -7,7 +7,7 @@ if [ "$1" = "build" ]; then
   mkdir -p tools/probe
   for A in $2; do
     rm -rf build/obj_abl && cp -r build/obj build/obj_abl && rm -f build/obj_abl/conv_igemm_bf16_pp.o
-    if [ "$A" = "ord" ]; then FL="-DHN_PP_MMORD"; elif [ "$A" = "stamp1" ] || [ "$A" = "stamp2" ]; then FL="-DHN_PP_STAMP=${A#stamp} -DHN_CONV_TRACE"; rm -f build/obj_abl/conv_igemm_bf16.o; elif [ "$A" = "lgkb" ]; then FL="-DHN_PP_LGKB"; else FL="-DHN_PP_ABL=$A"; fi
+    if [ "$A" = "ord" ]; then FL="-DHN_PP_MMORD"; elif [ "$A" = "stamp1" ] || [ "$A" = "stamp2" ]; then FL="-DHN_PP_STAMP=${A#stamp} -DHN_CONV_TRACE"; rm -f build/obj_abl/conv_igemm_bf16.o; elif [ "$A" = "lgkb" ]; then FL="-DHN_PP_LGKB"; elif [ "${A:0:3}" = "pol" ]; then FL="-DHN_PP_POLICY_A=${A:3:1} -DHN_PP_POLICY_B=${A:4:1}"; else FL="-DHN_PP_ABL=$A"; fi
     HN_BUILD_OUT=$PWD/tools/probe/pp_abl_$A.so HN_BUILD_OBJ=$PWD/build/obj_abl HN_BUILD_FLAGS="$FL" bash horizonnet_amd/csrc/build.sh 2>&1 | grep -v warning | tail -1
   done
   rm -rf build/obj_abl
