@@ -40,6 +40,7 @@ SIGNATURES = {
     "hn_forward_bf16": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hn_stem_pool_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hn_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hn_conv2d_nhwc_bf16_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "hn_workspace_bf16_pipelined_bytes": (_sz, [_i]),
     "hn_forward_bf16_submit": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
     "hn_forward_bf16_collect": (_i, [_vp, _i, _vp]),

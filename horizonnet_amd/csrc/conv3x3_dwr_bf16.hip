@@ -95,13 +95,19 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
     const int hw_out = p.Ho * p.Wo;
     const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
     const int nwg = (int)gridDim.x;
-    const int nsteps = p.nk / 3;
+    // split-K (float32 partial tiles, OUT_F32 instantiation only): a work item = (tile, K slice); a slice = nsteps_s whole steps
+    const int S = OUT_F32 && p.ksplit > 1 ? p.ksplit : 1;   // a power of two (launcher)
+    const int s_sh = __builtin_ctz(S);
+    const int nsteps_s = (p.nk / 3) >> s_sh;
+    const int nk_s = 3 * nsteps_s;
+    const int items = total << s_sh;
 
     const int wo_sh = __builtin_ctz(p.Wo);                  // Wo is a power of two here (launcher)
     const int ho_sh = (p.Ho & (p.Ho - 1)) == 0 ? __builtin_ctz(p.Ho) : -1;
     const int nt_sh = (NT & (NT - 1)) == 0 ? __builtin_ctz(NT) : -1;
-    auto tile_coords = [&](int vb, int& m0, int& n0) {
-        int bid = vb;
+    auto tile_coords = [&](int item, int& m0, int& n0, int& sl) {
+        int bid = item >> s_sh;
+        sl = item - (bid << s_sh);
         if (p.xcd_swizzle) {
             const int q = total >> 3, r = total & 7;
             const int xcd = bid & 7, idx = bid >> 3;
@@ -117,13 +123,13 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
     constexpr int ROW_DEAD = -(1 << 24);
     const unsigned xs2 = (unsigned)p.xstride * 2u;
     const unsigned rowbytes = (unsigned)p.Wi * xs2;         // one image row of the activation tensor (< 2^24, launcher)
-    int avb = (int)blockIdx.x, astep = 0;
+    int avb = (int)blockIdx.x, astep = 0;                   // (work item, step inside its K slice)
     int dh = 0, c0 = 0;
     u32x4 rsrc_a, rsrc_w;
     unsigned a_base[G::AK];                                 // byte offset of (image, row 0, pixel wo, this lane's 16-byte piece): the dw = 1 tap
     int a_hi0[G::AK];
     unsigned a_off[G::AK], w_off[G::BK2];
-    int bvb = (int)blockIdx.x, bkc = 0;
+    int bvb = (int)blockIdx.x, bkc = 0, bcnt = 0;           // (work item, chunk index inside the tile's K, chunks done of the slice)
 #pragma unroll
     for (int kb = 0; kb < G::BK2; ++kb) {                   // kb = 2 pass + region
         const int lr = 64 * (kb >> 1) + lrow;
@@ -139,8 +145,8 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
         }
     };
     auto setup_a = [&](int vb) {
-        int m0, n0;
-        tile_coords(vb, m0, n0);
+        int m0, n0, sl;
+        tile_coords(vb, m0, n0, sl);
         const int b_first = __builtin_amdgcn_readfirstlane(ho_sh >= 0 ? m0 >> (wo_sh + ho_sh) : m0 / hw_out);
         rsrc_a = pp_rsrc(p.x + (size_t)b_first * img_elems);
 #pragma unroll
@@ -153,13 +159,16 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
             a_base[k] = (unsigned)((b - b_first) * p.Hi * p.Wi + wo) * xs2 + (unsigned)lcol * 16u;
             a_hi0[k] = m < p.M ? ho * p.sh - p.ph : ROW_DEAD;
         }
-        dh = 0; c0 = 0;
+        const int step0 = sl * nsteps_s;                    // first step of the K slice: (channel chunk, filter row)
+        const int cc = step0 / 3;
+        dh = step0 - 3 * cc;
+        c0 = cc * BKE;
     };
     auto advance_a = [&]() {                                // scalar part; tap_rows() follows in the shadow of MFMA blocks
-        if (++astep == nsteps) {
+        if (++astep == nsteps_s) {
             astep = 0;
             avb += nwg;
-            if (avb < total) {
+            if (avb < items) {
                 setup_a(avb);
             } else {
 #pragma unroll
@@ -173,15 +182,17 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
         }
     };
     auto setup_b = [&](int vb) {
-        int m0, n0;
-        tile_coords(vb, m0, n0);
+        int m0, n0, sl;
+        tile_coords(vb, m0, n0, sl);
         rsrc_w = pp_rsrc(p.w + (size_t)n0 * p.K);
+        bkc = sl * nk_s;
     };
     auto advance_b = [&]() {
-        if (++bkc == p.nk) {
-            bkc = 0;
+        ++bkc;
+        if (++bcnt == nk_s) {
+            bcnt = 0;
             bvb += nwg;
-            if (bvb < total) {
+            if (bvb < items) {
                 setup_b(bvb);
             } else {
 #pragma unroll
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
     };
 
     // ---- MFMA side ----
-    int cvb = (int)blockIdx.x, cm0, cn0, ckc = 0;
-    tile_coords(cvb, cm0, cn0);
+    int cvb = (int)blockIdx.x, cm0, cn0, csl, ckc = 0;
+    tile_coords(cvb, cm0, cn0, csl);
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -269,8 +280,9 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
     using I0 = std::integral_constant<int, 0>;
 
     // ---- epilogue of the wave's 128 x 64 tile: 8 rounds of 16 rows through the wave's 4 KiB slab (see conv_igemm_bf16_pp.hip) ----
-    auto epilogue = [&](int em0, int en0, auto has_res_c) {
+    auto epilogue = [&](int em0, int en0, int esl, auto has_res_c) {
         constexpr bool HAS_RES = decltype(has_res_c)::value;
+        const bool raw = OUT_F32 && p.ksplit > 1;       // split-K partial tile: no scale / shift (the reduce kernel applies them once)
         float* slab = reinterpret_cast<float*>(smem + G::SLAB_OFF + wave * 4096);
         const int er = lane >> 3;
         const int ec = (lane & 7) * 8;
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
             sc[j] = p.scale[en0 + 64 * wn + 32 * j + fr];
             sf[j] = p.shift[en0 + 64 * wn + 32 * j + fr];
         }
+        const size_t slice_off = (size_t)esl * p.M * p.ldy;
         u32x4 rres[HAS_RES ? 8 : 1];
         auto res_load = [&](int q) {
             const int m = mrow0 + 8 * q;
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
                 for (int rr = 0; rr < 8; ++rr) {
                     const int lr16 = (rr & 3) + 8 * (rr >> 2) + 4 * half;
                     const int blk = (8 * j + (fr >> 2)) ^ (rr & 3);
-                    slab[lr16 * 64 + blk * 4 + (fr & 3)] = acc[i][j][8 * hb + rr] * sc[j] + sf[j];
+                    slab[lr16 * 64 + blk * 4 + (fr & 3)] = raw ? acc[i][j][8 * hb + rr] : acc[i][j][8 * hb + rr] * sc[j] + sf[j];
                 }
 #pragma unroll
             for (int sr = 0; sr < 2; ++sr) {
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
                 }
                 if (m < p.M) {
                     if (OUT_F32) {
-                        float* yo = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + colg;
+                        float* yo = reinterpret_cast<float*>(p.y) + slice_off + (size_t)m * p.ldy + colg;
                         *reinterpret_cast<f32x4*>(yo) = v0;
                         *reinterpret_cast<f32x4*>(yo + 4) = v1;
                     } else {
@@ -403,14 +416,14 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
             for (int s = 0; s < 4; ++s) rd_a[dw][s] += (unsigned)adelta;
         adelta = -adelta;
         ckc += 3;
-        if (ckc == p.nk) {                                 // tile finished
+        if (ckc == nk_s) {                                 // tile (K slice) finished
             ckc = 0;
             if (g == 0) pp_bar_raw();                      // wait for group 1's last MFMA block: both epilogues run at once
             if (!G::PERSIST) {                             // the slabs re-use the A buffers: every wave's surplus pieces must have landed
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 pp_bar_raw();
             }
-            if (!OUT_F32 && p.res != nullptr) epilogue(cm0, cn0, std::true_type{}); else epilogue(cm0, cn0, std::false_type{});
+            if (!OUT_F32 && p.res != nullptr) epilogue(cm0, cn0, csl, std::true_type{}); else epilogue(cm0, cn0, csl, std::false_type{});
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -418,8 +431,8 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             cvb += nwg;
-            if (cvb >= total) break;
-            tile_coords(cvb, cm0, cn0);
+            if (cvb >= items) break;
+            tile_coords(cvb, cm0, cn0, csl);
             if (g == 1) pp_bar_raw();                      // re-stagger
         }
     }
@@ -440,7 +453,7 @@ int launch_dwr(const ConvArgsH& a, hipStream_t s)
         HN_HIP(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
         attr_done[dev] = true;
     }
-    const int tiles = hn_cdiv(a.M, BM) * (a.Cout / BN);
+    const int tiles = hn_cdiv(a.M, BM) * (a.Cout / BN) * (OUT_F32 && a.ksplit > 1 ? a.ksplit : 1);      // work items
     const int cus = dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
     const int grid = G::PERSIST ? (tiles < cus ? tiles : cus) : tiles;      // 512 x 128: one tile per workgroup (the slabs alias the A buffers)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, s, a);
@@ -456,7 +469,8 @@ bool hn_conv_bf16_dwr_ok(const ConvArgsH& a, int shape)
     const int group_rows = shape == 0 ? 128 : 256;
     const int bn = shape == 0 ? 256 : 128;
     return a.KH == 3 && a.KW == 3 && a.sw == 1 && a.pw == 1 && a.ph == 1 && a.Wi == a.Wo && (a.Wo & (a.Wo - 1)) == 0 && a.Wo >= 32 &&
-           group_rows % a.Wo == 0 && a.Cout % bn == 0 && a.Cin % BKE == 0 && a.ksplit <= 1 && a.stat_sum == nullptr &&
+           group_rows % a.Wo == 0 && a.Cout % bn == 0 && a.Cin % BKE == 0 && a.stat_sum == nullptr &&
+           (a.ksplit <= 1 || ((a.ksplit & (a.ksplit - 1)) == 0 && (a.nk / 3) % a.ksplit == 0)) &&
            (long)a.Hi * a.Wi < (1L << 24) && (long)a.Wi * a.xstride * 2 < (1L << 24) && a.Hi < (1 << 20);
 }
 
@@ -464,6 +478,7 @@ int hn_launch_conv_bf16_dwr(const ConvArgsH& a, int out_f32, int shape, hipStrea
 {
     HN_REQUIRE(hn_conv_bf16_dwr_ok(a, shape), "conv bf16 (dw reuse): 3x3, stride 1 / pad 1 along W, Wo a power of two that divides the group rows");
     HN_REQUIRE(!out_f32 || a.res == nullptr, "conv bf16 (dw reuse): no residual with float32 output");
+    HN_REQUIRE(a.ksplit <= 1 || out_f32, "conv bf16 (dw reuse): split-K writes float32 partial tiles");
     if (shape == 0) return out_f32 ? launch_dwr<256, 256, true>(a, s) : launch_dwr<256, 256, false>(a, s);
     return out_f32 ? launch_dwr<512, 128, true>(a, s) : launch_dwr<512, 128, false>(a, s);
 }

@@ -1558,6 +1558,31 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BKE;
     HN_REQUIRE(256.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
+    // Split-K on the dw-reuse kernel for the 3x3 convs that give a 256-CU part only 64 .. 160 tiles of 256 x 256 at the nominal batch
+    // (ghc3.0 / ghc3.1 / ghc2.1, layer4.*.conv2): 2 or 4 K slices of whole (channel chunk, filter row) steps as float32 partial
+    // tiles + the ordered reduce below.  The slice count is a function of the layer's shape at the nominal batch of 32 ONLY (never of
+    // the actual M), so every output bit is the same for any batch size.  HN_BF16_SPLITK=0 / HN_BF16_DWR=0 switch it off.
+    if (!out_f32 && !d.res && !d.stat_sum && d.splitk_ws && d.B > 0 && !d.stem) {
+        static const char* sk_env = getenv("HN_BF16_SPLITK");
+        const char* dwe = getenv("HN_BF16_DWR");
+        const long t32 = (long)hn_cdiv(32L * d.Ho * d.Wo, 256) * (d.Cout / 256);
+        int S = t32 >= 64 && t32 <= 160 ? (int)(256 / t32) : 1;
+        S = S >= 4 ? 4 : (S >= 2 ? 2 : 1);
+        ConvArgsH b = a;
+        b.ksplit = S;
+        if (S > 1 && !(sk_env && atoi(sk_env) == 0) && !(dwe && atoi(dwe) == 0) && d.Cout % 256 == 0 && hn_conv_bf16_dwr_ok(b, 0) &&
+            (size_t)S * a.M * d.Cout <= d.splitk_ws_floats) {
+            b.y = d.splitk_ws;
+            b.relu = 0;
+            b.ldy = d.Cout;
+            if (int rc = hn_launch_conv_bf16_dwr(b, 1, 0, s)) return rc;
+            const long MN8 = (long)a.M * d.Cout / 8;
+            hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid_for(MN8)), dim3(256), 0, s, d.splitk_ws, d.scale, d.shift,
+                               reinterpret_cast<u16*>(d.y), MN8, d.Cout / 8, (long)a.M * d.Cout, S, d.relu);
+            HN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     // Split-K for deep-K convs with few output tiles (tails of the height-compression chains: ghc3.2 has 64 tiles of 128x128
     // with K = 9216, ghc3.3 16 tiles).  The slice count depends on the layer's shape at the nominal batch of 32 ONLY, never on
     // the actual M, so the summation order -- and with it every output bit -- is the same for any batch size.

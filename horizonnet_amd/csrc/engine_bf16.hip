@@ -46,10 +46,10 @@ size_t hn_bf16_whh_offset(int l, int d) { return hoff().whh[l][d]; }
 
 namespace {
 
-constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 8 * 128 * 256;   // up to 8 slices of the largest split layer (ghc2.2: 256 x 256 per panorama)
+constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 2 * 256 * 1024;   // 2 slices of ghc3.0's 256 pixels x 1024 channels per panorama (= 4 of ghc3.1, 2 of layer4.*.conv2)
 
 struct PlanH {                     // byte offsets
-    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, xch, sk, total;
+    size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, xch, sk, sk2, total;
     size_t c[4];                   // C1..C4 (the layer outputs): own buffers, read by the next stage AND by the branch stream
     size_t ga[4], gb[4];           // per-scale ping-pong of the height-compression chain (the four chains may overlap)
 };
@@ -81,7 +81,8 @@ PlanH make_plan_h(int B)
     p.y1h = take((size_t)T_COLS * b * 1024 * 2);
     p.y2 = take((size_t)T_COLS * b * 1024 * 4);
     p.xch = take(hn_lstm_bf16_xch_bytes());
-    p.sk = take(SPLITK_WS_FLOATS_PER_PANO * b * 4);      // split-K partial tiles (branch stream only: one user at a time)
+    p.sk = take(SPLITK_WS_FLOATS_PER_PANO * b * 4);      // split-K partial tiles of the branch stream (one user at a time)
+    p.sk2 = take(SPLITK_WS_FLOATS_PER_PANO * b * 4);     // ... of the caller's stream (layer4's 3x3 convs run beside the height-compression chains)
     p.total = off;
     return p;
 }
@@ -251,7 +252,9 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
             const bool chained_in = chain_on && ((li == 0 && (j == 2 || (j == 1 && e->fuse_downsample))) || (li == 1 && j == 0));
             const bool c1_done = chained_in || (stem_c1 && li == 0 && j == 0);
             if (!c1_done && (rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
-            if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s))) return rc;
+            if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s,
+                                 reinterpret_cast<float*>(W + pl.sk2), SPLITK_WS_FLOATS_PER_PANO * (size_t)B)))
+                return rc;
             if (chain_out) {
                 const ConvLayer& c3 = a.convs[i1 + 2];
                 const int in1 = j + 1 < nblk[li] ? a.block_first[li][j + 1] : a.block_first[li + 1][0];
@@ -529,9 +532,9 @@ extern "C" int hn_stem_pool_bf16(const float* x_nchw, const float* w_oihw, const
 }
 
 // per-stage entry point for the parity tests: x / w / res / y are bf16 device buffers (y f32 when out_f32)
-extern "C" int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
-                                   const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
-                                   int relu, int out_f32, void* stream)
+extern "C" int hn_conv2d_nhwc_bf16_ws(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
+                                      const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
+                                      int relu, int out_f32, void* splitk_ws, size_t splitk_ws_floats, void* stream)
 {
     HN_REQUIRE(x && w_scratch && scale && shift && y, "hn_conv2d_nhwc_bf16: null pointer");
     HN_REQUIRE(KH == KW && (KH == 1 || KH == 3), "hn_conv2d_nhwc_bf16: kernel %dx%d unsupported", KH, KW);
@@ -546,5 +549,13 @@ extern "C" int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_s
     d.Ho = (Hi + 2 * d.ph - KH) / sh + 1;
     d.Wo = (Wi + 2 * d.pw - KW) / sw + 1;
     d.relu = relu; d.ldy = Cout;
+    d.splitk_ws = reinterpret_cast<float*>(splitk_ws); d.splitk_ws_floats = splitk_ws_floats;
     return hn_launch_conv_bf16(d, out_f32, s);
+}
+
+extern "C" int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
+                                   const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
+                                   int relu, int out_f32, void* stream)
+{
+    return hn_conv2d_nhwc_bf16_ws(x, w_oihw, w_scratch, scale, shift, res, y, B, Hi, Wi, Cin, Cout, KH, KW, sh, sw, relu, out_f32, nullptr, 0, stream);
 }

@@ -163,6 +163,11 @@ int hn_stem_pool_bf16(const float* x_nchw, const float* w_oihw, const float* sca
 int hn_conv2d_nhwc_bf16(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
                         const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
                         int relu, int out_f32, void* stream);
+/* the same stage with a split-K workspace (float32, `splitk_ws_floats` elements): what the engine passes for the deep-K / few-tile
+ * convs of layer4 and of the height-compression chains (model.py:123-135); the slice count depends on the per-image shape only */
+int hn_conv2d_nhwc_bf16_ws(const void* x, const float* w_oihw, void* w_scratch, const float* scale, const float* shift,
+                           const void* res, void* y, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int sh, int sw,
+                           int relu, int out_f32, void* splitk_ws, size_t splitk_ws_floats, void* stream);
 
 /* per-stage (tests): one bi-LSTM layer with the bf16 recurrence of hn_forward_bf16 (reference model.py:222-227,263-264).
  * gx [T*B][4096] float32 gate pre-activations (fwd gates | rev gates), whh_*_bf16 [2048][512] bf16, y [T*B][1024] float32,

