@@ -191,7 +191,11 @@ struct HeadBufs {
 
 // The convolutional trunk (model.py:73-81,123-179): stem, the four ResNet stages, the four height-compression chains, the
 // up-sample / flatten into `seq`.  Everything is enqueued on `s` (+ the engine's branch stream, joined back into `s`).
-int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const PlanH& pl, char* seq, hipStream_t s)
+// defer_join (pipelined entry): the caller's stream does NOT wait for the four chains at the end -- the recurrent head does -- so the
+// next batch's stem / layer1 (HBM-bound) start beside this batch's last chain (ghc3: deep-K matrix work + a tail of small launches).
+// *forked tells the caller whether chains went to the branch stream.
+int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const PlanH& pl, char* seq, hipStream_t s, bool defer_join = false,
+                bool* forked = nullptr)
 {
     const Arch& a = arch();
     const HOff& h = hoff();
@@ -237,7 +241,13 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
     const char* cur = W + pl.pool;
     int Hh = 128, Wd = 256;
     const int nblk[4] = {3, 4, 6, 3};
+    if (forked) *forked = fork;
     for (int li = 0; li < 4; ++li) {
+        // C_li is about to be overwritten: a chain of an EARLIER batch that was not joined (deferred) must have finished reading it
+        if (e->join_deferred[li]) {
+            HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
+            e->join_deferred[li] = false;
+        }
         for (int j = 0; j < nblk[li]; ++j) {
             const int stride = (j == 0 && li > 0) ? 2 : 1;
             const int i1 = a.block_first[li][j];
@@ -319,8 +329,13 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
         }
         if (fork) HN_HIP(hipEventRecord(e->ev_join[li], sb));
     }
-    if (fork)
-        for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
+    if (fork) {
+        if (defer_join) {
+            for (int li = 0; li < 4; ++li) e->join_deferred[li] = true;
+        } else {
+            for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
+        }
+    }
     return 0;
 }
 
@@ -447,9 +462,12 @@ extern "C" int hn_forward_bf16_submit(hn_engine* e, const float* x, int B, int C
     else hb = {W + pp.sync1, W + pp.seq1, W + pp.gx1, W + pp.y11, W + pp.y1h1, W + pp.y21, nullptr, W + pp.y2h[1]};
     // this slot's `seq` was last read by the head submitted two calls ago: the trunk's writes into it wait for that head
     if (e->head_pending[slot]) HN_HIP(hipStreamWaitEvent(s, e->ev_head[slot], 0));
-    if (int rc = run_trunk_h(e, x, B, C_in, W, pl, hb.seq, s)) return rc;
+    bool forked = false;
+    if (int rc = run_trunk_h(e, x, B, C_in, W, pl, hb.seq, s, e->defer_join, &forked)) return rc;
     HN_HIP(hipEventRecord(e->ev_trunk[slot], s));
     HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_trunk[slot], 0));
+    if (forked && e->defer_join)
+        for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_join[li], 0));
     if (int rc = run_head_h(e, B, hb, bon, cor, true, e->head_stream)) return rc;
     HN_HIP(hipEventRecord(e->ev_head[slot], e->head_stream));
     e->head_pending[slot] = true;
