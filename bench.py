@@ -751,13 +751,20 @@ def main():
         igemm_fl = sum(v[1] for k, v in fam.items() if "conv_igemm" in k)
         traffic, traffic_note = None, None               # HBM-side bytes per forward from the committed PMC passes of the newest round's kernels
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        for tname in ("r3_pmc_forward.json", "r2_pmc_forward.json"):
+        traffic_stale = None
+        for tname in ("r4_pmc_forward.json", "r3_pmc_forward.json", "r2_pmc_forward.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if B == 32 and os.path.exists(tpath):
-                rec = json.load(open(tpath))["precisions"].get(args.dtype)
+                whole = json.load(open(tpath))
+                rec = whole["precisions"].get(args.dtype)
                 if rec is None:
                     continue
                 traffic = rec["total_bytes"]
+                # the counters are from a separate rocprofv3 run: tie them to the code that runs NOW (hash of the loaded library)
+                import hashlib
+                from horizonnet_amd import _lib as _l
+                measured = (whole.get("measured_on") or {}).get("lib_sha256")
+                traffic_stale = measured is None or measured != hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()
                 traffic_note = ("bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes, profiles/%s "
                                 "(tools/profile_forward.sh); Infinity-Cache hits included; algorithmic minimum %.1f GB -> counter / algorithmic = %.2f; "
                                 "matrix pipe busy %s %% of the conv kernels' cycles" % (
@@ -787,6 +794,7 @@ def main():
                              ("hn_forward" if args.plain else "hn_forward_submit") if args.dtype == "f32" else ("hn_forward_bf16" if args.plain else "hn_forward_bf16_submit"), 100.0 * igemm_ms / prof_total),
                          "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / peak, 4), "traffic": traffic,
+                         "traffic_stale": traffic_stale,
                          "traffic_note": traffic_note,
                          "algorithmic_flop_per_launch": FWD_FLOP_PER_PANO * B,
                          "launch_ms_hip_events": round(ms_per_fwd, 3),

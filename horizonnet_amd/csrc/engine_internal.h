@@ -75,7 +75,7 @@ struct hn_engine {
     hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool join_deferred[4] = {false, false, false, false};   // bf16 pipelined entry: ev_join[li] of the previous batch has not been waited for yet
-    bool defer_join = true;                                  // option "defer_join"
+    bool defer_join = false;                                 // option "defer_join"
     // head stream (hn_forward_bf16_submit): the recurrent head of batch i runs here, beside the trunk of batch i+1 on the
     // caller's stream; per slot one event "trunk finished" (recorded on the caller's stream) and one "head finished"
     hipStream_t head_stream = nullptr;

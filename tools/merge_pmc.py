@@ -1,10 +1,16 @@
 """Merge the per-counter JSONs of tools/profile_forward.sh into profiles/rN_pmc_forward.json (MEASUREMENT TOOL): per precision
 the HBM-side bytes per forward (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes), the ratio to the algorithmic
 minimum and the matrix-pipe busy share per kernel family -- the record bench.py quotes in `roofline.traffic`.
-    python tools/merge_pmc.py gpurun_out r3 > profiles/r3_pmc_forward.json"""
+    python tools/merge_pmc.py gpurun_out r4 > profiles/r4_pmc_forward.json
+The record carries the SHA-256 of libhorizonnet_hip.so it was measured on (and the git HEAD): bench.py sets `traffic_stale` when the
+library it runs is another one."""
+import hashlib
 import json
 import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 ALGORITHMIC_MIN = {"f32": 31.686e9, "bf16": 15.9e9}      # every conv reads in + W once, writes out once (B = 32)
 
@@ -15,6 +21,11 @@ def main():
                    "tools/prof_target.py {f32p,bf16p} 32 4 (pipelined entry), three separate passes per precision (tools/profile_forward.sh)",
            "correction": "FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64 bytes), KB -> bytes; WRITE_SIZE as reported; Infinity-Cache hits included",
            "precisions": {}}
+    # what these counters were measured ON: bench.py compares the hash with the library it loads and flags `traffic_stale` otherwise
+    lib = os.path.join(ROOT, "horizonnet_amd", "libhorizonnet_hip.so")
+    out["measured_on"] = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+                          "git_head": (subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or
+                                       os.environ.get("HN_GIT_HEAD", "unknown (no .git on the GPU box: pass HN_GIT_HEAD)"))}
     for prec in ("f32", "bf16"):
         recs = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
