@@ -102,23 +102,27 @@ def cpu_baseline(seconds_budget=12.0):
     cores = usable_cores()                           # cgroup-aware (the GPU box shows 256 CPUs, grants 16)
     torch.set_num_threads(cores)
     sd = make_state_dict(0, "random")
-    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(0))
+    x = torch.rand(4, 3, 512, 1024, generator=torch.Generator().manual_seed(0))
     horizonnet_ref.forward(x[:1], sd)                  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        horizonnet_ref.forward(x, sd)
-        n += x.shape[0]
-        el = time.perf_counter() - t0
-        if el > seconds_budget and n >= 16:              # a bounded sample: ~12 s of CPU work, at least 16 panoramas
-            break
-        if el > 3 * seconds_budget:
-            break
-    return {"value": n / el, "unit": "panoramas/s", "cores": cores, "kind": "port",
-            "sample": "%d panoramas (batches of 2) through oracle.horizonnet_ref.forward, torch %s fp32, %d threads, %.1f s"
-                      % (n, torch.__version__, cores, el),
+    by_batch, total_n, total_s = {}, 0, 0.0
+    for b in (1, 4):                                   # SURVEY 8d / BASELINE.md section 4: B = 1 and B = 4, >= 3 timed iterations each
+        n, t0 = 0, time.perf_counter()
+        while True:
+            horizonnet_ref.forward(x[:b], sd)
+            n += b
+            el = time.perf_counter() - t0
+            if (el > seconds_budget / 2 and n >= 3 * b) or el > 1.5 * seconds_budget:
+                break
+        by_batch[b] = {"panoramas_per_s": round(n / el, 3), "iterations": n // b, "seconds": round(el, 2)}
+        total_n += n
+        total_s += el
+    best = max(v["panoramas_per_s"] for v in by_batch.values())
+    return {"value": best, "unit": "panoramas/s", "cores": cores, "kind": "port", "by_batch": by_batch,
+            "sample": "%d panoramas (B = 1: %d iterations, B = 4: %d iterations) through oracle.horizonnet_ref.forward, torch %s fp32, %d threads, %.1f s; "
+                      "value = the better of the two batch sizes" % (total_n, by_batch[1]["iterations"], by_batch[4]["iterations"], torch.__version__, cores, total_s),
             "note": "port = the oracle's restatement of the reference forward (same torch conv / LSTM kernels, pinned to the unmodified "
                     "reference at 2.4e-7); /root/reference is absent on the GPU box.  The UNMODIFIED reference model.py measured "
-                    "2.2 panoramas/s on the build container's 8 vCPUs (SURVEY.md section 6)"}
+                    "2.2 panoramas/s (B = 1) / 1.6 (B = 4) on the build container's 8 vCPUs (SURVEY.md section 6)"}
 
 
 def pano_stretch_leg(dev, n_img=64, iters=10):

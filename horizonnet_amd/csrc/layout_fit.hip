@@ -104,6 +104,7 @@ struct Ctx {
     std::vector<int> gpid;     // [W]
     std::vector<double> bufx, bufy, tmp;
     bool bad = false;
+    bool overflow = false;     // more walls than the fixed-size output of one panorama holds (HN_FIT_MAX_CORNERS): NOT an error of the layout
 };
 
 // _vote_axis: is the segment a constant-x (0) or constant-y (1) wall?
@@ -197,7 +198,7 @@ bool walls_general(Ctx& c, const int* peaks, int n, double tol, std::vector<Wall
         for (int i = 0; i < (int)walls.size(); ++i)
             if (walls[i].tbd && (cur == -1 || walls[i].score > walls[cur].score)) cur = i;
         if (cur == -1) break;
-        if ((int)walls.size() > MAXC) return false;
+        if ((int)walls.size() > MAXC) { c.overflow = true; return false; }
         Wall& w = walls[cur];
         w.tbd = false;
         const int nw = (int)walls.size();
@@ -243,7 +244,8 @@ bool walls_general(Ctx& c, const int* peaks, int n, double tol, std::vector<Wall
             walls.insert(walls.begin() + cur + 1, b);
         }
     }
-    return (int)walls.size() <= MAXC;
+    if ((int)walls.size() > MAXC) { c.overflow = true; return false; }
+    return true;
 }
 
 // polygon_is_simple (the stand-in for shapely's Polygon.is_valid at inference.py:120) on the float32-rounded plan
@@ -324,7 +326,11 @@ int fit_one(Ctx& c, const unsigned char* mask, double tol, int force_cuboid, dou
             }
         }
     }
-    if (!ok || c.bad || walls.empty() || (int)walls.size() > MAXC) {
+    if (c.overflow || (int)walls.size() > MAXC) {
+        *npts = 0;
+        return 3;                                          // a valid layout with more walls than this call's output rows: the caller re-runs it
+    }
+    if (!ok || c.bad || walls.empty()) {
         *npts = 0;
         return 2;                                          // one of the reference's assertions would have fired
     }
@@ -406,6 +412,7 @@ extern "C" int hn_layout_fit_batch(const double* xs, const double* ys, const uns
             c.xs = xs + (size_t)b * W;
             c.ys = ys + (size_t)b * W;
             c.bad = false;
+            c.overflow = false;
             flags[b] = fit_one(c, peak_mask + (size_t)b * W, tol[b], force_cuboid, pts + (size_t)b * MAXC * 2, npts + b);
         }
     };

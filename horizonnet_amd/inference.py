@@ -207,9 +207,40 @@ def layouts_from_signals_batch(y_bon, y_cor, mask_main, mask_zero=None, H=512, W
                 print("Fail to generate valid general layout!! Generate cuboid as fallback.", file=sys.stderr)
             p2, n2, f2 = run(redo, np.ascontiguousarray(np.stack([top4_mask(mz[b], prob[b]) for b in redo])), True)
             pts[redo], npts[redo], flags[redo] = p2, n2, f2
-    if (flags == 2).any():
-        raise AssertionError("layout fit: panorama(s) %s of the batch hit an assertion of the reference's gen_ww / vote "
-                             "(too few corner peaks, degenerate vote)" % np.nonzero(flags == 2)[0].tolist())
+    # flag 3: a layout with more walls than one call's output rows hold (HN_FIT_MAX_CORNERS; e.g. a saturated corner signal whose
+    # plateau columns are all peaks).  The reference has no cap: those panoramas go through the per-panorama numpy path below, the
+    # rest of the batch keeps its native results.  flag 2 (an assertion of the reference's gen_ww / vote) is reported PER panorama.
+    over = np.nonzero(flags == 3)[0]
+    slow = {}
+    for b in over:
+        peaks_of = _MaskPeaks({(0.0 if force_cuboid else 0.05): np.asarray(mask_main[b]),
+                               0.0: np.asarray(mask_main[b] if (force_cuboid or mask_zero is None) else mask_zero[b])})
+        try:
+            slow[int(b)] = layout_from_signals(np.array(y_bon[b], np.float32), prob[b], H, W, force_cuboid=force_cuboid, peaks_fn=peaks_of)
+        except AssertionError as exc:
+            slow[int(b)] = exc
+    bad = [int(b) for b in np.nonzero(flags == 2)[0]] + [b for b, v in slow.items() if isinstance(v, AssertionError)]
+    if bad:
+        err = AssertionError("layout fit: panorama(s) %s of the batch hit an assertion of the reference's gen_ww / vote "
+                             "(too few corner peaks, degenerate vote); the other panoramas of the batch are unaffected" % sorted(bad))
+        err.failed_panoramas = sorted(bad)
+        raise err
+    if len(over):
+        keep = np.nonzero(flags != 3)[0]
+        done = dict(slow)
+        if len(keep):
+            sub = _finish_layouts(pts[keep], npts[keep], z0, z1[keep], W, H)
+            for i, b in enumerate(keep):
+                done[int(b)] = sub[i]
+        return [done[b] for b in range(B)]
+    return _finish_layouts(pts, npts, z0, z1, W, H)
+
+
+def _finish_layouts(pts, npts, z0, z1, W, H):
+    """np_xy2coor + infer_coory + the roll to the left-most corner + cor_id for the corner points of a batch (second half of
+    layouts_from_signals_batch)."""
+    PI = postproc.PI
+    B = len(npts)
     # np_xy2coor + infer_coory (post_proc.py:46-66,126-131) on all corner points at once
     off = np.concatenate([[0], np.cumsum(npts)])
     P = np.concatenate([pts[b, :npts[b]] for b in range(B)], 0)

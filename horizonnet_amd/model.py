@@ -369,6 +369,39 @@ class _HipTrainStep(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def _follow_autocast(bon, cor):
+    """"dtype follows autocast".  The reference's last op under ``torch.autocast`` (train.py:51,273) is the
+    autocast ``nn.Linear`` (model.py:266), so its outputs arrive in the autocast dtype; the engine computes its head in float32
+    and casts the two outputs here (differentiably), so that code written against the reference sees the same dtypes."""
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        return bon.to(dt), cor.to(dt)
+    return bon, cor
+
+
+def _guard_data_parallel():
+    """``nn.DataParallel(net, device_ids=[0, 1, ...])`` (reference train.py:190-192) replicates the module onto several GPUs inside ONE
+    process -- the pattern this engine replaces with one process per GPU over RCCL.  Fail where the user
+    writes the wrap, with the command to run instead, not at the first forward of a replica."""
+    import torch.nn as nn
+    if getattr(nn.DataParallel.__init__, "_horizonnet_amd_guard", False):
+        return
+    orig = nn.DataParallel.__init__
+
+    def checked_init(self, module, device_ids=None, output_device=None, dim=0):
+        ids = device_ids if device_ids is not None else list(range(torch.cuda.device_count()))
+        if isinstance(module, HorizonNet) and len(ids) > 1:
+            raise RuntimeError(
+                "horizonnet_amd.HorizonNet cannot be wrapped by nn.DataParallel over %d devices: the HIP engine runs one process per "
+                "GPU.  Launch the same script with\n    python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                "train.py ...\n(horizonnet_amd.train / horizonnet_amd.parallel shard the batches and all-reduce the gradients over RCCL); "
+                "nn.DataParallel(net, device_ids=[one device]) keeps working." % (len(ids), len(ids)))
+        orig(self, module, device_ids, output_device, dim)
+
+    checked_init._horizonnet_amd_guard = True
+    nn.DataParallel.__init__ = checked_init
+
+
 class HorizonNet(nn.Module):
     x_mean = torch.FloatTensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     x_std = torch.FloatTensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
@@ -513,7 +546,7 @@ class HorizonNet(nn.Module):
                     "(horizonnet_amd.parallel); nn.DataParallel(net, device_ids=[one device]) works because it calls the "
                     "module itself.")
             with torch.cuda.device(x.device):
-                return _HipTrainStep.apply(self, xin, *params)
+                return _follow_autocast(*_HipTrainStep.apply(self, xin, *params))
         if C_in < 3:
             raise RuntimeError("expected at least 3 input channels")
         xin = x.detach()
@@ -537,7 +570,7 @@ class HorizonNet(nn.Module):
                 raise ValueError("precision must be 'f32' or 'bf16'")
             if self.check_status_async:
                 st.post_status_read(ws)
-        return bon, cor
+        return _follow_autocast(bon, cor)
 
     def forward_async(self, x):
         """Two-stage form of ``forward`` for back-to-back batches (serving loops, ``inference_stream``): enqueues the
@@ -654,3 +687,6 @@ class HorizonNet(nn.Module):
                 off = st.pipelined_status_bytes(B, kind == "bf16p")[1]
                 worst = max(worst, int(ws[off:off + 4].view(torch.int32).item()))
         return worst
+
+
+_guard_data_parallel()

@@ -176,7 +176,9 @@ def test_dataparallel_single_device_and_replica_guard():
 
 def test_autocast_gradscaler_step_equals_plain_step():
     """train.py:273-280 verbatim around the engine: fp16 autocast context + GradScaler.  The engine computes in its own
-    precision whatever autocast says; the scaler's 65536x loss scaling must cancel exactly (float32 gradients)."""
+    precision whatever autocast says and hands its two outputs over in the autocast dtype (SURVEY 8b "dtype follows autocast": the
+    reference's last op is an autocast nn.Linear); the scaler's 65536x loss scaling cancels, what remains against the plain step is
+    the float16 rounding of the outputs (loss ~1e-3 relative; Adam's first update is lr * sign(g), so a few near-zero gradients flip)."""
     from torch.cuda.amp import GradScaler, autocast
     x, y_bon, y_cor = _batch(42, B=1)
     upd = []
@@ -189,6 +191,7 @@ def test_autocast_gradscaler_step_equals_plain_step():
             opt.zero_grad()
             with autocast():
                 bon, cor = net(x)
+                assert bon.dtype == torch.float16 and cor.dtype == torch.float16        # dtype follows autocast
                 loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
             scaler.scale(loss).backward()
             scaler.step(opt)
@@ -201,8 +204,16 @@ def test_autocast_gradscaler_step_equals_plain_step():
             opt.step()
         upd.append((float(loss.detach()), (net.linear.weight.detach() - w0).cpu()))
     torch.cuda.synchronize()
-    assert abs(upd[0][0] - upd[1][0]) < 1e-6
-    assert float((upd[0][1] - upd[1][1]).abs().max()) < 2e-6 and float(upd[0][1].abs().max()) > 5e-5
+    assert abs(upd[0][0] - upd[1][0]) < 2e-3 * max(1.0, abs(upd[1][0]))
+    diff = (upd[0][1] - upd[1][1]).abs()
+    assert float(diff.median()) < 2e-6 and float((diff > 1e-5).float().mean()) < 0.05 and float(upd[0][1].abs().max()) > 5e-5
+    with torch.no_grad():                                       # eval mode: the same rule, and float32 outside autocast
+        net.eval()
+        with autocast(dtype=torch.bfloat16):
+            b16, c16 = net(x)
+        b32, c32 = net(x)
+    assert b16.dtype == torch.bfloat16 and c16.dtype == torch.bfloat16 and b32.dtype == torch.float32
+    assert float((b16.float() - b32).abs().max()) <= 2.0 ** -7 * max(1.0, float(b32.abs().max()))
 
 
 # ---- configs[2] in miniature: loss curve vs the unmodified reference -------------------------------------------------

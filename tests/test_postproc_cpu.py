@@ -329,3 +329,30 @@ def test_native_batched_fit_on_perturbed_signals_and_failures(gold):
             n_bad += 1
     print("perturbed rooms: %d fitted identically, %d rejected by both paths" % (n_ok, n_bad))
     assert n_ok >= 250
+
+
+def test_native_batched_fit_more_walls_than_one_call_holds(gold):
+    """a saturated corner signal (plateau columns are all peaks) gives the general layout more walls than the 64 output rows
+    of hn_layout_fit_batch.  The reference has no cap: those panoramas must come back as the per-panorama path returns them (a large
+    polygon, or the cuboid fallback when that polygon is invalid), inside a batch whose other panoramas keep their native results --
+    not as an AssertionError for the whole batch."""
+    from horizonnet_amd.inference import layouts_from_signals_batch
+    g, meta = gold
+    js, yb, yc = _signals(g, meta, kinds=None)
+    yb, yc = yb[:6].copy(), yc[:6].copy()
+    masks = _peak_masks(yc, [0.05, 0.0])
+    rng = np.random.RandomState(3)
+    crowded = (1, 4)
+    for b, npk in zip(crowded, (90, 140)):
+        cols = np.sort(rng.choice(1024, npk, replace=False))
+        masks[0, b] = 0
+        masks[0, b, cols] = 1
+        yc[b, cols] = 1.0                                  # plateau: equal maxima
+    want = _per_panorama(yb, yc, masks[0], masks[1], False)
+    assert all(w is not None for w in want)
+    assert max(len(want[b][0]) for b in crowded) // 2 > 0
+    got = layouts_from_signals_batch(yb, yc, masks[0], masks[1], 512, 1024, False, 3)
+    assert len(got) == 6
+    for a, b in zip(got, want):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+    print("corners of the crowded panoramas:", [len(want[b][0]) // 2 for b in crowded])

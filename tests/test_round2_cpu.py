@@ -308,3 +308,31 @@ def test_resume_restores_each_ranks_own_rng_streams(tmp_path):
         draws[r] = d
         assert a.rng_restore == ("own" if r == 0 else "reseeded")
     assert draws[0] == nxt[0] and len({draws[0], draws[1], draws[2]}) == 3
+
+
+def test_layout_comparison_handles_the_column_seam():
+    """tools/c5_layout.seam_aware_max_abs: a corner that moves across the 0 / 1024 column seam re-orders the corner list; the raw
+    |a - b| reads ~1000 px for a sub-pixel move, the seam-aware figure reads the move."""
+    import numpy as np
+    from tools.c5_layout import seam_aware_max_abs
+    a = np.array([[0.2, 100], [0.2, 400], [300, 110], [300, 390], [700, 100], [700, 400], [900, 90], [900, 410]], float)
+    b = np.array([[300.5, 110], [300.5, 390], [700, 100.4], [700, 400], [900, 90], [900, 410], [1023.9, 100], [1023.9, 400]], float)
+    assert np.abs(a - b).max() > 300                      # what the round-3 bench line printed
+    assert abs(seam_aware_max_abs(a, b) - 0.5) < 1e-9     # the real displacement: 0.5 px (x of the second corner)
+    assert seam_aware_max_abs(a, a) == 0.0
+    c = a.copy()
+    c[3, 1] += 7.0
+    assert seam_aware_max_abs(a, c) == 7.0
+
+
+def test_data_parallel_over_several_devices_fails_at_wrap_time():
+    """train.py:190-192 on a multi-GPU box: nn.DataParallel(net, device_ids=[0, 1]) must fail WHERE IT IS WRITTEN, with the
+    torchrun command to use instead -- not at the first forward of a replica; other modules and the one-device wrap are untouched."""
+    import pytest
+    import torch.nn as nn
+    import horizonnet_amd
+    net = horizonnet_amd.HorizonNet("resnet50", True)
+    with pytest.raises(RuntimeError, match="torch.distributed.run --nnodes=1 --nproc-per-node 2"):
+        nn.DataParallel(net, device_ids=[0, 1])
+    nn.DataParallel(nn.Linear(2, 2))                      # any other module: as before
+    assert nn.DataParallel(net).module is net              # no visible devices here -> no replicas -> allowed (the one-device form runs on the GPU box)
