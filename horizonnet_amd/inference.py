@@ -391,11 +391,15 @@ class _HostRing:
 _RING = _HostRing()
 
 
-def _stage_submit(net, x, device, flip, rotate):
+def _stage_submit(net, x, device, flip, rotate, pipelined=True):
     """First device stage of one batch: test-time augmentation + the engine forward, submitted asynchronously
-    (``forward_async``: in bf16 mode the recurrent head runs on the engine's own stream beside the NEXT batch's trunk)."""
+    (``forward_async``: in bf16 mode the recurrent head runs on the engine's own stream beside the NEXT batch's trunk).
+    pipelined=False (``inference_batch``): the plain ``net(x)`` of ``inference()`` -- in float32 the pipelined entry's recurrence kernel
+    sums in another order (~1e-6 on the logits, enough to flip a peak at the min_v threshold), and ``inference_batch`` promises the
+    results of B calls of ``inference()``; in bf16 the two entries are bit-identical, so the stream form keeps the faster one."""
     x_aug, tags = augment(x.to(device), flip, rotate)
-    fwd = net.forward_async(x_aug) if hasattr(net, "forward_async") else None
+    use_async = hasattr(net, "forward_async") and (pipelined or getattr(net, "precision", "f32") == "bf16")
+    fwd = net.forward_async(x_aug) if use_async else None
     return {"pending": fwd, "out": None if fwd is not None else net(x_aug), "tags": tags, "B": int(x.shape[0]), "W": int(x.shape[-1]),
             "net": net, "device": device}
 
@@ -424,7 +428,7 @@ def _stage_post(sub, force_cuboid, min_v, r, depth):
 
 def _stage_device(net, x, device, flip, rotate, force_cuboid, min_v, r, depth):
     """Both device stages of one batch back to back (the unpipelined form)."""
-    return _stage_post(_stage_submit(net, x, device, flip, rotate), force_cuboid, min_v, r, depth)
+    return _stage_post(_stage_submit(net, x, device, flip, rotate, pipelined=False), force_cuboid, min_v, r, depth)
 
 
 def _raise_if_engine_failed(st):
@@ -497,17 +501,24 @@ def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=F
     from collections import deque
     pending = deque()
     sub = None                         # the batch whose forward is submitted but whose second device stage is not yet enqueued:
-    for x in batches:                  # batch i+1's trunk goes onto the stream BEFORE batch i's wait for its recurrent head
-        H, W = tuple(x.shape[2:])
-        nxt = (_stage_submit(net, x, device, flip, rotate), H, W)
+    try:
+        for x in batches:              # batch i+1's trunk goes onto the stream BEFORE batch i's wait for its recurrent head
+            H, W = tuple(x.shape[2:])
+            nxt = (_stage_submit(net, x, device, flip, rotate), H, W)
+            if sub is not None:
+                pending.append((_stage_post(sub[0], force_cuboid, min_v, r, depth + 1), sub[1], sub[2]))
+            sub = nxt
+            if len(pending) >= depth:
+                st, h, w = pending.popleft()
+                yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals, native)
         if sub is not None:
             pending.append((_stage_post(sub[0], force_cuboid, min_v, r, depth + 1), sub[1], sub[2]))
-        sub = nxt
-        if len(pending) >= depth:
+            sub = None
+        while pending:
             st, h, w = pending.popleft()
             yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals, native)
-    if sub is not None:
-        pending.append((_stage_post(sub[0], force_cuboid, min_v, r, depth + 1), sub[1], sub[2]))
-    while pending:
-        st, h, w = pending.popleft()
-        yield _finish_host(st, h, w, force_cuboid, force_raw, min_v, r, workers, shared_signals, native)
+    finally:
+        # the generator was closed early (or a stage raised): the forward of `sub` is still writing its outputs from the engine's own
+        # stream -- collect it before its tensors go back to the allocator (PendingForward.__del__ does the same as a last resort)
+        if sub is not None and sub[0].get("pending") is not None:
+            sub[0]["pending"].result()

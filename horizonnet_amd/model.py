@@ -263,6 +263,15 @@ class PendingForward:
             self._done = True
         return self._bon, self._cor
 
+    def __del__(self):
+        # bon / cor / the workspace are torch allocations of the CALLER's stream, written by the engine-owned head stream the caching
+        # allocator knows nothing about: a handle dropped without result() must not hand them back while the head kernels still write
+        if not getattr(self, "_done", True):
+            try:
+                self.result()
+            except Exception:                                # interpreter shutdown, destroyed engine: nothing left to protect
+                pass
+
 
 class _HipTrainStep(torch.autograd.Function):
     """autograd node of one train-mode forward on the HIP engine (hn_train_forward / hn_train_backward)."""
@@ -352,7 +361,8 @@ class _HipTrainStep(torch.autograd.Function):
                     full.copy_(half)
                 net._grad_mean_scale = 1.0
                 if world > 1:
-                    if getattr(net, "defer_grad_mean", False):      # FusedAdam folds the 1/N into hn_adam_step's grad_scale
+                    ref = getattr(net, "_fused_adam_ref", None)
+                    if getattr(net, "defer_grad_mean", False) and ref is not None and ref() is not None:   # a LIVE FusedAdam folds the 1/N into hn_adam_step's grad_scale
                         net._grad_mean_scale = 1.0 / world
                     else:
                         flat.mul_(1.0 / world)

@@ -44,10 +44,25 @@ class FusedAdam:
         self.m = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.net.defer_grad_mean = True       # data-parallel backward leaves the gradient SUM; step() applies 1/world in the same launch
+        # While THIS optimiser is alive a data-parallel backward leaves the gradient SUM in p.grad and step() applies 1 / world in its own
+        # launch.  The module only holds a weak reference: once the optimiser is gone (another optimiser, gradient clipping or logging
+        # takes over) backward goes back to storing the mean.  Code that reads p.grad between backward() and step() calls
+        # mean_gradients_() first.
+        import weakref
+        self.net.defer_grad_mean = True
+        self.net._fused_adam_ref = weakref.ref(self)
         self._ptr_sig = None
         self._ptrs = None
         self._active = None
+
+    @torch.no_grad()
+    def mean_gradients_(self):
+        """Turn the rank SUM a data-parallel backward left in p.grad into the mean now (for gradient clipping / logging in front of
+        step()); step() then applies no further 1 / world factor."""
+        scale = float(getattr(self.net, "_grad_mean_scale", 1.0))
+        if scale != 1.0:
+            torch._foreach_mul_([p.grad for _, p in self.named if p.grad is not None], scale)
+            self.net._grad_mean_scale = 1.0
 
     def zero_grad(self, set_to_none=True):
         for _, p in self.named:

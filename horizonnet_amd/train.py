@@ -214,7 +214,12 @@ def main(argv=None):
                           flush=True)
         batches.close()
         torch.cuda.synchronize(device)
-        if net.hip_status(device) != 0:                     # a timed-out persistent LSTM kernel produced garbage this epoch:
+        status = int(net.hip_status(device) != 0)
+        if world > 1:                                       # EVERY rank must leave together: the collectives below would otherwise
+            flag = torch.tensor([status], dtype=torch.int32, device=device)       # block the healthy ranks until the process-group time-out
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            status = int(flag.item())
+        if status != 0:                                     # a timed-out persistent LSTM kernel produced garbage this epoch:
             raise RuntimeError("horizonnet_amd.train: the engine's status word is non-zero after epoch %d; refusing to "
                                "validate / checkpoint weights updated from invalid activations" % epoch)
         rng_ranks = utils.gather_rng_states()               # collective: every rank's streams go into rank 0's checkpoint
