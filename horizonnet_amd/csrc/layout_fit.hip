@@ -249,8 +249,19 @@ bool walls_general(Ctx& c, const int* peaks, int n, double tol, std::vector<Wall
 }
 
 // polygon_is_simple (the stand-in for shapely's Polygon.is_valid at inference.py:120) on the float32-rounded plan
-bool polygon_is_simple(const double* px, const double* py, int n)
+bool polygon_is_simple(const double* px_in, const double* py_in, int n_in)
 {
+    // repeated consecutive points (cyclically) are dropped first, as in postproc.polygon_is_simple
+    std::vector<double> ux, uy;
+    for (int i = 0; i < n_in; ++i) {
+        const int pv = (i - 1 + n_in) % n_in;
+        if (n_in > 1 && px_in[i] == px_in[pv] && py_in[i] == py_in[pv]) continue;
+        ux.push_back(px_in[i]);
+        uy.push_back(py_in[i]);
+    }
+    const double* px = ux.data();
+    const double* py = uy.data();
+    const int n = (int)ux.size();
     if (n < 3) return false;
     std::vector<double> qx(n), qy(n), ex(n), ey(n);
     for (int i = 0; i < n; ++i) {

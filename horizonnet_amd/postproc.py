@@ -251,6 +251,10 @@ def polygon_is_simple(xy):
     """What ``shapely.geometry.Polygon(xy).is_valid`` answers at inference.py:120 for a single ring: non-zero area and
     no point shared by two non-adjacent edges (crossing or touching).  All edge pairs at once, O(n^2) on n <= ~20."""
     p = np.asarray(xy, np.float64).reshape(-1, 2)
+    # repeated consecutive points (an explicitly closed ring repeats its first point) do not make a ring invalid (OGC SFS / the GEOS
+    # validity rules shapely documents): drop them before looking at edge pairs, a zero-length edge would separate true neighbours
+    if len(p) > 1:
+        p = p[(p != np.roll(p, 1, axis=0)).any(axis=1)]
     n = len(p)
     if n < 3:
         return False

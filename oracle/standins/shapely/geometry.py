@@ -28,7 +28,12 @@ class Polygon:
     def __init__(self, shell=None, holes=None):
         if holes:
             raise NotImplementedError("shapely stand-in: holes are out of scope")
-        self._ring = np.asarray(shell, np.float64).reshape(-1, 2)
+        ring = np.asarray(shell, np.float64).reshape(-1, 2)
+        # repeated consecutive points (an explicitly closed shell repeats its first point) are legal in OGC SFS / GEOS rings and
+        # change neither area nor validity: drop them, a zero-length edge would otherwise hide two true neighbours from each other
+        if len(ring) > 1:
+            ring = ring[(ring != np.roll(ring, 1, axis=0)).any(axis=1)]
+        self._ring = ring
 
     @property
     def area(self):

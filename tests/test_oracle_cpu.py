@@ -140,3 +140,41 @@ def test_train_step_oracle_matches_reference_golden(golden_dir):
         assert abs(n - g["grad_norm"][i]) <= 1e-3 * g["grad_norm"][i] + 1e-9, k
     assert np.abs(osd["feature_extractor.encoder.bn1.running_mean"].numpy() - g["rm:bn1"]).max() < 1e-6
     assert np.abs(osd["feature_extractor.encoder.bn1.running_var"].numpy() - g["rv:bn1"]).max() < 1e-6
+
+
+def test_torchvision_standin_and_imagenet_remap_match_the_published_state_dict(golden_dir, tmp_path, monkeypatch):
+    """tests/golden/torchvision_resnet50_state_dict.json = key -> shape of torchvision's resnet50 checkpoint, written out from the
+    PUBLISHED architecture (oracle/gen_torchvision_keys.py, 25,557,032 parameters).  (a) the stand-in the fixtures were generated
+    through has exactly that state_dict, in that order; (b) a checkpoint in that layout is consumed COMPLETELY by the engine module's
+    ImageNet remap (every non-fc tensor lands, bit for bit, in the LR_PAD-wrapped trunk: model.py:66-69,204-207)."""
+    import json
+    import sys
+    spec = json.load(open(os.path.join(golden_dir, "torchvision_resnet50_state_dict.json")))
+    assert spec["parameters"] == 25557032 and len(spec["state_dict"]) == 320
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "standins"))
+    try:
+        import torchvision.models as tvm
+        sd = tvm.resnet50().state_dict()
+    finally:
+        sys.path.pop(0)
+    assert [[k, list(v.shape)] for k, v in sd.items()] == spec["state_dict"]
+    # (b) the remap
+    import horizonnet_amd
+    from horizonnet_amd import model as hmodel
+    torch.manual_seed(5)
+    ck = {k: (torch.randn(s) if s else torch.tensor(7)) for k, s in spec["state_dict"]}
+    path = str(tmp_path / "resnet50-0676ba61.pth")
+    torch.save(ck, path)
+    monkeypatch.setenv("HORIZONNET_RESNET50_WEIGHTS", path)
+    net = horizonnet_amd.HorizonNet("resnet50", True)
+    assert net.feature_extractor.pretrained_loaded
+    enc = {k[len("feature_extractor.encoder."):]: v for k, v in net.state_dict().items() if k.startswith("feature_extractor.encoder.")}
+    used = 0
+    for k, v in ck.items():
+        if k.startswith("fc."):
+            continue
+        tk = "conv1.1.weight" if k == "conv1.weight" else k.replace(".conv2.weight", ".conv2.1.weight")
+        assert tk in enc, k
+        assert torch.equal(enc[tk], v), k
+        used += 1
+    assert used == 318 and len(enc) == 318        # every encoder tensor came from the checkpoint, nothing of it was dropped but fc

@@ -159,6 +159,15 @@ def test_polygon_validity_rule():
     assert not pp.polygon_is_simple([(0, 0), (2, 2), (2, 0), (0, 2)])           # bow tie
     assert not pp.polygon_is_simple([(0, 0), (2, 0), (2, 2), (1, 0), (0, 2)])    # vertex touching an edge
     assert not pp.polygon_is_simple([(0, 0), (1, 0), (2, 0)])                    # no area
+    # adversarial rings, answered as the OGC / GEOS validity rules shapely documents answer them (the library itself is absent offline):
+    assert not pp.polygon_is_simple([(0, 0), (4, 0), (2, 2), (4, 4), (0, 4), (2, 2)])                 # ring touching itself at a vertex ("ring self-intersection")
+    assert not pp.polygon_is_simple([(0, 0), (4, 0), (4, 4), (2, 4), (2, 6), (2, 4), (0, 4)])        # zero-area spike: an edge run forth and back
+    assert not pp.polygon_is_simple([(0, 0), (4, 0), (4, 4), (2, 4), (2, 0), (0, 4)])                 # edge through a vertex of another edge + crossing
+    assert pp.polygon_is_simple([(0, 0), (2, 0), (2, 2), (0, 2), (0, 0)])                            # explicitly closed ring: the repeated point is fine
+    assert pp.polygon_is_simple([(0, 0), (2, 0), (2, 0), (2, 2), (0, 2)])                            # a repeated consecutive point is fine
+    assert pp.polygon_is_simple([(0, 0), (4, 0), (4, 1), (1, 1), (1, 3), (4, 3), (4, 4), (0, 4)])    # non-convex "C": valid
+    assert pp.polygon_is_simple([(0, 0), (0, 2), (2, 2), (2, 0)])                                    # clockwise orientation: valid (orientation is not a validity rule)
+    assert not pp.polygon_is_simple([(0, 0), (2, 0), (2, 2), (0, 2), (0, 0), (2, 0), (2, 2), (0, 2)])  # the same ring traversed twice: every edge is shared
     from oracle.standins.shapely.geometry import Polygon
     rng = np.random.RandomState(3)
     for _ in range(500):
