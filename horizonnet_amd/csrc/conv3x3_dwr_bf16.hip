@@ -463,11 +463,13 @@ int launch_dwr(const ConvArgsH& a, hipStream_t s)
 
 }  // namespace
 
-// shape: 0 = 256 x 256 tiles (Cout % 256 == 0, Wo in {32, 64, 128}), 1 = 512 x 128 tiles (Cout % 128 == 0, Wo in {32 .. 256})
+// shape: 0 = 256 x 256 tiles (Cout % 256 == 0, Wo in {32, 64, 128}), 1 = 512 x 128 tiles (Cout % 128 == 0, Wo in {32 .. 256}),
+// 2 = 512 x 64 tiles (conv3x3_dwr64_bf16.hip: Cout % 64 == 0, bf16 output without residual, no split-K)
 bool hn_conv_bf16_dwr_ok(const ConvArgsH& a, int shape)
 {
     const int group_rows = shape == 0 ? 128 : 256;
-    const int bn = shape == 0 ? 256 : 128;
+    const int bn = shape == 0 ? 256 : shape == 1 ? 128 : 64;
+    if (shape == 2 && (a.res != nullptr || a.ksplit > 1)) return false;
     return a.KH == 3 && a.KW == 3 && a.sw == 1 && a.pw == 1 && a.ph == 1 && a.Wi == a.Wo && (a.Wo & (a.Wo - 1)) == 0 && a.Wo >= 32 &&
            group_rows % a.Wo == 0 && a.Cout % bn == 0 && a.Cin % BKE == 0 && a.stat_sum == nullptr &&
            (a.ksplit <= 1 || ((a.ksplit & (a.ksplit - 1)) == 0 && (a.nk / 3) % a.ksplit == 0)) &&
@@ -479,6 +481,10 @@ int hn_launch_conv_bf16_dwr(const ConvArgsH& a, int out_f32, int shape, hipStrea
     HN_REQUIRE(hn_conv_bf16_dwr_ok(a, shape), "conv bf16 (dw reuse): 3x3, stride 1 / pad 1 along W, Wo a power of two that divides the group rows");
     HN_REQUIRE(!out_f32 || a.res == nullptr, "conv bf16 (dw reuse): no residual with float32 output");
     HN_REQUIRE(a.ksplit <= 1 || out_f32, "conv bf16 (dw reuse): split-K writes float32 partial tiles");
+    if (shape == 2) {
+        HN_REQUIRE(!out_f32, "conv bf16 (dw reuse, 64 columns): bf16 output only");
+        return hn_launch_conv_bf16_dwr64(a, s);
+    }
     if (shape == 0) return out_f32 ? launch_dwr<256, 256, true>(a, s) : launch_dwr<256, 256, false>(a, s);
     return out_f32 ? launch_dwr<512, 128, true>(a, s) : launch_dwr<512, 128, false>(a, s);
 }

@@ -65,6 +65,8 @@ static __device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_b
 // ping-pong persistent 256x256 kernel (conv_igemm_bf16_pp.hip): forward convs with Cout % 256 == 0 and K >= 128
 int hn_launch_conv_bf16_pp(const ConvArgsH& a, int out_f32, int variant, hipStream_t s);
 
-// 3x3 / stride 1 along W with the activations of a filter row loaded once (conv3x3_dwr_bf16.hip); shape 0: 256 x 256 tiles, 1: 512 x 128
+// 3x3 / stride 1 along W with the activations of a filter row loaded once (conv3x3_dwr_bf16.hip); shape 0: 256 x 256 tiles, 1: 512 x 128,
+// 2: 512 x 64 (conv3x3_dwr64_bf16.hip: bf16 output, no residual, no split-K)
 bool hn_conv_bf16_dwr_ok(const ConvArgsH& a, int shape);
 int hn_launch_conv_bf16_dwr(const ConvArgsH& a, int out_f32, int shape, hipStream_t s);
+int hn_launch_conv_bf16_dwr64(const ConvArgsH& a, hipStream_t s);

@@ -1232,6 +1232,7 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
     if ((force == 4 || force == 5) && t256 && a.nk >= 2) return hn_launch_conv_bf16_pp(a, OUT_F32 ? 1 : 0, force - 4, s);
     if ((force == 6 || force == 7) && hn_conv_bf16_dwr_ok(a, force - 6)) return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, force - 6, s);
+    if (force == 8 && !OUT_F32 && hn_conv_bf16_dwr_ok(a, 2)) return hn_launch_conv_bf16_dwr(a, 0, 2, s);
     if (force == 1 && t256) return launch_cfg_w8<256, 256, 2, 4, OUT_F32>(a, s);
     if (force == 2 && t256x128) return launch_cfg_w8<256, 128, 4, 2, OUT_F32>(a, s);
     if (force == 3 && t128x256) return launch_cfg_w8<128, 256, 2, 4, OUT_F32>(a, s);
@@ -1245,6 +1246,10 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     if (force < 0 && dwr && t256 >= 224 && hn_conv_bf16_dwr_ok(a, 0)) return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 0, s);
     if (force < 0 && dwr && t256 < 224 && (long)hn_cdiv(M, 512) * (Cout / 128) >= 224 && hn_conv_bf16_dwr_ok(a, 1))
         return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 1, s);
+    // 64 output channels (layer1's conv2, the 64-channel height-compression convs): 512 x 64 tiles, same rule
+    const char* d64 = getenv("HN_BF16_DWR64");        // 0 for A/B runs
+    if (force < 0 && dwr && !(d64 && atoi(d64) == 0) && !OUT_F32 && Cout == 64 && (long)hn_cdiv(M, 512) >= 224 && hn_conv_bf16_dwr_ok(a, 2))
+        return hn_launch_conv_bf16_dwr(a, 0, 2, s);
     if (force < 0 && t256 >= 224) {
         // ping-pong persistent kernel (conv_igemm_bf16_pp.hip); HN_BF16_PP=0 for A/B runs, 2 = with s_setprio
         const char* ppe = getenv("HN_BF16_PP");

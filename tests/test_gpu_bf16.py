@@ -551,7 +551,7 @@ def test_pingpong_conv_bit_identical(case, monkeypatch):
 
 
 DWR_CASES = [
-    # name, variant (6: 256 x 256 tiles, 7: 512 x 128), B, H, W, cin, cout, stride, residual
+    # name, variant (6: 256 x 256 tiles, 7: 512 x 128, 8: 512 x 64 of conv3x3_dwr64_bf16.hip), B, H, W, cin, cout, stride, residual
     ("256sq Wo=32 every row tile is a seam", "6", 3, 16, 32, 64, 256, 1, False),
     ("256sq Wo=64 s(2,1) ragged M", "6", 3, 10, 64, 128, 256, (2, 1), False),
     ("256sq Wo=128 residual two column tiles", "6", 2, 8, 128, 64, 512, 1, True),
@@ -559,6 +559,10 @@ DWR_CASES = [
     ("512x128 Wo=256 s(2,1)", "7", 2, 16, 256, 64, 128, (2, 1), False),
     ("512x128 Wo=128 residual ragged M", "7", 3, 7, 128, 128, 128, 1, True),
     ("512x128 Wo=32 two column tiles", "7", 4, 32, 32, 64, 256, 1, False),
+    ("512x64 Wo=256 one step per tile", "8", 2, 16, 256, 64, 64, 1, False),
+    ("512x64 Wo=256 s(2,1) two channel chunks", "8", 2, 16, 256, 128, 64, (2, 1), False),
+    ("512x64 Wo=32 ragged M two column tiles", "8", 3, 23, 32, 64, 128, 1, False),
+    ("512x64 Wo=128 persistent 300 tiles", "8", 6, 200, 128, 64, 64, 1, False),
 ]
 
 

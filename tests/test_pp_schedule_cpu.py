@@ -31,3 +31,17 @@ def test_model_detects_broken_dw_reuse_schedules(bug):
         for ns in (1, 2, 3):
             for nt in (1, 2, 3):
                 m.sweep(lambda w: m.dwr_program(w, ns, nt, 4, 1, bug), seeds=10)
+
+
+@pytest.mark.parametrize("nsteps,ntiles", [(1, 1), (1, 3), (2, 2), (3, 3), (6, 2)])
+def test_dw_reuse_64_column_schedule_is_race_free(nsteps, ntiles):
+    """conv3x3_dwr64_bf16.hip: two phases per chunk, weight ring of four, the epilogue slabs inside region A1 of the finished buffer."""
+    m.sweep(lambda w: m.dwr64_program(w, nsteps, ntiles), seeds=6)
+
+
+@pytest.mark.parametrize("bug", ["wait", "lgk", "slab", "norealign"])
+def test_model_detects_broken_64_column_schedules(bug):
+    with pytest.raises(AssertionError):
+        for ns in (1, 2, 3):
+            for nt in (2, 3):
+                m.sweep(lambda w: m.dwr64_program(w, ns, nt, bug), seeds=10)

@@ -93,7 +93,8 @@ def main():
             legal = v in (0, -1) or (v in (1, 3) and cout % 256 == 0) or (v == 2 and cout % 128 == 0) or \
                 (v in (4, 5) and cout % 256 == 0 and cin * k * k >= 128) or \
                 (v == 6 and k == 3 and sw == 1 and cout % 256 == 0 and 32 <= Wi <= 128) or \
-                (v == 7 and k == 3 and sw == 1 and cout % 128 == 0 and 32 <= Wi <= 256)      # 4 / 5: ping-pong kernel; 6 / 7: dw-reuse 3x3 kernel, 256x256 / 512x128 tiles
+                (v == 7 and k == 3 and sw == 1 and cout % 128 == 0 and 32 <= Wi <= 256) or \
+                (v == 8 and k == 3 and sw == 1 and cout % 64 == 0 and 32 <= Wi <= 256 and not res)      # 8: dw-reuse 512x64; 4 / 5: ping-pong kernel; 6 / 7: dw-reuse 3x3 kernel, 256x256 / 512x128 tiles
             if not legal:
                 row.append("      -      ")
                 continue

@@ -75,6 +75,11 @@ def simulate(make_prog, mode, seed=0):
                     for r in pending[w]:
                         check(w, r[1], r[2], r[3])
                     pending[w] = []
+                elif ins[0] == "slabw":                   # epilogue slabs inside an activation region: (slabw, region, buffer, identity)
+                    for ww in range(8):
+                        landed[(ins[1], ins[2], ww)] = ins[3]
+                elif ins[0] == "slabr":                   # ... still intact when the epilogue ends (no piece landed on them)
+                    check(w, ins[1], ins[2], ins[3])
                 elif ins[0] == "bar":
                     at_bar[w] = True
                     nbar[w] += 1
@@ -165,6 +170,43 @@ def dwr_program(w, nsteps, ntiles, APW=2, BPW=2, bug=None):
     return prog
 
 
+def dwr64_program(w, nsteps, ntiles, bug=None):
+    """conv3x3_dwr64_bf16_kernel (512 x 64 tiles, wave tile 128 x 32): TWO phases per chunk (K halves), ONE weight region per chunk in a
+    ring of four (B of chunk G+3 goes out in phase X of chunk G), the activations of step t+1 in phases X / Y of (t, dw 0); counted
+    waits in every Y phase: 10, 10, 2; every Y phase waits for its fragment reads in front of its barrier."""
+    g = w >> 2
+    total = nsteps * ntiles
+    prog = [("issue", "A0", 0, ("s", 0), 4), ("issue", "A1", 0, ("s", 0), 4)] + [("issue", "B", 10 + c, ("c", c), 1) for c in range(3)]
+    prog += [("wait", 2), ("bar",)]
+    if g == 1:
+        prog.append(("bar",))
+    G = 0
+    for t in range(total):
+        ab = t & 1
+        for dw in range(3):
+            bb = 10 + (G & 3)
+            prog += [("read", "A0", ab, ("s", t)), ("read", "A1", ab, ("s", t)), ("read", "B", bb, ("c", G)), ("issue", "B", 10 + ((G + 3) & 3), ("c", G + 3), 1)]
+            if dw == 0:
+                prog.append(("issue", "A0", ab ^ 1, ("s", t + 1), 4))
+            prog += [("bar",), ("lgk",), ("mfma",), ("bar",)]
+            prog += [("read", "A0", ab, ("s", t)), ("read", "A1", ab, ("s", t)), ("read", "B", bb, ("c", G))]
+            if dw == 0:
+                prog.append(("issue", "A1", ab ^ 1, ("s", t + 1), 4))
+            n = (2 if dw == 2 else 10) + (1 if bug == "wait" else 0)
+            prog.append(("wait", n))
+            prog += [("bar",), ("lgk",), ("mfma",), ("bar",)] if bug == "lgk" else [("lgk",), ("bar",), ("mfma",), ("bar",)]
+            G += 1
+        if (t + 1) % nsteps == 0:                       # the slabs live in region A1 of the buffer this tile has just finished with
+            if g == 0 and bug != "norealign":
+                prog.append(("bar",))
+            prog += [("slabw", "A0" if bug == "slab" else "A1", ab, ("slab", t)), ("slabr", "A0" if bug == "slab" else "A1", ab, ("slab", t))]
+            if t + 1 == total:
+                break
+            if g == 1 and bug != "norealign":
+                prog.append(("bar",))
+    return prog
+
+
 def sweep(make, seeds=10):
     for mode in ("early", "late", "random"):
         for seed in range(seeds):
@@ -179,4 +221,7 @@ if __name__ == "__main__":
         for ns in (1, 2, 3, 6):
             for nt in (1, 2, 3):
                 sweep(lambda w: dwr_program(w, ns, nt, apw, bpw))
+    for ns in (1, 2, 3, 6):
+        for nt in (1, 2, 3):
+            sweep(lambda w: dwr64_program(w, ns, nt))
     print("schedule model: ok")
