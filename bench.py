@@ -284,7 +284,7 @@ def seeded_net_from_state(seed):
     return net
 
 
-def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with_curve=True):
+def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with_curve=True, allreduce_dtype="f32"):
     """BASELINE configs[2] (and configs[3] at world > 1): the loop of reference train.py:246-286 on the engine.  Every step
     draws its batch through the device data pipeline INSIDE the timed region -- DeviceBatcher: Pano-Stretch + flip + roll +
     gamma in one fused launch (dataset.py:70-105) plus the host label rasterisation (dataset.py:85,108-120) -- then
@@ -298,6 +298,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
     data = DeviceBatcher(images=imgs, corners=cors, device=dev, flip=True, rotate=True, gamma=True, stretch=True)
     net = seeded_net(0).to(dev).train()
     net.train_precision = dtype          # bf16: the three conv GEMMs on the bf16 matrix cores, rest f32
+    net.allreduce_dtype = allreduce_dtype   # "bf16": the gradient ranges travel as bf16 (163 MB instead of 326 MB over xGMI)
     broadcast_module_(net)
     from horizonnet_amd.optim import FusedAdam
     opt = FusedAdam(net, lr=1e-4, betas=(0.9, 0.999))     # one hn_adam_step launch over the flat gradient buffer (train.py:216-225,279)
@@ -358,7 +359,15 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
                    "overlap_fraction": round(1.0 - exposed_ms / rccl["allreduce_ms"], 3) if rccl and rccl["allreduce_ms"] > 0 else None,
                    "note": "backward runs in 5 gradient-completion segments; each finished range of the flat gradient buffer starts its "
                            "RCCL all-reduce at once (64 MB buckets) while the remaining segments compute"}
+        overlap.update(traced_backward(net, step, dev))
     close_batches()
+    host_half_ms = {}
+    for label_mode in (True, False):                       # one batch's host half (draws + labels), labels on the device / on the host
+        keep, data.device_labels = data.device_labels, label_mode
+        th = time.perf_counter()
+        data.host_half(list(np.random.RandomState(5).randint(len(data), size=B)), np.random.RandomState(6))
+        host_half_ms["device_labels" if label_mode else "host_labels"] = round((time.perf_counter() - th) * 1e3, 2)
+        data.device_labels = keep
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     flop = 3.0 * FWD_FLOP_PER_PANO * B * world * steps          # fwd + dgrad + wgrad
     out = {"metric": "training panoramas/s (512x1024, data pipeline + fwd + bwd + Adam)", "value": round(B * world * steps / wall, 2),
@@ -369,12 +378,15 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
                                   % (2 if world == 1 else 3, "float32 engine" if dtype == "f32" else
                                      "bf16 MFMA conv GEMMs (forward, data and weight gradients), f32 accumulation / BN / LSTM / master weights"),
                       "batch_per_gpu": B, "global_batch": B * world, "rooms_per_gpu": len(cors),
-                      "parallelism": "dp%d (one process per GPU, RCCL all-reduce of the flat 326 MB gradient buffer overlapped with backward)" % world},
+                      "parallelism": "dp%d (one process per GPU, RCCL all-reduce of the flat 326 MB gradient buffer overlapped with backward)" % world,
+                      "allreduce_dtype": allreduce_dtype, "defer_grad_mean": bool(getattr(net, "defer_grad_mean", False)),
+                      "labels": "device (hn_labels_rasterise)" if data.device_labels else "host (labels.py)"},
            "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flop: forward, data gradient, weight gradient GEMMs)",
                         "achieved": round(flop / wall / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(flop / wall / 1e12 / world / peak, 4), "traffic": None,
                         "note": "per GPU, against the dense MFMA peak of the GEMM dtype (%s)" % ("fp32 matrix 157.3 TF" if dtype == "f32" else "bf16 2.5 PF")},
-           "host_data_pipeline_ms_per_step": round(host_s / steps * 1e3, 2),
+           "host_data_pipeline_ms_per_step": round(host_s / steps * 1e3, 2),       # time the step waited for its batch (host thread two batches ahead)
+           "host_half_ms_per_batch": host_half_ms,                                # one thread's work per batch of B: what 8 ranks per host must fit 8 x of
            "final_loss": float(loss.detach())}
     if rccl is not None:
         out["rccl"] = rccl
@@ -385,6 +397,35 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
     del net, opt, data
     torch.cuda.empty_cache()
     return out
+
+
+def traced_backward(net, step, dev):
+    """ONE more step with net.allreduce_trace on (model.py: device events at the start of the backward, after every gradient segment's
+    kernels, at the end of every all-reduce bucket) -> when each bucket could start, when it was done, and how much of the exchange
+    ran under the backward's own kernels: the diagnosis of an N-GPU run in the bench line itself."""
+    net.allreduce_trace = []
+    step()
+    torch.cuda.synchronize(dev)
+    tr, net.allreduce_trace = net.allreduce_trace, None
+    t0 = [e for e in tr if e["kind"] == "start"][-1]["event"]
+    segs = [e for e in tr if e["kind"] == "segment"]
+    seg_end = {e["segment"]: t0.elapsed_time(e["event"]) for e in segs}
+    compute_end = max(seg_end.values()) if seg_end else 0.0
+    rows, prev_done, busy, hidden = [], 0.0, 0.0, 0.0
+    for e in [e for e in tr if e["kind"] == "bucket"]:
+        done = t0.elapsed_time(e["event"])
+        begin = max(seg_end[e["segment"]], prev_done)                   # buckets queue behind each other on RCCL's stream
+        rows.append({"segment": e["segment"], "bucket": e["bucket"], "MB": round(e["bytes"] / 1e6, 1), "may_start_ms": round(seg_end[e["segment"]], 2),
+                     "done_ms": round(done, 2), "GBps": round(e["bytes"] / max(done - begin, 1e-3) / 1e6, 1)})
+        busy += max(0.0, done - begin)
+        hidden += max(0.0, min(done, compute_end) - min(begin, compute_end))
+        prev_done = max(prev_done, done)
+    return {"traced_step": {"segment_kernels_done_ms": [round(seg_end[k], 2) for k in sorted(seg_end)], "backward_kernels_done_ms": round(compute_end, 2),
+                            "last_bucket_done_ms": round(prev_done, 2), "exchange_busy_ms": round(busy, 2),
+                            "exchange_under_backward_kernels_ms": round(hidden, 2),
+                            "overlap_fraction_traced": round(hidden / busy, 3) if busy > 0 else None, "buckets": rows,
+                            "note": "ms from the start of the backward on the device clock; a bucket may start when its segment's kernels are "
+                                    "done and the previous bucket has left RCCL's stream"}}
 
 
 def max_over_ranks(value, dist, dev):
@@ -568,6 +609,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for --gpus N (nccl = RCCL, the product path; gloo only to exercise the N > 1 "
                          "code path on a box with one GPU, together with --share-gpu)")
+    ap.add_argument("--allreduce-dtype", choices=["f32", "bf16"], default="f32",
+                    help="train mode, N > 1: wire format of the gradient all-reduce (bf16 = 163 MB instead of 326 MB per step over xGMI; the sum is "
+                         "rounded to bf16 -- net.allreduce_dtype)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--mode", choices=["forward", "train", "layout"], default="forward",
                     help="forward = the headline metric (default, configs[1]); train = configs[2]/[3]: one optimisation step per step "
@@ -652,7 +696,7 @@ def main():
             dist.destroy_process_group()
         return
     if args.mode == "train":
-        out = train_leg(dev, world, rank, args.batch, args.steps, args.warmup, dist, args.dtype, rccl, rooms["train"])
+        out = train_leg(dev, world, rank, args.batch, args.steps, args.warmup, dist, args.dtype, rccl, rooms["train"], allreduce_dtype=args.allreduce_dtype)
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:

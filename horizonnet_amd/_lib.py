@@ -73,6 +73,7 @@ SIGNATURES = {
     "hn_conv2d_wgrad_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_pano_stretch": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _i, _i, _i, _i, _vp]),
     "hn_pano_stretch_tables": (_i, [_vp, _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hn_labels_rasterise": (_i, [_vp, _i, _i, _i, _i, _i, _i, _c.c_double, _vp, _vp, _vp, _vp]),
     "hn_augment_batch": (_i, [_vp, _i, _c.POINTER(_c.c_int), _vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                                _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _i, _i, _i, _vp]),
     "hn_find_peaks": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),

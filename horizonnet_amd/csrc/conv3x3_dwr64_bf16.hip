@@ -26,6 +26,13 @@
 
 #include <type_traits>
 
+// measurement builds only (tools/pp_ablate.sh d64_N): 1 no LDS-DMA, 2 no fragment reads after the first chunk, 4 no barriers, 8 no MFMAs,
+// 16 no counted waits, 32 no epilogue (the compiler then drops the MFMAs and fragment reads too), 64 epilogue without its stores,
+// 128 non-temporal stores -- the results are wrong, only the timing means something
+#ifndef HN_D64_ABL
+#define HN_D64_ABL 0
+#endif
+
 namespace {
 
 constexpr int BM = 512, BN = 64;
@@ -148,11 +155,13 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
         }
     };
     auto issue_a = [&](int abuf, int reg) {
+        if (HN_D64_ABL & 1) return;
         const unsigned dst = lds0 + (unsigned)(abuf * ABUF + reg * REGION_A + wave * 1024);
 #pragma unroll
         for (int ps = 0; ps < APW; ++ps) pp_dma16<0>(rsrc_a, dst + ps * 8192, reg ? a_off[APW + ps] : a_off[ps], (unsigned)c0 * 2u);
     };
     auto issue_b = [&](int slot) {
+        if (HN_D64_ABL & 1) return;
         pp_dma16<0>(rsrc_w, lds0 + (unsigned)(B_OFF + slot * BSLOT + wave * 1024), w_off, (unsigned)bkc * (unsigned)ROWB);
     };
 
@@ -176,8 +185,10 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
 #pragma unroll
     for (int s = 0; s < 4; ++s) rd_b[s] = (unsigned)(B_OFF + (32 * wn + fr) * ROWB + (((2 * s + half) ^ fswz) * 16));
     const int seam_bytes = p.Wo * ROWB;
+    bool abl_first = true;
     auto read_a = [&](auto dw_c, int h) {                   // see conv3x3_dwr_bf16.hip: the lane at an image-row seam reads Wo rows away
         constexpr int DW = decltype(dw_c)::value;
+        if ((HN_D64_ABL & 2) && !abl_first) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t0 = 128 * wm2 + 32 * i;
@@ -196,11 +207,13 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
     };
     int bslot = 0;
     auto read_b = [&](int h) {
+        if ((HN_D64_ABL & 2) && !abl_first) return;
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh) fb[sh] = *reinterpret_cast<const u32x4*>(smem + rd_b[2 * h + sh] + bslot * BSLOT);
     };
     auto mm = [&](auto tap0_c, auto tapn_c) {
         constexpr int TAP0 = decltype(tap0_c)::value, TAPN = decltype(tapn_c)::value;
+        if (!(HN_D64_ABL & 8))
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
@@ -256,7 +269,10 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
                 u32x4 o;
                 o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                 o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
-                *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + colg) = o;
+                u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + colg);
+                if (HN_D64_ABL & 64) { if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u) *dst = o; }      // (practically) no stores
+                else if (HN_D64_ABL & 128) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
             }
         }
     };
@@ -273,8 +289,9 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
     tap_rows(0, AK);
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // step 0's activations and chunk 0's weights have landed (this wave's pieces)
     pp_bar_raw();
-    if (g == 1) pp_bar_raw();                              // group 1 runs one barrier behind group 0 from here on
+    if (g == 1 && !(HN_D64_ABL & 4)) pp_bar_raw();         // group 1 runs one barrier behind group 0 from here on
 
+    auto bar = [&]() { if (!(HN_D64_ABL & 4)) pp_bar_raw(); };
     int abuf = 0;
     int adelta = ABUF;
     auto chunk = [&](auto dw_c) {
@@ -285,21 +302,23 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
         issue_b((bslot + 3) & 3);                          // weights of chunk G+3
         if (DW == 0) issue_a(abuf ^ 1, 0);                 // A0 of the next step
         if (DW == 1) advance_a();
-        pp_bar_raw();
+        bar();
         if constexpr (DW == 1) mm(I0{}, I4{}); else mm(I0{}, I0{});
-        pp_bar_raw();
+        bar();
         // ---- phase Y: K half 1; the last reads of this chunk's weights (and, dw 2, of this step's activations) ----
         read_a(dw_c, 1);
         read_b(1);
         if (DW == 0) issue_a(abuf ^ 1, 1);                 // A1 of the next step
         advance_b();
-        if (DW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // the next step's activations and the next chunk's weights
+        if (HN_D64_ABL & 16) {}
+        else if (DW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // the next step's activations and the next chunk's weights
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");            // the next chunk's weights
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        pp_bar_raw();
+        bar();
         if constexpr (DW == 1) mm(I4{}, I4{}); else mm(I0{}, I0{});
-        pp_bar_raw();
+        bar();
         bslot = (bslot + 1) & 3;
+        abl_first = false;
     };
     while (true) {
         chunk(std::integral_constant<int, 0>{});
@@ -314,8 +333,8 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
         adelta = -adelta;
         if (++cstep == nsteps) {                           // tile finished
             cstep = 0;
-            if (g == 0) pp_bar_raw();                      // wait for group 1's last MFMA block (its reads of this buffer retired in front of it)
-            epilogue(cm0, cn0, done_buf);
+            if (g == 0) bar();                      // wait for group 1's last MFMA block (its reads of this buffer retired in front of it)
+            if (!(HN_D64_ABL & 32)) epilogue(cm0, cn0, done_buf);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -323,7 +342,7 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
             cvb += nwg;
             if (cvb >= total) break;
             tile_coords(cvb, cm0, cn0);
-            if (g == 1) pp_bar_raw();                      // re-stagger
+            if (g == 1) bar();                      // re-stagger
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus (out-of-range) pieces of the loader

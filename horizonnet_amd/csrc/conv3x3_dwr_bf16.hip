@@ -280,6 +280,18 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
     using I0 = std::integral_constant<int, 0>;
 
     // ---- epilogue of the wave's 128 x 64 tile: 8 rounds of 16 rows through the wave's 4 KiB slab (see conv_igemm_bf16_pp.hip) ----
+    // folded-BN scale / shift of the wave's columns stay in registers across tiles: a global load at the head of the epilogue is exposed
+    // latency, and the vmcnt(0) hipcc puts behind it also waits for every LDS-DMA piece in flight
+    float sc[2], sf[2];
+    int sc_n0 = cn0;
+    auto load_scale = [&](int en0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sc[j] = p.scale[en0 + 64 * wn + 32 * j + fr];
+            sf[j] = p.shift[en0 + 64 * wn + 32 * j + fr];
+        }
+    };
+    if constexpr (G::PERSIST) load_scale(cn0);          // (one tile per workgroup otherwise: loaded in the epilogue, no registers held across the loop)
     auto epilogue = [&](int em0, int en0, int esl, auto has_res_c) {
         constexpr bool HAS_RES = decltype(has_res_c)::value;
         const bool raw = OUT_F32 && p.ksplit > 1;       // split-K partial tile: no scale / shift (the reduce kernel applies them once)
@@ -288,11 +300,9 @@ __global__ __launch_bounds__(512) void conv3x3_dwr_bf16_kernel(ConvArgsH p)
         const int ec = (lane & 7) * 8;
         const int colg = en0 + 64 * wn + ec;
         const int mrow0 = em0 + G::GROUP_ROWS * g + 128 * wm2 + er;
-        float sc[2], sf[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            sc[j] = p.scale[en0 + 64 * wn + 32 * j + fr];
-            sf[j] = p.shift[en0 + 64 * wn + 32 * j + fr];
+        if (!G::PERSIST || en0 != sc_n0) {              // rare: a persistent workgroup's tiles share their column tile (grid % column tiles == 0)
+            sc_n0 = en0;
+            load_scale(en0);
         }
         const size_t slice_off = (size_t)esl * p.M * p.ldy;
         u32x4 rres[HAS_RES ? 8 : 1];

@@ -280,6 +280,18 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     using NoTaps = std::integral_constant<int, -1>;
 
     // ---- epilogue of the wave's 128 x 64 tile: 8 rounds of 16 rows through the wave's slab ----
+    // folded-BN scale / shift of the wave's columns stay in registers across tiles: a global load at the head of the epilogue is exposed
+    // latency, and the vmcnt(0) hipcc puts behind it also waits for every LDS-DMA piece in flight
+    float sc[2], sf[2];
+    int sc_n0 = cn0;
+    auto load_scale = [&](int en0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sc[j] = p.scale[en0 + 64 * wn + 32 * j + fr];
+            sf[j] = p.shift[en0 + 64 * wn + 32 * j + fr];
+        }
+    };
+    load_scale(cn0);
     auto epilogue = [&](int em0, int en0, auto has_res_c) {
         // (HAS_RES is a compile-time copy of the body: with a runtime `if` around the residual loads AND around their uses hipcc
         //  assumes loads that were never consumed and makes the next chunk's fragment reads wait for them -- vmcnt(0), i.e. for the
@@ -290,11 +302,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
         const int ec = (lane & 7) * 8;                  // 8 consecutive channels of the wave's 64
         const int colg = en0 + 64 * wn + ec;
         const int mrow0 = em0 + 128 * g + er;
-        float sc[2], sf[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            sc[j] = p.scale[en0 + 64 * wn + 32 * j + fr];
-            sf[j] = p.shift[en0 + 64 * wn + 32 * j + fr];
+        if (en0 != sc_n0) {                             // rare: a persistent workgroup's tiles share their column tile (grid % column tiles == 0)
+            sc_n0 = en0;
+            load_scale(en0);
         }
         // residual rows: a ring of 8 requests (4 rounds) ahead of their use
         u32x4 rres[HAS_RES ? 8 : 1];

@@ -6,7 +6,9 @@ image half on the MI355X.
 * ``DeviceBatcher``: the MI355X-shaped path.  The decoded dataset sits in HBM as uint8 (1.5 MB per panorama; a
   20k-panorama training set is 31 GB of the 288 GB); a training batch is ONE fused launch (``hn_augment_batch``:
   /255, Pano-Stretch, flip, roll, gamma, HWC->CHW) straight into the float32 NCHW tensor the engine consumes.  The
-  labels (<= ~30 corners and two 1024-long vectors per sample) are rasterised on the host (``labels.py``).
+  labels are rasterised on the device too (``hn_labels_rasterise``, csrc/labels.hip): the host keeps the per-corner
+  scalars (<= ~30 corners, the reference's float32 flow) and every per-column operation runs in one more launch;
+  ``device_labels=False`` keeps the host rasterisation (``labels.py``, ~1.5 ms per panorama).
 
 The augmentation parameters are drawn by ``draw_augmentation`` in the reference's order (stretch: uniform, uniform,
 randint, randint; flip: randint; rotate: randint; gamma: uniform, randint), so a seeded run reproduces the reference's
@@ -20,7 +22,8 @@ import torch
 
 from . import _lib
 from .augment import sample_stretch
-from .labels import cor_2_1d, corner_probability, find_occlusion, flip_labels, roll_labels
+from .labels import (LABEL_MAX_CORNERS, LABEL_MAX_EDGES, LABEL_REC_FLOATS, cor_2_1d, corner_probability, device_label_record, find_occlusion,
+                     flip_labels, roll_labels)
 from .panostretch import _stretch_corners
 
 
@@ -151,7 +154,8 @@ class DeviceBatcher:
     augmented training batch on the device: (x [B,3,H,W], bon [B,2,W], y_cor [B,1,W]) float32."""
 
     def __init__(self, root_dir=None, images=None, corners=None, device="cuda", flip=False, rotate=False, gamma=False,
-                 stretch=False, p_base=0.96, max_stretch=2.0):
+                 stretch=False, p_base=0.96, max_stretch=2.0, device_labels=True):
+        self.device_labels = bool(device_labels)
         if root_dir is not None:
             img_dir, cor_dir, names, labels = _list_samples(root_dir)
             images = np.stack([_decode(os.path.join(img_dir, n)) for n in names])
@@ -171,22 +175,35 @@ class DeviceBatcher:
         return len(self.labels)
 
     def host_half(self, indices, rng=np.random):
-        """The host part of one batch: augmentation draws (reference order) + label rasterisation ->
-        (indices, augs, bon [B,2,W] float32, y_cor [B,1,W] float32)."""
+        """The host part of one batch: augmentation draws (reference order) + the labels' host half ->
+        (indices, augs, bon, y_cor).  device_labels: bon = the per-panorama records [B, LABEL_REC_FLOATS] float32 for
+        hn_labels_rasterise and y_cor = {row: (bon [2,W], y_cor [1,W])} for the panoramas that must be rasterised on the host
+        (an outline that does not close; normally empty).  Otherwise bon [B,2,W] / y_cor [B,1,W] float32 from labels.py."""
         augs, bons, cors = [], [], []
-        for i in indices:
+        recs = np.empty((len(indices), LABEL_REC_FLOATS), np.float32) if self.device_labels else None
+        on_host = {}
+        for row, i in enumerate(indices):
             cor, occ = self.labels[i]
             a = draw_augmentation(cor, self.W, self.flip, self.rotate, self.gamma, self.stretch, self.max_stretch, rng)
-            bon, y_cor, _ = make_labels(cor, occ, a, self.H, self.W, self.p_base)
             augs.append(a)
+            if self.device_labels:
+                c = cor if (a["kx"] == 1.0 and a["ky"] == 1.0) else _stretch_corners(cor, a["kx"], a["ky"], self.W, self.H)
+                _, closed = device_label_record(c, occ, a["flip"], a["roll"] if a["rotate"] else None, self.H, self.W, out=recs[row])
+                if not closed:
+                    bon, y_cor, _ = make_labels(cor, occ, a, self.H, self.W, self.p_base)
+                    on_host[row] = (bon.astype(np.float32), y_cor.astype(np.float32))
+                continue
+            bon, y_cor, _ = make_labels(cor, occ, a, self.H, self.W, self.p_base)
             bons.append(bon)
             cors.append(y_cor)
+        if self.device_labels:
+            return list(indices), augs, recs, on_host
         return list(indices), augs, np.stack(bons).astype(np.float32), np.stack(cors).astype(np.float32)
 
     def device_half(self, indices, augs, bon, y_cor):
-        """The device part: one fused augmentation launch + the label upload.  The labels go through a ring of PINNED
-        staging tensors: a copy from pageable memory is a host-side wait for the stream on ROCm, i.e. one full
-        host <-> GPU synchronisation per training step."""
+        """The device part: one fused augmentation launch + the labels (device_labels: the record upload and ONE rasterisation
+        launch; otherwise the upload of the host-rasterised vectors).  Uploads go through a ring of PINNED staging tensors: a copy
+        from pageable memory is a host-side wait for the stream on ROCm, i.e. one full host <-> GPU synchronisation per step."""
         x = augment_images(self.data, indices, augs)
         dev = self.data.device
         B = len(indices)
@@ -197,10 +214,27 @@ class DeviceBatcher:
         slot = self._staging[k]
         if slot is None or slot["bon"].shape[0] < B:
             slot = {"bon": torch.empty((B, 2, self.W), dtype=torch.float32).pin_memory(),
-                    "cor": torch.empty((B, 1, self.W), dtype=torch.float32).pin_memory(), "done": torch.cuda.Event()}
+                    "cor": torch.empty((B, 1, self.W), dtype=torch.float32).pin_memory(),
+                    "rec": torch.empty((B, LABEL_REC_FLOATS), dtype=torch.float32).pin_memory(), "done": torch.cuda.Event()}
             self._staging[k] = slot
         else:
             slot["done"].synchronize()                  # the upload that last used this slot (ring-size batches ago)
+        if self.device_labels:
+            slot["rec"][:B].copy_(torch.from_numpy(bon))
+            with torch.cuda.device(dev):
+                d_rec = slot["rec"][:B].to(dev, non_blocking=True)
+                slot["done"].record()
+                d_bon = torch.empty((B, 2, self.W), dtype=torch.float32, device=dev)
+                d_cor = torch.empty((B, 1, self.W), dtype=torch.float32, device=dev)
+                status = torch.empty((B,), dtype=torch.int32, device=dev)
+                _lib.check(_lib.load().hn_labels_rasterise(_lib.ptr(d_rec), LABEL_REC_FLOATS, LABEL_MAX_EDGES, LABEL_MAX_CORNERS, B, self.H, self.W,
+                                                          float(self.p_base), _lib.ptr(d_bon), _lib.ptr(d_cor), _lib.ptr(status),
+                                                          _lib.stream_ptr(dev)), "hn_labels_rasterise")
+                for row, (hb, hc) in y_cor.items():     # outlines the device kernel does not take (host_half)
+                    d_bon[row].copy_(torch.from_numpy(hb))
+                    d_cor[row].copy_(torch.from_numpy(hc))
+            self.last_label_status = status             # device int32 [B]: 1 = a column without a trace point (tests read it)
+            return x, d_bon, d_cor
         slot["bon"][:B].copy_(torch.from_numpy(bon))
         slot["cor"][:B].copy_(torch.from_numpy(y_cor))
         with torch.cuda.device(dev):

@@ -3,7 +3,7 @@
 (``pano_connect_points``).
 
 Per-image scalar work on <= ~30 corners and 1024 columns; host numpy as in the reference, same arithmetic and the same
-numpy dtype flow (float32 corner scalars, float64 column vectors), pinned by ``tests/golden/labels.npz``."""
+numpy dtype flow (float32 corner scalars, float64 column vectors), pinned by ``tests/golden/dataset.npz`` (written by the reference's own ``__getitem__``)."""
 import numpy as np
 
 
@@ -15,11 +15,9 @@ def _lat(y, h):
     return ((y + 0.5) / h - 0.5) * np.pi
 
 
-def pano_connect_points(p1, p2, z=-50, w=1024, h=512):
-    """Image-space trace, one point per integer column, of the straight wall edge joining the corners p1 and p2 on
-    the horizontal plane z (ceiling z<0, floor z>0) -- the great-arc between them."""
-    if p1[0] == p2[0]:
-        return np.array([p1, p2], np.float32)
+def edge_scalars(p1, p2, z=-50, w=1024, h=512):
+    """The per-corner half of ``pano_connect_points`` (panostretch.py:51-70), in the reference's float32 scalar flow: the edge's first
+    end point (x1, y1) and direction (dx, dy) on the plane z, and the integer columns it covers (first, last; the short way round)."""
     u1, v1, u2, v2 = _lon(p1[0], w), _lat(p1[1], h), _lon(p2[0], w), _lat(p2[1], h)
     r1, r2 = z / np.tan(v1), z / np.tan(v2)
     x1, y1 = r1 * np.cos(u1), r1 * np.sin(u1)
@@ -29,8 +27,16 @@ def pano_connect_points(p1, p2, z=-50, w=1024, h=512):
         first, last = np.ceil(lo), np.floor(hi)
     else:                                   # the short way round crosses the image border
         first, last = np.ceil(hi), np.floor(lo + w)
+    return x1, y1, x2 - x1, y2 - y1, first, last
+
+
+def pano_connect_points(p1, p2, z=-50, w=1024, h=512):
+    """Image-space trace, one point per integer column, of the straight wall edge joining the corners p1 and p2 on
+    the horizontal plane z (ceiling z<0, floor z>0) -- the great-arc between them."""
+    if p1[0] == p2[0]:
+        return np.array([p1, p2], np.float32)
+    x1, y1, dx, dy, first, last = edge_scalars(p1, p2, z, w, h)
     cols = (np.arange(first, last + 1) % w).astype(np.float64)
-    dx, dy = x2 - x1, y2 - y1
     t = np.tan(_lon(cols, w))
     s = (t * x1 - y1) / (dy - t * dx)       # where the column's ray meets the edge
     rng = np.sqrt((x1 + s * dx) ** 2 + (y1 + s * dy) ** 2)
@@ -72,6 +78,53 @@ def corner_probability(corx, W=1024, p_base=0.96):
     cols = np.arange(W).reshape(1, -1)
     d = np.minimum(np.minimum(np.abs(corx - cols), np.abs(corx - (cols + W))), np.abs(corx - (cols - W)))
     return (p_base ** d.min(0)).reshape(1, -1)
+
+
+LABEL_MAX_EDGES = 64       # wall edges per boundary in a device record (general layouts have <= ~16)
+LABEL_MAX_CORNERS = 128    # visible wall-wall corners
+LABEL_REC_FLOATS = 8 + 2 * LABEL_MAX_EDGES * 8 + LABEL_MAX_CORNERS
+
+
+def device_label_record(cor, occlusion, flip, roll, H, W, out=None):
+    """One panorama's record for ``hn_labels_rasterise`` (csrc/labels.hip): the per-corner scalars of every wall edge (``edge_scalars``,
+    the reference's float32 flow) + the visible corner columns after flip / roll (dataset.py:88-97,113-118).  `cor`: the corners AFTER
+    the stretch, BEFORE flip / roll (cor_2_1d runs there, dataset.py:84).  Returns (record float32 [LABEL_REC_FLOATS], closed): closed
+    False = some column is covered by no edge of a boundary -> rasterise this panorama with ``cor_2_1d`` instead."""
+    rec = np.zeros(LABEL_REC_FLOATS, np.float32) if out is None else out
+    rec[:] = 0
+    n = len(cor)
+    closed = n // 2 <= LABEL_MAX_EDGES
+    for bd, z in ((0, -50), (1, 50)):
+        covered = np.zeros(W, bool)
+        k = 0
+        for i in range(n // 2):
+            if k >= LABEL_MAX_EDGES:
+                break
+            p1, p2 = cor[i * 2 + bd], cor[(i * 2 + 2 + bd) % n]
+            e = rec[8 + (bd * LABEL_MAX_EDGES + k) * 8:8 + (bd * LABEL_MAX_EDGES + k + 1) * 8]
+            if p1[0] == p2[0]:
+                e[0], e[1], e[2], e[3] = 1, p1[0], p1[1], p2[1]
+                if float(p1[0]) == int(p1[0]):
+                    covered[int(p1[0]) % W] = True
+            else:
+                x1, y1, dx, dy, first, last = edge_scalars(p1, p2, z, W, H)
+                cnt = max(0, int(last) - int(first) + 1)
+                e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7] = 0, x1, y1, dx, dy, first, cnt, z
+                covered[(int(first) + np.arange(cnt)) % W] = True
+            k += 1
+        rec[bd] = k
+        closed = closed and bool(covered.all())
+    cx = np.asarray(cor[:, 0], np.float32)
+    if flip:
+        cx = W - 1 - cx                                   # dataset.py:89 (float32 array arithmetic, as flip_labels)
+    if roll is not None:
+        cx = (cx + roll) % W                              # dataset.py:96
+    cx = cx[~np.asarray(occlusion, bool)]
+    nc = min(len(cx), LABEL_MAX_CORNERS)
+    closed = closed and len(cx) <= LABEL_MAX_CORNERS
+    rec[2], rec[3], rec[4] = nc, 1 if flip else 0, 0 if roll is None else int(roll) % W
+    rec[8 + 2 * LABEL_MAX_EDGES * 8:8 + 2 * LABEL_MAX_EDGES * 8 + nc] = cx[:nc]
+    return rec, closed
 
 
 def flip_labels(bon, cor, W):

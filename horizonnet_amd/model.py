@@ -345,6 +345,17 @@ class _HipTrainStep(torch.autograd.Function):
                 from .parallel import allreduce_sum_async
                 works, casts = [], []
                 half_wire = getattr(net, "allreduce_dtype", "f32") == "bf16" and world > 1
+                # net.allreduce_trace = [] asks for the timing of ONE backward: device events at the start, after every segment's
+                # kernels, and (on a side stream that waits for the collective) at the end of every bucket -- bench.py turns them into
+                # the per-bucket table of its allreduce_overlap block.  Off (None) in normal steps: nothing is recorded.
+                trace = getattr(net, "allreduce_trace", None)
+                if trace is not None:
+                    side = getattr(net, "_trace_stream", None)
+                    if side is None:
+                        side = net._trace_stream = torch.cuda.Stream(device=dev)
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    trace.append({"kind": "start", "event": ev0})
                 lo, cnt = ctypes.c_int64(), ctypes.c_int64()
                 for seg in range(st.lib.hn_grad_segments()):
                     _lib.check(st.lib.hn_train_backward_segment(*args, seg, _lib.stream_ptr(dev)), "hn_train_backward_segment")
@@ -354,7 +365,20 @@ class _HipTrainStep(torch.autograd.Function):
                         half = part.to(torch.bfloat16)
                         casts.append((part, half))
                         part = half
-                    works += allreduce_sum_async(part, net.process_group)
+                    new_works = allreduce_sum_async(part, net.process_group)
+                    if trace is not None:
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record()                                  # this segment's kernels (and the cast) are done: its buckets may start
+                        trace.append({"kind": "segment", "segment": seg, "event": ev, "bytes": part.numel() * part.element_size()})
+                        per = max(1, (64 << 20) // part.element_size())
+                        for k, w in enumerate(new_works):
+                            with torch.cuda.stream(side):
+                                w.wait()                             # the side stream waits for the collective; the compute stream does not
+                                evd = torch.cuda.Event(enable_timing=True)
+                                evd.record(side)
+                            trace.append({"kind": "bucket", "segment": seg, "bucket": k, "event": evd,
+                                          "bytes": min(per, part.numel() - k * per) * part.element_size()})
+                    works += new_works
                 for w in works:
                     w.wait()
                 for full, half in casts:                             # bf16 exchange: the summed halves back into the f32 buffer

@@ -335,6 +335,19 @@ def test_bench_two_rank_self_launch_train():
     assert rec["allreduce_overlap"]["ms_per_step_with_allreduce"] > 0 and rec["rccl"]["world_size_seen_by_rccl"] == 2
 
 
+def test_bench_two_rank_train_bf16_wire_and_deferred_mean():
+    """The flags an 8-GPU run would use, through bench.py itself: gradients travel as bf16 (--allreduce-dtype bf16), FusedAdam takes the
+    1 / world mean into its own launch (defer_grad_mean), labels rasterised on the device; plus the traced step's per-bucket table."""
+    rec = _bench_two_ranks(["--mode", "train", "--dtype", "bf16", "--allreduce-dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"])
+    cfg = rec["config"]
+    assert cfg["allreduce_dtype"] == "bf16" and cfg["defer_grad_mean"] is True and cfg["labels"].startswith("device")
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and np.isfinite(rec["final_loss"])
+    tr = rec["allreduce_overlap"]["traced_step"]
+    assert len(tr["segment_kernels_done_ms"]) == 5 and tr["buckets"] and tr["last_bucket_done_ms"] > 0
+    assert sum(b["MB"] for b in tr["buckets"]) == pytest.approx(163.1, abs=1.0)          # 81.57 M gradients x 2 bytes
+    assert rec["host_half_ms_per_batch"]["device_labels"] > 0
+
+
 def test_bench_two_rank_self_launch_layout():
     """configs[4] sharded over 2 ranks: every rank renders and infers its own contiguous shard, rank 0 merges the layouts
     and evaluates all of them against the reference's -- same parity as the single-rank run on the same panoramas."""
