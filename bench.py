@@ -87,6 +87,43 @@ def bf16_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
     return t, fl, by, t_hbm
 
 
+def train_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
+    """The bf16 TRAINING step's governing roofline, the forward's model extended to the passes a training step cannot avoid
+    (train.py:259-281 on model.py:216-281): per conv three GEMMs -- forward, data gradient (not for the stem: the image needs none),
+    weight gradient -- each max(flops / MFMA peak, bytes / HBM) with bytes = the two activation-sized operands x 2 B + the weights
+    (bf16 read, float32 gradient write); per BatchNorm the passes batch statistics force: forward normalise + ReLU (read z, write a;
+    + the identity branch for conv3), backward reduce (read dy, z) and apply (read dy, z, write dz) -- 7 (8) activation-sized
+    transfers of 2 B, HBM-bound; max-pool, the LSTM at 3 x its forward flops, Adam at 28 B per parameter.
+    -> (seconds per batch, flops, bytes, seconds of the HBM-bound passes)."""
+    t = fl = by = t_hbm = 0.0
+    for name, cin, cout, k, H, W, sh, sw in conv_table():
+        Ho, Wo = H // sh, W // sw
+        f = 2.0 * Ho * Wo * cout * cin * k * k * B
+        a_in, a_out, w = H * W * cin * 2.0 * B, Ho * Wo * cout * 2.0 * B, cout * cin * k * k
+        gemms = [a_in + a_out + 2.0 * w, a_in + a_out + 4.0 * w] + ([] if name == "stem" else [a_in + a_out + 2.0 * w])   # forward, wgrad, dgrad
+        for b in gemms:
+            t += max(f / peak_flops, b / hbm)
+            t_hbm += b / hbm if b / hbm > f / peak_flops else 0.0
+            fl += f
+            by += b
+        bn = a_out * (8.0 if name.endswith("conv3") else 7.0)
+        t += bn / hbm
+        t_hbm += bn / hbm
+        by += bn
+    pool = 64 * 256 * 512 * 2.0 * B * 1.25 * 2.0           # stem max-pool: read + write a quarter, forward and backward
+    t += pool / hbm
+    by += pool
+    rows = 256.0 * B
+    for _ in range(2):
+        f = 3.0 * (2.0 * rows * 1024 * 4096 + 2.0 * rows * 512 * 2048 * 2)
+        t += f / peak_flops
+        fl += f
+    adam = 81.57e6 * 28.0
+    t += adam / hbm
+    by += adam
+    return t, fl, by, t_hbm
+
+
 def shard_for_rank(global_units, world, rank):
     """Contiguous [start, end) slice of `global_units` independent panoramas owned by `rank`."""
     base, rem = divmod(global_units, world)
@@ -381,10 +418,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
                       "parallelism": "dp%d (one process per GPU, RCCL all-reduce of the flat 326 MB gradient buffer overlapped with backward)" % world,
                       "allreduce_dtype": allreduce_dtype, "defer_grad_mean": bool(getattr(net, "defer_grad_mean", False)),
                       "labels": "device (hn_labels_rasterise)" if data.device_labels else "host (labels.py)"},
-           "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flop: forward, data gradient, weight gradient GEMMs)",
-                        "achieved": round(flop / wall / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(flop / wall / 1e12 / world / peak, 4), "traffic": None,
-                        "note": "per GPU, against the dense MFMA peak of the GEMM dtype (%s)" % ("fp32 matrix 157.3 TF" if dtype == "f32" else "bf16 2.5 PF")},
+           "roofline": train_roofline(dtype, B, wall / steps, flop / wall / 1e12 / world, peak),
            "host_data_pipeline_ms_per_step": round(host_s / steps * 1e3, 2),       # time the step waited for its batch (host thread two batches ahead)
            "host_half_ms_per_batch": host_half_ms,                                # one thread's work per batch of B: what 8 ranks per host must fit 8 x of
            "final_loss": float(loss.detach())}
@@ -397,6 +431,35 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
     del net, opt, data
     torch.cuda.empty_cache()
     return out
+
+
+def train_roofline(dtype, B, s_per_step, achieved_tflops, peak):
+    """The training leg's roofline block: bf16 against the MIXED per-pass bound (train_mixed_roofline) with the HBM-side bytes per step
+    from the committed counter passes (profiles/r4_pmc_train.json, tools/profile_train.sh), tied to the loaded library by its hash;
+    float32 against the fp32 matrix peak as before."""
+    if dtype != "bf16":
+        return {"bound": "mfma", "kernel": "whole training step (3 x forward flop: forward, data gradient, weight gradient GEMMs)",
+                "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tflops / peak, 4), "traffic": None,
+                "note": "per GPU, against the dense fp32 matrix peak (157.3 TF)"}
+    t_mixed, fl, by, t_hbm = train_mixed_roofline(B)
+    traffic = stale = note = None
+    tpath = os.path.join(ROOT, "profiles", "r4_pmc_train.json")
+    if B == 64 and os.path.exists(tpath):
+        import hashlib
+        from horizonnet_amd import _lib as _l
+        rec = json.load(open(tpath))
+        traffic = rec["total_bytes"]
+        measured = (rec.get("measured_on") or {}).get("lib_sha256")
+        stale = measured is None or measured != hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()
+        note = ("bytes per step, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes over tools/prof_train_target.py "
+                "bf16 64 (tools/profile_train.sh); the model's unavoidable bytes %.1f GB -> counter / model = %.2f"
+                % (rec["fetch_bytes"] / 1e9, rec["write_bytes"] / 1e9, by / 1e9, traffic / by))
+    return {"bound": "mixed (per pass max(flops / 2.5 PFLOP/s, bytes / 8 TB/s), summed: three GEMMs per conv, the BatchNorm passes batch "
+                     "statistics force, LSTM x 3, Adam)",
+            "achieved": round(B / s_per_step, 1), "peak": round(B / t_mixed, 1), "unit": "panoramas/s", "frac": round(t_mixed / s_per_step, 4),
+            "mixed_roofline_ms_per_step": round(t_mixed * 1e3, 2), "hbm_bound_passes_ms": round(t_hbm * 1e3, 2),
+            "model_flop_per_step": fl, "model_bytes_per_step": by, "traffic": traffic, "traffic_stale": stale, "traffic_note": note,
+            "mfma_only": {"achieved_tflops": round(achieved_tflops, 2), "peak": peak, "frac": round(achieved_tflops / peak, 4)}}
 
 
 def traced_backward(net, step, dev):

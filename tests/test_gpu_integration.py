@@ -451,7 +451,14 @@ def test_config5_layouts_vs_reference_inference(golden_dir):
     s32 = f32["signal_sum_max_abs_vs_reference"]
     assert s32["panoramas"] == 1000 and s32["bon"] < 2048 * 2e-6 and s32["cor"] < 1024 * 2e-5, s32
     assert f32["corner_count_mismatches"] <= 1 and f32["iou3d_mean"] > 0.9999       # a 1e-7 signal difference may flip one vote in 1000
-    assert bf16["iou3d_mean"] >= 0.999 and bf16["corner_count_mismatches"] <= 10
+    assert bf16["iou3d_mean"] >= 0.999
+    # bf16 against the reference's layouts, corner by corner, WRAP-AWARE (a corner at column 1023.6 vs 0.2 is 0.6 px apart, not 1023):
+    # measured 1.24 px worst / 0.16 px at the 99th percentile over the 999 panoramas whose corner counts agree, 1 panorama with another
+    # count (its IoU 0.986 is the run's minimum).  Bounds = 2 x measured; the forward is deterministic, so these are regression bounds.
+    assert bf16["corner_count_mismatches"] <= 1, bf16["corner_count_mismatch_panoramas"]
+    assert bf16["cor_id_max_abs_px_seam_aware"] <= 2.5 and bf16["cor_id_p99_px_seam_aware"] <= 0.35, bf16
+    assert bf16["iou3d_min"] >= 0.97 and bf16["iou3d_below_0.99"] <= 1
+    assert f32["cor_id_max_abs_px_seam_aware"] <= 0.01                                 # measured 0.0008 px
 
 
 # ---- train.py:216-225,279: the optimiser ----------------------------------------------------------------------------
