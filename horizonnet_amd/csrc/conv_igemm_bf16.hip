@@ -1228,6 +1228,11 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
         return 0;
     }
     const long t256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
+    // tiles a persistent 8-wave kernel needs before it is preferred to the 4-wave kernels.  224 = "fills the chip on its own" (the rule the
+    // isolated sweep gives); HN_BF16_MIN_TILES lowers it for A/B runs of the PIPELINED forward, where a kernel that keeps 128 CUs busy at
+    // a higher per-CU rate leaves the other 128 to the other stream
+    const char* mte = getenv("HN_BF16_MIN_TILES");
+    const long min_tiles = mte ? atol(mte) : 224;
     const long t128x256 = Cout % 256 == 0 ? (long)hn_cdiv(M, 128) * (Cout / 256) : 0;
     const long t256x128 = Cout % 128 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 128) : 0;
     if ((force == 4 || force == 5) && t256 && a.nk >= 2) return hn_launch_conv_bf16_pp(a, OUT_F32 ? 1 : 0, force - 4, s);
@@ -1243,14 +1248,14 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
     // 3x3 convs with stride 1 along W: the activations of a filter row loaded once (conv3x3_dwr_bf16.hip); HN_BF16_DWR=0 for A/B runs
     const char* dwe = getenv("HN_BF16_DWR");
     const bool dwr = !(dwe && atoi(dwe) == 0);
-    if (force < 0 && dwr && t256 >= 224 && hn_conv_bf16_dwr_ok(a, 0)) return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 0, s);
-    if (force < 0 && dwr && t256 < 224 && (long)hn_cdiv(M, 512) * (Cout / 128) >= 224 && hn_conv_bf16_dwr_ok(a, 1))
+    if (force < 0 && dwr && t256 >= min_tiles && hn_conv_bf16_dwr_ok(a, 0)) return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 0, s);
+    if (force < 0 && dwr && t256 < min_tiles && (long)hn_cdiv(M, 512) * (Cout / 128) >= min_tiles && hn_conv_bf16_dwr_ok(a, 1))
         return hn_launch_conv_bf16_dwr(a, OUT_F32 ? 1 : 0, 1, s);
     // 64 output channels (layer1's conv2, the 64-channel height-compression convs): 512 x 64 tiles, same rule
     const char* d64 = getenv("HN_BF16_DWR64");        // 0 for A/B runs
     if (force < 0 && dwr && !(d64 && atoi(d64) == 0) && !OUT_F32 && Cout == 64 && (long)hn_cdiv(M, 512) >= 224 && hn_conv_bf16_dwr_ok(a, 2))
         return hn_launch_conv_bf16_dwr(a, 0, 2, s);
-    if (force < 0 && t256 >= 224) {
+    if (force < 0 && t256 >= min_tiles) {
         // ping-pong persistent kernel (conv_igemm_bf16_pp.hip); HN_BF16_PP=0 for A/B runs, 2 = with s_setprio
         const char* ppe = getenv("HN_BF16_PP");
         const int pp = ppe ? atoi(ppe) : 1;
@@ -1575,7 +1580,8 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
         S = S >= 4 ? 4 : (S >= 2 ? 2 : 1);
         ConvArgsH b = a;
         b.ksplit = S;
-        if (S > 1 && !(sk_env && atoi(sk_env) == 0) && !(dwe && atoi(dwe) == 0) && d.Cout % 256 == 0 && hn_conv_bf16_dwr_ok(b, 0) &&
+        if (S > 1 && !(sk_env && (atoi(sk_env) == 0 || atoi(sk_env) == 2)) && !(dwe && atoi(dwe) == 0) && d.Cout % 256 == 0 && hn_conv_bf16_dwr_ok(b, 0) &&      // HN_BF16_SPLITK=2: only the 4-wave tail split below
+           
             (size_t)S * a.M * d.Cout <= d.splitk_ws_floats) {
             b.y = d.splitk_ws;
             b.relu = 0;

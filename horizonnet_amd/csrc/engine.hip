@@ -175,7 +175,14 @@ extern "C" int hn_create(hn_engine** out, int device)
     {
         DeviceGuard guard(device);
         HN_REQUIRE(guard.ok, "hn_create: cannot select device %d", device);
-        HN_HIP(hipStreamCreateWithFlags(&e->branch_stream, hipStreamNonBlocking));
+        {
+            // the height-compression branches' stream.  HN_BRANCH_PRIORITY=low|high for A/B runs (default: the same priority as the trunk)
+            const char* bp = getenv("HN_BRANCH_PRIORITY");
+            int least = 0, greatest = 0;
+            HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            if (bp && (bp[0] == 'l' || bp[0] == 'h')) HN_HIP(hipStreamCreateWithPriority(&e->branch_stream, hipStreamNonBlocking, bp[0] == 'l' ? least : greatest));
+            else HN_HIP(hipStreamCreateWithFlags(&e->branch_stream, hipStreamNonBlocking));
+        }
         for (int i = 0; i < 4; ++i) {
             HN_HIP(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming));
             HN_HIP(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
