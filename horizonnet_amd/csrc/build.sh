@@ -9,7 +9,7 @@ mkdir -p $OBJDIR
 OBJS=""
 for f in $SRCS; do
   o=$OBJDIR/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ hn_common.h -nt "$o" ] || [ engine_internal.h -nt "$o" ] || [ multi_job.h -nt "$o" ] || [ conv_bf16_args.h -nt "$o" ] || [ conv_bf16_pp.h -nt "$o" ] || [ ../../include/horizonnet_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ hn_common.h -nt "$o" ] || [ engine_internal.h -nt "$o" ] || [ multi_job.h -nt "$o" ] || [ conv_bf16_args.h -nt "$o" ] || [ conv_bf16_pp.h -nt "$o" ] || [ stat_commit.h -nt "$o" ] || [ ../../include/horizonnet_hip.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed ${HN_BUILD_FLAGS:-} -c "$f" -o "$o"
   fi
   OBJS="$OBJS $o"

@@ -25,6 +25,7 @@ struct ConvArgsH {
     int ksplit;          // > 1: split-K -- blockIdx.y = K slice, float32 partial tiles to y + slice * M * ldy (forward, OUT_F32 only)
     double* stat_sum;    // optional per-channel sum / sum of squares of the stored rows (train-mode BatchNorm statistics)
     double* stat_sq;
+    int stat_rep;        // replicas of the statistics slot (power of two >= 1), see ConvDesc in hn_common.h
     // data-gradient mode (template TR), see conv_igemm_f32.hip: one launch = one stride-parity class of dX pixels
     int sh_log2, sw_log2;
     int ca, cb, cHo, cWo;

@@ -17,6 +17,7 @@
 // one-row-per-chunk form of round 1 spent K = 448 on the same 147 real products).
 #include "hn_common.h"
 #include "conv_bf16_args.h"
+#include "stat_commit.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -344,16 +345,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                 *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol + 4) = st2b;
             }
             __syncthreads();
+            float a1 = 0.f, a2 = 0.f;
             if (tid < BN) {
-                float a1 = 0.f, a2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < RPP; ++r) {
                     a1 += red[r * BN + tid];
                     a2 += red[(RPP + r) * BN + tid];
                 }
-                atomicAdd(p.stat_sum + n0 + tid, (double)a1);
-                atomicAdd(p.stat_sq + n0 + tid, (double)a2);
             }
+            hn_stat_commit(p.stat_sum, p.stat_sq, p.stat_rep, p.Cout, n0, BN, tid, a1, a2);
         }
     };
     if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
@@ -1167,16 +1167,15 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8_kernel(ConvArgsH p)
         *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol) = st2a;
         *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol + 4) = st2b;
         __syncthreads();
+        float a1 = 0.f, a2 = 0.f;
         if (tid < BN) {
-            float a1 = 0.f, a2 = 0.f;
 #pragma unroll
             for (int r = 0; r < RPP; ++r) {
                 a1 += red[r * BN + tid];
                 a2 += red[(RPP + r) * BN + tid];
             }
-            atomicAdd(p.stat_sum + n0 + tid, (double)a1);
-            atomicAdd(p.stat_sq + n0 + tid, (double)a2);
         }
+        hn_stat_commit(p.stat_sum, p.stat_sq, p.stat_rep, p.Cout, n0, BN, tid, a1, a2);
     }
 }
 
@@ -1544,7 +1543,7 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.M = d.B * d.Ho * d.Wo;
     a.relu = d.relu;
     a.ldy = d.ldy ? d.ldy : d.Cout;
-    a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq;
+    a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq; a.stat_rep = d.stat_rep > 1 ? d.stat_rep : 1;
     a.ksplit = 1;
     a.sh_log2 = a.sw_log2 = a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
     for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;

@@ -25,6 +25,7 @@
 //    the MFMAs of step kk, also across the per-chunk barrier.
 //  * Epilogue through LDS: whole output rows as float4 (folded BN scale/shift, residual, ReLU).
 #include "hn_common.h"
+#include "stat_commit.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +45,7 @@ struct ConvArgs {
     float* y;
     double* stat_sum;    // optional per-channel sum / sum of squares of the stored output rows (see the epilogue)
     double* stat_sq;
+    int stat_rep;        // replicas of the statistics slot (power of two >= 1), see ConvDesc
     int Hi, Wi, Cin, Ho, Wo, Cout;
     int KW, sh, sw, ph, pw;
     int M, K, nk, relu, ldy;
@@ -387,16 +389,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
             *reinterpret_cast<f32x4*>(red + crow * BN + ccol) = st1;
             *reinterpret_cast<f32x4*>(red + (RPP + crow) * BN + ccol) = st2;
             __syncthreads();
+            float a1 = 0.f, a2 = 0.f;
             if (tid < BN) {
-                float a1 = 0.f, a2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < RPP; ++r) {
                     a1 += red[r * BN + tid];
                     a2 += red[(RPP + r) * BN + tid];
                 }
-                atomicAdd(p.stat_sum + n0 + tid, (double)a1);
-                atomicAdd(p.stat_sq + n0 + tid, (double)a2);
             }
+            hn_stat_commit(p.stat_sum, p.stat_sq, p.stat_rep, p.Cout, n0, BN, tid, a1, a2);
         }
     };
     if (p.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
@@ -756,7 +757,7 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     ConvArgs a;
     a.xcd_swizzle = xcd_swizzle;
     a.x = d.x; a.w = d.w; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.y = d.y;
-    a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq;
+    a.stat_sum = d.stat_sum; a.stat_sq = d.stat_sq; a.stat_rep = d.stat_rep > 1 ? d.stat_rep : 1;
     HN_REQUIRE((d.stat_sum == nullptr) == (d.stat_sq == nullptr), "conv: stat_sum and stat_sq come together");
     a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.KW = d.KW; a.sh = d.sh; a.sw = d.sw; a.ph = d.ph; a.pw = d.pw;

@@ -80,11 +80,19 @@ struct ConvDesc {
     int xstride;         // floats between input pixels (0 = Cin)
     double* stat_sum;    // optional [Cout]: += column sums of the stored output (train-mode BatchNorm statistics, fused in the epilogue)
     double* stat_sq;     // optional [Cout]: += column sums of squares
+    int stat_rep;        // R > 1 (power of two): the slot is [sum | sq][Cout] followed by R replicas of the same (hn_stat_slot_doubles);
+                         // workgroup b adds into replica b % R and hn_launch_stat_replica_sum adds them into the leading [sum | sq] the
+                         // readers use.  Thousands of workgroups adding into the 8 cache lines of a 64-channel slot serialise at the
+                         // memory side (0.06-0.25 ms per layer1 conv).  0 / 1: straight into [sum | sq].  The slot must be zero at launch.
     float* splitk_ws;    // optional scratch for split-K partial tiles (bf16 forward; see hn_launch_conv_bf16)
     size_t splitk_ws_floats;
     int transposed;      // 1 = data-gradient mode: x = dY [B][Hi][Wi][Cin(=Cout of the fwd conv)], y = dX [B][Ho][Wo][Cout(=Cin fwd)],
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };
+// replicas only where thousands of workgroups meet on few channels (layer1 / layer2 at training batch sizes): the extra launch is ~5 us
+inline int hn_stat_replicas(int C, long M) { return M < 400000 ? 1 : C <= 128 ? 16 : C <= 256 ? 8 : 1; }
+inline size_t hn_stat_slot_doubles(int C, long M) { const int r = hn_stat_replicas(C, M); return r > 1 ? 2 * (size_t)C * (1 + r) : 2 * (size_t)C; }
+int hn_launch_stat_replica_sum(double* slot, int C, int rep, hipStream_t s);
 int hn_launch_conv(const ConvDesc& d, hipStream_t s);
 int hn_launch_conv_dgrad(const ConvDesc& fwd, const float* dz, const float* w_oihw, const float* add, float* dx, float* w_scratch,
                          const float* ones, const float* zeros, hipStream_t s);

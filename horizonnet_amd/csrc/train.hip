@@ -66,7 +66,7 @@ TrainPlan make_train_plan(int B)
         u.st = take(4 * (size_t)c.cout);
         u.mk = take(((size_t)u.M * c.cout / 4 + 3) / 4);
         u.yh = take((size_t)u.M * c.cout / 2);
-        u.sf = stat_f; stat_f += 2 * (size_t)c.cout;
+        u.sf = stat_f; stat_f += hn_stat_slot_doubles(c.cout, u.M);     // [sum | sq][C] (+ replicas), see ConvDesc::stat_rep
         u.sb = stat_b; stat_b += 3 * (size_t)c.cout;
         p.units.push_back(u);
         return (int)p.units.size() - 1;
@@ -174,6 +174,7 @@ int conv_z(const Ctx& c, const Unit& u)
         double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + u.sf;       // zeroed once at the start of hn_train_forward
         d.stat_sum = ds;
         d.stat_sq = ds + cl.cout;
+        d.stat_rep = hn_stat_replicas(cl.cout, u.M);
     }
     if (c.e->train_bf16) {     // bf16 operands on the matrix cores (the unit's input has a bf16 copy, weights packed by
                                // hn_pack_weights_bf16), float32 accumulation, float32 z
@@ -198,10 +199,13 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
     float* y32 = (c.e->train_bf16 && (!u.keep_y32 || u.stem)) ? nullptr : c.W + u.y;      // (the stem's max-pool reads the bf16 copy)
     void* yh = c.e->train_bf16 ? c.W + u.yh : nullptr;
     unsigned char* mk = reinterpret_cast<unsigned char*>(c.W + u.mk);
-    if (!c.bn_eval(u))        // statistics -> affine (+ running-stat update) inside the element pass's launch
+    if (!c.bn_eval(u)) {      // statistics -> affine (+ running-stat update) inside the element pass's launch
+        const int rep = (u.stem && c.e->train_bf16 && c.e->fuse_stem_pool) ? 1 : hn_stat_replicas(C, u.M);     // (the fused stem kernel adds straight into [sum | sq])
+        if (rep > 1 && (rc = hn_launch_stat_replica_sum(ds, C, rep, c.s))) return rc;
         return hn_launch_affine_act_bn(c.W + u.z, ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
                                        c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum,
                                        st + 2 * C, st + 3 * C, st, st + C, res, y32, mk, yh, u.M, C, relu, c.e->train_bf16, res_bf16, c.s);
+    }
     // frozen block (train.py:245-256): running statistics, untouched
     if ((rc = hn_launch_bn_eval_affine(c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"), c.bound(cl.bnkey + ".running_mean"),
                                        c.bound(cl.bnkey + ".running_var"), st + 2 * C, st + 3 * C, st, st + C, C, c.s)))

@@ -854,6 +854,23 @@ int hn_launch_bn_bwd_reduce(const float* dy, const unsigned char* bmask, const f
     return 0;
 }
 
+// [sum | sq][C] += its `rep` replicas (ConvDesc::stat_rep), in replica order
+__global__ __launch_bounds__(256) void stat_replica_sum_kernel(double* slot, int n2, int rep)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n2) return;
+    double s = slot[c];
+    for (int r = 1; r <= rep; ++r) s += slot[(size_t)r * n2 + c];
+    slot[c] = s;
+}
+
+int hn_launch_stat_replica_sum(double* slot, int C, int rep, hipStream_t s)
+{
+    hipLaunchKernelGGL(stat_replica_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, slot, 2 * C, rep);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
 int hn_launch_bn_finalize(const double* sum, const double* sumsq, double n, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float* a, float* b, float* save_mean, float* save_invstd, int C,
                           hipStream_t s)
