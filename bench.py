@@ -531,6 +531,7 @@ def bf16_leg(net, x, dev, steps, f32_out):
     B = int(x.shape[0])
     net.precision = "bf16"
     bon, cor = f32_out
+    steps = max(int(steps), 60)                           # 0.4 s: the pipelined entry's fill + drain (one recurrent head, ~2 ms) is < 1 % of the region
 
     def run_plain(n):
         for _ in range(n):
@@ -569,7 +570,7 @@ def bf16_leg(net, x, dev, steps, f32_out):
     best = max(res["plain"]["value"], res["pipelined"]["value"])
     ms_best = B / best * 1e3
     tf = FWD_FLOP_PER_PANO * B / (ms_best * 1e-3) / 1e12
-    return {"value": best, "unit": "panoramas/s", "ms_per_step": round(ms_best, 3),
+    return {"value": best, "unit": "panoramas/s", "ms_per_step": round(ms_best, 3), "steps": steps,
             "plain": res["plain"], "pipelined": res["pipelined"], "pipelined_equals_plain_bitwise": identical,
             "f32_output_max_abs": round(float(max(bon.abs().max(), cor.abs().max())), 3),
             "roofline": {"bound": "mixed (per layer max(flops / 2.5 PFLOP/s, unfused bytes / 8 TB/s), summed)",

@@ -317,12 +317,22 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
     {
         // 8-wave 256-wide tiles where both channel counts allow them (layer3 / layer4, the deep height-compression convs): one
-        // workgroup per CU, m split into ~256 workgroups.  HN_WGRAD_W8 = 0 disables, 1 = 256x256 (default), 2 = 256x128, 3 = 128x256, 4 = 256x256 then 256x128
+        // workgroup per CU, m split into ~256 workgroups.  HN_WGRAD_W8 = 0 disables, 1 = per-shape choice between 256x256 and 256x128 (default), 2 = 256x128, 3 = 128x256, 4 = 256x256 then 256x128, 5 = 256x256 only
         static const char* e8 = getenv("HN_WGRAD_W8");
         const int w8 = e8 ? atoi(e8) : 1;
         static const char* envw = getenv("HN_WGRAD_W8_WGS");
         const long target = envw ? atol(envw) : 256;
-        if ((w8 == 1 || w8 == 4) && Cout % 256 == 0 && Cin % 256 == 0) return launch_wgrad_h_w<256, 256, 64, 8>(a, s, target);
+        if (w8 == 1 && Cout % 256 == 0 && Cin % 128 == 0) {
+            // per-dispatch durations of the B = 64 step under both shapes (tools/r4_run24.sh, profiles/r4_wgrad_tile_shapes.txt): the 1x1 convs
+            // and the LSTM input GEMMs are 10-20 % faster on 256x128 (twice the workgroups for the same m split), the 3x3 convs 10-60 %
+            // faster on 256x256 -- except where 256x256 gives a few tiles more than one resident round (ghc3.0: 288 tiles on 256 CUs)
+            const long t256 = Cin % 256 == 0 ? (long)(Cout / 256) * (a.K / 256) : 0;
+            const bool ragged = t256 > 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) < 0.6;
+            if (t256 == 0 || KH == 1 || ragged) return launch_wgrad_h_w<256, 128, 64, 8>(a, s, target);
+            return launch_wgrad_h_w<256, 256, 64, 8>(a, s, target);
+        }
+        if (w8 == 5 && Cout % 256 == 0 && Cin % 256 == 0) return launch_wgrad_h_w<256, 256, 64, 8>(a, s, target);      // (the round-3 rule, for A/B runs)
+        if (w8 == 4 && Cout % 256 == 0 && Cin % 256 == 0) return launch_wgrad_h_w<256, 256, 64, 8>(a, s, target);
         if ((w8 == 2 || w8 == 4) && Cout % 256 == 0 && Cin % 128 == 0) return launch_wgrad_h_w<256, 128, 64, 8>(a, s, target);
         if (w8 == 3 && Cout % 128 == 0 && Cin % 256 == 0) return launch_wgrad_h_w<128, 256, 64, 8>(a, s, target);
     }

@@ -11,7 +11,7 @@ from bench import seeded_net  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-B = 32
+B = int(os.environ.get("PIPE_B", "32"))
 dev = torch.device("cuda:0")
 x = torch.rand(B, 3, 512, 1024, generator=torch.Generator().manual_seed(1000)).to(dev)
 for lanes in (1, 2, 3):
