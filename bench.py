@@ -435,7 +435,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
 
 def train_roofline(dtype, B, s_per_step, achieved_tflops, peak):
     """The training leg's roofline block: bf16 against the MIXED per-pass bound (train_mixed_roofline) with the HBM-side bytes per step
-    from the committed counter passes (profiles/r4_pmc_train.json, tools/profile_train.sh), tied to the loaded library by its hash;
+    from the committed counter passes (profiles/r4_pmc_train.json, tools/profile_train.sh), tied to the kernel sources by their hash;
     float32 against the fp32 matrix peak as before."""
     if dtype != "bf16":
         return {"bound": "mfma", "kernel": "whole training step (3 x forward flop: forward, data gradient, weight gradient GEMMs)",
@@ -445,12 +445,11 @@ def train_roofline(dtype, B, s_per_step, achieved_tflops, peak):
     traffic = stale = note = None
     tpath = os.path.join(ROOT, "profiles", "r4_pmc_train.json")
     if B == 64 and os.path.exists(tpath):
-        import hashlib
         from horizonnet_amd import _lib as _l
         rec = json.load(open(tpath))
         traffic = rec["total_bytes"]
-        measured = (rec.get("measured_on") or {}).get("lib_sha256")
-        stale = measured is None or measured != hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()
+        measured = (rec.get("measured_on") or {}).get("csrc_sha256")
+        stale = measured is None or measured != _l.source_fingerprint()
         note = ("bytes per step, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes over tools/prof_train_target.py "
                 "bf16 64 (tools/profile_train.sh); the model's unavoidable bytes %.1f GB -> counter / model = %.2f"
                 % (rec["fetch_bytes"] / 1e9, rec["write_bytes"] / 1e9, by / 1e9, traffic / by))
@@ -873,10 +872,9 @@ def main():
                     continue
                 traffic = rec["total_bytes"]
                 # the counters are from a separate rocprofv3 run: tie them to the code that runs NOW (hash of the loaded library)
-                import hashlib
                 from horizonnet_amd import _lib as _l
-                measured = (whole.get("measured_on") or {}).get("lib_sha256")
-                traffic_stale = measured is None or measured != hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()
+                measured = (whole.get("measured_on") or {}).get("csrc_sha256")
+                traffic_stale = measured is None or measured != _l.source_fingerprint()      # (kernel sources: a library hash is not reproducible)
                 traffic_note = ("bytes per forward, rocprofv3 FETCH_SIZE (x2, gfx950) %.1f GB + WRITE_SIZE %.1f GB, separate --pmc passes, profiles/%s "
                                 "(tools/profile_forward.sh); Infinity-Cache hits included; algorithmic minimum %.1f GB -> counter / algorithmic = %.2f; "
                                 "matrix pipe busy %s %% of the conv kernels' cycles" % (

@@ -129,3 +129,20 @@ def ptr(t):
 def stream_ptr(device=None):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def source_fingerprint():
+    """SHA-256 over the kernel sources (csrc/*.hip, *.h, build.sh, the public header), in name order.  The counter records under
+    profiles/ carry it (tools/merge_pmc*.py) and bench.py compares it with the tree it runs from: `traffic_stale`.  (The hash of the
+    built library is NOT reproducible from a fresh build, the sources are.)"""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, "csrc", "*.hip")) + glob.glob(os.path.join(root, "csrc", "*.h")) +
+                   [os.path.join(root, "csrc", "build.sh"), os.path.join(os.path.dirname(root), "include", "horizonnet_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+

@@ -2,8 +2,8 @@
 the HBM-side bytes per forward (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes), the ratio to the algorithmic
 minimum and the matrix-pipe busy share per kernel family -- the record bench.py quotes in `roofline.traffic`.
     python tools/merge_pmc.py gpurun_out r4 > profiles/r4_pmc_forward.json
-The record carries the SHA-256 of libhorizonnet_hip.so it was measured on (and the git HEAD): bench.py sets `traffic_stale` when the
-library it runs is another one."""
+The record carries the SHA-256 of the kernel SOURCES it was measured on (horizonnet_amd._lib.source_fingerprint; the built library's
+hash is not reproducible from a fresh build) and the git HEAD: bench.py sets `traffic_stale` when the tree it runs from differs."""
 import hashlib
 import json
 import os
@@ -23,7 +23,10 @@ def main():
            "precisions": {}}
     # what these counters were measured ON: bench.py compares the hash with the library it loads and flags `traffic_stale` otherwise
     lib = os.path.join(ROOT, "horizonnet_amd", "libhorizonnet_hip.so")
-    out["measured_on"] = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+    sys.path.insert(0, ROOT)
+    from horizonnet_amd import _lib as _l
+    out["measured_on"] = {"csrc_sha256": _l.source_fingerprint(),
+                          "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
                           "git_head": (subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or
                                        os.environ.get("HN_GIT_HEAD", "unknown (no .git on the GPU box: pass HN_GIT_HEAD)"))}
     for prec in ("f32", "bf16"):

@@ -1,7 +1,7 @@
 """Merge the per-counter JSONs of tools/profile_train.sh into profiles/rN_pmc_train.json (MEASUREMENT TOOL): HBM-side bytes of ONE bf16
 training step at B = 64 (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes), the ratio to the bytes of bench.py's
 train_mixed_roofline model, the matrix-pipe busy share per kernel family -- the record bench.py quotes in train_bf16.roofline.traffic,
-tied to the library it was measured on by its SHA-256.
+tied to the kernel sources it was measured on by their SHA-256 (horizonnet_amd._lib.source_fingerprint).
     python tools/merge_pmc_train.py gpurun_out r4 > profiles/r4_pmc_train.json"""
 import hashlib
 import json
@@ -37,7 +37,8 @@ def main():
         "what": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} over tools/prof_train_target.py "
                 "bf16 64 3 (4 identical steps: forward + backward + FusedAdam), three separate passes (tools/profile_train.sh); per step",
         "correction": "FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64 bytes), KB -> bytes; WRITE_SIZE as reported; Infinity-Cache hits included",
-        "measured_on": {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+        "measured_on": {"csrc_sha256": __import__("horizonnet_amd._lib", fromlist=["x"]).source_fingerprint(),
+                        "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
                         "git_head": os.environ.get("HN_GIT_HEAD", "unknown (no .git on the GPU box: pass HN_GIT_HEAD)")},
         "fetch_bytes": fetch, "write_bytes": write, "total_bytes": fetch + write,
         "model_bytes": by, "counter_over_model": round((fetch + write) / by, 3), "model_flop": fl, "mixed_roofline_ms": round(t_mixed * 1e3, 2),
