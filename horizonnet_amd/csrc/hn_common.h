@@ -1,5 +1,6 @@
 // Internal helpers shared by the HIP translation units of libhorizonnet_hip.so.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -90,7 +91,13 @@ struct ConvDesc {
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };
 // replicas only where thousands of workgroups meet on few channels (layer1 / layer2 at training batch sizes): the extra launch is ~5 us
-inline int hn_stat_replicas(int C, long M) { return M < 400000 ? 1 : C <= 128 ? 16 : C <= 256 ? 8 : 1; }
+inline int hn_stat_replicas(int C, long M)
+{
+    static const char* env = getenv("HN_STAT_REPLICAS");       // "0": never (A/B runs); "all": also for small M (tests exercise the path at B = 2)
+    if (env && env[0] == '0') return 1;
+    if (M < 400000 && !(env && env[0] == 'a')) return 1;
+    return C <= 128 ? 16 : C <= 256 ? 8 : 1;
+}
 inline size_t hn_stat_slot_doubles(int C, long M) { const int r = hn_stat_replicas(C, M); return r > 1 ? 2 * (size_t)C * (1 + r) : 2 * (size_t)C; }
 int hn_launch_stat_replica_sum(double* slot, int C, int rep, hipStream_t s);
 int hn_launch_conv(const ConvDesc& d, hipStream_t s);

@@ -703,3 +703,54 @@ def test_train_stem_conv_direct_matches_implicit_gemm():
     for a, b in zip(outs[0], outs[1]):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
+
+
+def test_replicated_statistics_slots_equal_the_single_slot():
+    """ConvDesc::stat_rep (csrc/stat_commit.h): the conv epilogues of the few-channel layers add their batch statistics into 8-16
+    replicas that hn_launch_stat_replica_sum adds up.  The rule only switches it on for M >= 400000 (B >= 13); HN_STAT_REPLICAS=all
+    forces it at B = 2, HN_STAT_REPLICAS=0 never uses it: same outputs, running statistics and gradients up to summation order, in
+    both precisions."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys, torch
+sys.path.insert(0, %r)
+from horizonnet_amd import HorizonNet
+from oracle.weights import make_state_dict
+out = {}
+for prec in ("f32", "bf16"):
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(51, "random"))
+    net = net.to("cuda:0").train()
+    net.train_precision = prec
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(52)).to("cuda:0")
+    bon, cor = net(x)
+    (bon.abs().sum() + cor.sum()).backward()
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    out[prec] = {"bon": float(bon.double().sum()), "cor": float(cor.double().sum()),
+                 "rm": [float(sd[k].double().norm()) for k in sorted(sd) if k.endswith("running_mean")][:12],
+                 "rv": [float(sd[k].double().norm()) for k in sorted(sd) if k.endswith("running_var")][:12],
+                 "g": [float(p.grad.double().norm()) for n_, p in sorted(net.named_parameters()) if n_.endswith("conv1.weight") or n_.endswith("conv2.weight")][:16],
+                 "status": int(net.hip_status(torch.device("cuda:0")))}
+print("RESULT " + json.dumps(out))
+''' % ROOT
+    res = {}
+    for mode in ("0", "all"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, HN_STAT_REPLICAS=mode))
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[mode] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    # norm-level agreement: the runs differ by the order of the double atomics (statistics) and float atomics (weight gradients) anyway;
+    # bf16: z is rounded to bf16 after the statistics, a last-bit change of a mean moves rounding points downstream.  A lost replica
+    # would change a mean by 1/16 and every figure below by percents.
+    for prec, tol in (("f32", 3e-4), ("bf16", 1e-2)):
+        a, b = res["0"][prec], res["all"][prec]
+        assert a["status"] == 0 and b["status"] == 0
+        for key in ("rm", "rv", "g"):
+            worst = max(abs(u - v) / (abs(u) + 1e-12) for u, v in zip(a[key], b[key]))
+            assert worst < tol, (prec, key, worst)
+        assert abs(a["bon"] - b["bon"]) < tol * (abs(a["bon"]) + 1.0) * 10 and abs(a["cor"] - b["cor"]) < tol * (abs(a["cor"]) + 1.0) * 10, (prec, a["bon"], b["bon"], a["cor"], b["cor"])
