@@ -23,6 +23,7 @@
 #include "hn_common.h"
 #include "conv_bf16_args.h"
 #include "conv_bf16_pp.h"
+#include "stat_wave.h"
 
 #include <type_traits>
 
@@ -46,6 +47,9 @@ constexpr int BSLOT = BN * ROWB;                // 8 KiB: one piece per wave
 constexpr int LDS_BYTES = B_OFF + 4 * BSLOT;
 static_assert(LDS_BYTES == 163840, "LDS budget");
 
+// STATS: the training forward -- bf16 z + the batch statistics (sum, sum of squares per channel) of the float32 accumulators it stores,
+// accumulated per lane across ALL tiles of the persistent workgroup and flushed once (stat_wave.h); 174 -> 190 registers, no spills.
+template <bool STATS>
 __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -237,6 +241,8 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
     int sc_n0 = cn0;
     float sc = p.scale[cn0 + 32 * wn + fr];
     float sf = p.shift[cn0 + 32 * wn + fr];
+    [[maybe_unused]] HnWaveStats wstat;
+    if constexpr (STATS) wstat.zero();
     auto epilogue = [&](int em0, int en0, int slab_buf) {
         float* slab = reinterpret_cast<float*>(smem + slab_buf * ABUF + REGION_A + wave * 2048);
         const int row16 = lane >> 2;
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
         const int colg = en0 + 32 * wn + 8 * cb;
         const int mrow0 = em0 + GROUP_ROWS * g + 128 * wm2 + row16;
         if (en0 != sc_n0) {
+            if constexpr (STATS) wstat.template flush<4>(p.stat_sum, p.stat_sq, p.stat_rep, p.Cout, sc_n0 + 32 * wn, lane);
             sc_n0 = en0;
             sc = p.scale[en0 + 32 * wn + fr];
             sf = p.shift[en0 + 32 * wn + fr];
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
             }
             const int m = mrow0 + 16 * rd;
             if (m < p.M) {
+                if constexpr (STATS) wstat.add(v0, v1);
                 u32x4 o;
                 o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                 o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
@@ -346,21 +354,24 @@ __global__ __launch_bounds__(512) void conv3x3_dwr64_bf16_kernel(ConvArgsH p)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus (out-of-range) pieces of the loader
+    if constexpr (STATS) wstat.template flush<4>(p.stat_sum, p.stat_sq, p.stat_rep, p.Cout, sc_n0 + 32 * wn, lane);
 }
 
 }  // namespace
 
 int hn_launch_conv_bf16_dwr64(const ConvArgsH& a, hipStream_t s)
 {
-    auto kern = conv3x3_dwr64_bf16_kernel;
-    static bool attr_done[64] = {};
+    const bool stats = a.stat_sum != nullptr;
+    HN_REQUIRE(!stats || (a.stat_sq != nullptr && a.stat_rep >= 1 && a.relu == 0), "conv bf16 (dw reuse, 64 columns): statistics come without ReLU");
+    auto kern = stats ? conv3x3_dwr64_bf16_kernel<true> : conv3x3_dwr64_bf16_kernel<false>;
+    static bool attr_done[2][64] = {};
     static int n_cu[64] = {};
     int dev = 0;
     HN_HIP(hipGetDevice(&dev));
-    if (dev < 64 && !attr_done[dev]) {
+    if (dev < 64 && !attr_done[stats][dev]) {
         HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HN_HIP(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done[dev] = true;
+        attr_done[stats][dev] = true;
     }
     const int tiles = hn_cdiv(a.M, BM) * (a.Cout / BN);
     const int cus = dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;

@@ -480,8 +480,9 @@ bool hn_conv_bf16_dwr_ok(const ConvArgsH& a, int shape)
     const int group_rows = shape == 0 ? 128 : 256;
     const int bn = shape == 0 ? 256 : shape == 1 ? 128 : 64;
     if (shape == 2 && (a.res != nullptr || a.ksplit > 1)) return false;
+    if (a.stat_sum != nullptr && shape != 2) return false;      // only the 64-column kernel has a statistics epilogue (the others spill with it)
     return a.KH == 3 && a.KW == 3 && a.sw == 1 && a.pw == 1 && a.ph == 1 && a.Wi == a.Wo && (a.Wo & (a.Wo - 1)) == 0 && a.Wo >= 32 &&
-           group_rows % a.Wo == 0 && a.Cout % bn == 0 && a.Cin % BKE == 0 && a.stat_sum == nullptr &&
+           group_rows % a.Wo == 0 && a.Cout % bn == 0 && a.Cin % BKE == 0 &&
            (a.ksplit <= 1 || ((a.ksplit & (a.ksplit - 1)) == 0 && (a.nk / 3) % a.ksplit == 0)) &&
            (long)a.Hi * a.Wi < (1L << 24) && (long)a.Wi * a.xstride * 2 < (1L << 24) && a.Hi < (1 << 20);
 }

@@ -1222,6 +1222,10 @@ int dispatch_w8(const ConvArgsH& a, int Cout, hipStream_t s, bool* taken)
         // train-mode forward (batch statistics in the epilogue): the 256x256 tile under the same >= 224-workgroup rule, bf16 z only
         static const char* tenv = getenv("HN_BF16_W8_TRAIN");
         const long t = Cout % 256 == 0 ? (long)hn_cdiv(M, 256) * (Cout / 256) : 0;
+        // 64 output channels, 3x3, stride 1 along W (layer1's conv2): the dw-reuse kernel's statistics variant (conv3x3_dwr64_bf16.hip)
+        static const char* d64t = getenv("HN_BF16_DWR64");
+        if (!OUT_F32 && !(d64t && atoi(d64t) == 0) && a.res == nullptr && a.relu == 0 && Cout == 64 && (long)hn_cdiv(M, 512) >= 224 && hn_conv_bf16_dwr_ok(a, 2))
+            return hn_launch_conv_bf16_dwr(a, 0, 2, s);
         if (!OUT_F32 && !(tenv && atoi(tenv) == 0) && a.res == nullptr && t >= 224) return launch_cfg_w8<256, 256, 2, 4, false, true>(a, s);
         *taken = false;
         return 0;

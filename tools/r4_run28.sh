@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_gpu_train.py -x -q -m gpu 2>&1 | grep -v "^$" | tail -12 | cut -c1-300
+timeout 600 python bench.py --mode train --dtype bf16 --batch 64 --steps 6 --warmup 2 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('train', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('loss_curve_check',{}).get('max_rel_diff'))"
