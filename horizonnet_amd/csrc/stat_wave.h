@@ -2,11 +2,6 @@
 // of squares of its 8 channels over the rows it stores; at the end of the kernel (or when a persistent workgroup moves to another column
 // tile) the lanes that share a channel group are added up across the wave and GROUPS lanes issue the double atomics (stat_commit.h's
 // replica addressing: ConvDesc::stat_rep).
-//
-// Used by conv3x3_dwr64_bf16.hip only (174 -> 199 registers).  The ping-pong and the 256-wide dw-reuse kernels sit at 220-240 of their 256
-// registers; both this form and a 4-register form that sums in the accumulator layout (a lane owns one column per 32-column MFMA tile)
-// made hipcc spill 25-160 registers in them (the add chains change its scheduling of the whole epilogue), and scratch traffic counts in
-// vmcnt, i.e. against the hand-counted LDS-DMA waits.  The training forward therefore keeps the round-2 kernels for those shapes.
 #pragma once
 #include <hip/hip_runtime.h>
 
