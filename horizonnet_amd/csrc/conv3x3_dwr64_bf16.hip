@@ -374,7 +374,14 @@ int hn_launch_conv_bf16_dwr64(const ConvArgsH& a, hipStream_t s)
         attr_done[stats][dev] = true;
     }
     const int tiles = hn_cdiv(a.M, BM) * (a.Cout / BN);
-    const int cus = dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
+    int cus = dev < 64 && n_cu[dev] > 0 ? n_cu[dev] : 256;
+    // A persistent workgroup owns a CU (160 KiB of LDS) and a FIXED share of the tiles.  In the pipelined forward layer1 runs while the
+    // previous batch's recurrence holds 32 CUs: with 256 workgroups 32 of them start only when the first ones have finished, i.e. the
+    // kernel takes twice as long (measured 170-181 us in the timeline against 99 alone).  Leaving those CUs out costs 1 / 8 when they
+    // are free and saves 1 / 3 when they are not.  HN_D64_GRID overrides (A/B runs).
+    static const char* ge = getenv("HN_D64_GRID");
+    cus = ge ? atoi(ge) : cus - 32;
+    if (cus < 1) cus = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), LDS_BYTES, s, a);
     HN_LAUNCH_CHECK();
     return 0;
