@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 GPU call 1: ping-pong conv kernel -- bit-identity tests, per-shape sweep against the round-3 kernels, bf16 forward A/B
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 5 300 python -m pytest tests/test_gpu_bf16.py -x -q -k "pingpong or conv_bf16_stage" > gpurun_out/r4_1_pytest.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 5 600 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_integration.py -q -x -k "async or pipelined or stream or inference" 2>&1 | tail -4 | tee gpurun_out/r4_11_pytest.log

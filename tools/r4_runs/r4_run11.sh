@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 export HN_GIT_HEAD=$(cat gpurun_out/.git_head 2>/dev/null || echo unknown)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 12: the 64-column dw-reuse kernel (parity, per-shape sweep, bench) + the full GPU suite after the boundary changes
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_bf16.py -x -q -m gpu -k "dw_reuse or pingpong or split_k" > gpurun_out/r12_dwr_tests.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 13: A/B of the 64-column dw-reuse kernel inside the whole forward + kernel stats
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 for i in 1 2 3; do

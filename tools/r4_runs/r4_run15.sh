@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 15: scale/shift kept in registers (PP / DWR): parity + forward A/B vs HEAD~; fresh training-step timeline
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_bf16.py -x -q -m gpu -k "dw_reuse or pingpong or split_k" 2>&1 | tail -2

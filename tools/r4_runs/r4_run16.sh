@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 16: device labels (parity + suite), 2-rank bench with bf16 wire, config-5 seam-aware bf16 figures
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_dataset.py -x -q -m gpu -s 2>&1 | grep -v "^$" | tail -8

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 SWEEP_B=64 SWEEP_ONLY=layer1,layer2.0.conv1 SWEEP_VARIANTS=0,-1 SWEEP_NOASSERT=1 timeout 300 python tools/conv_sweep.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r17_sweep_b64.txt

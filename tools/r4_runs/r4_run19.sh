@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 SWEEP_VARIANTS=0,-1 SWEEP_NOASSERT=1 timeout 600 python tools/conv_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r19_sweep_auto.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 GPU call 2: k-half ping-pong schedule -- bit-identity, sweep vs the 8-wave two-stage kernel, loop ablations, forward A/B
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 5 300 python -m pytest tests/test_gpu_bf16.py -x -q -k "pingpong or conv_bf16_stage" > gpurun_out/r4_2_pytest.log 2>&1

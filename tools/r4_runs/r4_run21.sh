@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -4

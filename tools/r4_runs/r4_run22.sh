@@ -1,6 +1,6 @@
 #!/bin/bash
 # wgrad launch-parameter sweep at B = 64 (r2 tuned them at B = 32): family totals per step from the kernel trace
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 run() {

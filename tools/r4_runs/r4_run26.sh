@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python tools/pipe_bench.py 20 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r26_pipe_bench.txt

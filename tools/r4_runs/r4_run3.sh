@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 5 300 python -m pytest tests/test_gpu_bf16.py -x -q -k "pingpong" > gpurun_out/r4_4_pytest.log 2>&1

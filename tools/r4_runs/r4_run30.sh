@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace -f csv -d gpurun_out/r30_tl -- python tools/prof_target.py bf16p 32 6 > gpurun_out/r30.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 run() {
   env "$@" timeout 300 python bench.py --dtype bf16 --legs none --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 SH="ghc1.0,layer3.x.conv1,layer3.x.conv2,layer3.x.conv3,layer2.x.conv3,ghc2.0"

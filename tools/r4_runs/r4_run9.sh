@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 5 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 | tee gpurun_out/r4_10_pytest.log
