@@ -474,12 +474,30 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
             const void* wpk = reinterpret_cast<const unsigned short*>(e->packed_h) + hn_bf16_conv_offset(u.ci);
             if ((rc = hn_launch_stem_conv_train_bf16(x, C_in, wpk, W + u.z, ds, ds + a.convs[u.ci].cout, B, s))) return rc;
         } else if ((rc = conv_z(c, u))) return rc;
+        // bf16 mode, batch statistics: BatchNorm + ReLU + max-pool in ONE pass over z (train_ops.hip: affine_act_bn_pool_kernel) -- the bf16
+        // activation of the stem is consumed by the pool only.  HN_FUSE_STEM_BNPOOL=0: the two passes (A/B runs, the bit-equality test)
+        static const char* fbp = getenv("HN_FUSE_STEM_BNPOOL");
+        const bool stem_tapped_f = e->debug_unit == 0 || e->debug_unit2 == 0;      // a parity test reads this unit's tensors: keep the two-pass form (it writes the bf16 activation)
+        if (e->train_bf16 && !c.bn_eval(u) && !stem_tapped_f && !(fbp && fbp[0] == '0')) {
+            const ConvLayer& cl = a.convs[u.ci];
+            const int C = cl.cout;
+            double* ds = reinterpret_cast<double*>(W + pl.dstat) + u.sf;
+            float* st = W + u.st;
+            const int rep = (e->fuse_stem_pool) ? 1 : hn_stat_replicas(C, u.M);
+            if (rep > 1 && (rc = hn_launch_stat_replica_sum(ds, C, rep, s))) return rc;
+            if ((rc = hn_launch_affine_act_bn_pool(W + u.z, ds, ds + C, (double)u.M, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
+                                                   c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), bn_momentum,
+                                                   st + 2 * C, st + 3 * C, st, st + C, reinterpret_cast<unsigned char*>(W + u.mk), W + pl.poolh,
+                                                   W + pl.pidx, B, 256, 512, C, s)))
+                return rc;
+        } else {
         if ((rc = bn_forward(c, u, nullptr, 1, bn_momentum))) return rc;
         if (e->train_bf16) {
             // the stem's activation exists as bf16 only (bn_forward: no float32 y for the stem in bf16 mode) and is pooled as bf16
             // straight into the bf16 block input of layer1: 2.1 GB of float32 y written + read and a conversion pass less per step
             if ((rc = hn_launch_maxpool_idx(W + u.yh, nullptr, W + pl.pidx, B, 256, 512, 64, s, /*in_bf16=*/1, W + pl.poolh))) return rc;
         } else if ((rc = hn_launch_maxpool_idx(W + u.y, W + pl.pool, W + pl.pidx, B, 256, 512, 64, s))) return rc;
+        }
     }
     // backbone + height compression
     for (int li = 0; li < 4; ++li) {

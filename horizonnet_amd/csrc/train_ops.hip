@@ -220,6 +220,90 @@ __global__ __launch_bounds__(256) void affine_act_bn_kernel(const float* __restr
     }
 }
 
+// The stem of the bf16 training forward: affine_act_bn_kernel + maxpool_fwd_idx_kernel in one pass (model.py:73-76).  The two-pass form
+// writes the 1.07 GB bf16 activation (B = 64) only for the pool to read it back; here a thread owns one pooled pixel x 4 channels, forms
+// relu(a z + b) of its 3 x 3 window from z (bf16 rounding of every value as the stored activation had it, so the maximum and its position
+// are the two-pass form's bit for bit), writes the pooled value + position word, and the ReLU bit masks of the 2 x 2 input pixels it owns
+// (rows 2 ho, 2 ho + 1, columns 2 wo, 2 wo + 1: every input pixel has exactly one owner).  z 1.07 GB read, 0.27 + 0.13 + 0.13 GB
+// written instead of 3.75 GB moved.
+__global__ __launch_bounds__(256) void affine_act_bn_pool_kernel(const unsigned short* __restrict__ z, const double* __restrict__ sum,
+                                                                 const double* __restrict__ sumsq, double n, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                                 float momentum, float* a_out, float* b_out, float* save_mean, float* save_invstd,
+                                                                 unsigned char* __restrict__ bmask, unsigned short* __restrict__ pool_h,
+                                                                 unsigned* __restrict__ idx, int Hi, int Wi, int C4, long total)
+{
+    extern __shared__ __attribute__((aligned(16))) float ab[];      // [2][C]
+    const int C = C4 * 4;
+    for (int c = threadIdx.x; c < C; c += 256) {                    // bn_finalize_kernel's arithmetic, as in affine_act_bn_kernel
+        const double m = sum[c] / n;
+        double var = sumsq[c] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float aa = gamma[c] * invstd;
+        const float bb = beta[c] - (float)m * aa;
+        ab[c] = aa;
+        ab[C + c] = bb;
+        if (blockIdx.x == 0) {
+            a_out[c] = aa;
+            b_out[c] = bb;
+            save_mean[c] = (float)m;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long b = t / Ho;
+        const f32x4 aa = *reinterpret_cast<const f32x4*>(ab + c4 * 4), bb = *reinterpret_cast<const f32x4*>(ab + C + c4 * 4);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned pos[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = ho * 2 - 1 + dh;
+            if ((unsigned)hi >= (unsigned)Hi) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wi = wo * 2 - 1 + dw;
+                if ((unsigned)wi >= (unsigned)Wi) continue;
+                const long e = ((b * Hi + hi) * Wi + wi) * (long)C4 + c4;
+                f32x4 v = load_z4(reinterpret_cast<const float*>(z), e * 4, 1);
+                v = v * aa + bb;
+                unsigned mk = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    mk |= (v[k] > 0.f ? 1u : 0u) << k;
+                    v[k] = fmaxf(v[k], 0.f);
+                }
+                if (dh >= 1 && dw >= 1) bmask[e] = (unsigned char)mk;          // the 2 x 2 block this thread owns
+                unsigned lo, hi2;                                              // the activation as the two-pass form stored it
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi2) : "v"(v[2]), "v"(v[3]));
+                const f32x4 r = {__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                                 __builtin_bit_cast(float, hi2 << 16), __builtin_bit_cast(float, hi2 & 0xffff0000u)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (r[k] > m[k]) { m[k] = r[k]; pos[k] = (unsigned)(dh * 3 + dw); }
+            }
+        }
+        unsigned lo, hi2;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(m[0]), "v"(m[1]));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi2) : "v"(m[2]), "v"(m[3]));
+        *reinterpret_cast<uint2*>(pool_h + i * 4) = make_uint2(lo, hi2);
+        idx[i] = pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24);
+    }
+}
+
 // BN backward apply: g = dy * mask;  dz = gamma*invstd * (g - S1/N - zhat * S2/N);  optional dpre = g (identity branch)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ bmask,
                                                            const float* __restrict__ z, const float* __restrict__ mean,
@@ -910,6 +994,19 @@ int hn_launch_affine_act_bn(const float* z, const double* sum, const double* sum
     hipLaunchKernelGGL(affine_act_bn_kernel, dim3(grid_for(total4)), dim3(256), 2 * (size_t)C * sizeof(float), s, z, sum, sumsq, n, gamma,
                        beta, running_mean, running_var, momentum, a, b, save_mean, save_invstd, res, y, bmask,
                        reinterpret_cast<unsigned short*>(y_h), total4, C / 4, relu, z_bf16, res_bf16);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hn_launch_affine_act_bn_pool(const void* z_h, const double* sum, const double* sumsq, double n, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float* a, float* b, float* save_mean,
+                                 float* save_invstd, unsigned char* bmask, void* pool_h, void* idx, int B, int Hi, int Wi, int C, hipStream_t s)
+{
+    HN_REQUIRE(C % 4 == 0 && C <= 4096 && Hi % 2 == 0 && Wi % 2 == 0, "affine_act_bn_pool: C=%d Hi=%d Wi=%d", C, Hi, Wi);
+    const long total = (long)B * (Hi / 2) * (Wi / 2) * (C / 4);
+    hipLaunchKernelGGL(affine_act_bn_pool_kernel, dim3(grid_for(total, 256L * 64)), dim3(256), 2 * (size_t)C * sizeof(float), s,
+                       reinterpret_cast<const unsigned short*>(z_h), sum, sumsq, n, gamma, beta, running_mean, running_var, momentum, a, b, save_mean,
+                       save_invstd, bmask, reinterpret_cast<unsigned short*>(pool_h), reinterpret_cast<unsigned*>(idx), Hi, Wi, C / 4, total);
     HN_LAUNCH_CHECK();
     return 0;
 }

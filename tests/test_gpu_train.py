@@ -773,3 +773,13 @@ def test_dw_reuse_statistics_epilogue_equals_the_four_wave_kernel():
     base = _train_probe_in_subprocess({"HN_BF16_DWR64": "0"}, 4, ("bf16",))["bf16"]
     for env in ({"HN_BF16_DWR64": "1"}, {"HN_BF16_DWR64": "1", "HN_STAT_REPLICAS": "all"}):
         _assert_probes_agree(base, _train_probe_in_subprocess(env, 4, ("bf16",))["bf16"], "bf16", 1e-2)
+
+
+def test_fused_stem_batchnorm_pool_equals_the_two_passes():
+    """affine_act_bn_pool_kernel (BatchNorm + ReLU + 3x3 / 2 max-pool + position words + ReLU masks in one pass over the stem's z, bf16
+    training forward) against affine_act_bn_kernel + maxpool_fwd_idx_kernel (HN_FUSE_STEM_BNPOOL=0): the pooled tensor, positions and
+    masks are the same bits, so everything downstream agrees to the atomics' noise."""
+    base = _train_probe_in_subprocess({"HN_FUSE_STEM_BNPOOL": "0"}, 2, ("bf16",))["bf16"]
+    fused = _train_probe_in_subprocess({"HN_FUSE_STEM_BNPOOL": "1"}, 2, ("bf16",))["bf16"]
+    _assert_probes_agree(base, fused, "bf16", 1e-2)
+    assert abs(base["rm"][0] - fused["rm"][0]) <= 1e-6 * abs(base["rm"][0]) and abs(base["rv"][0] - fused["rv"][0]) <= 1e-6 * abs(base["rv"][0])   # the stem's own running statistics
