@@ -122,6 +122,9 @@ int hn_launch_bn_eval_affine(const float* gamma, const float* beta, const float*
                               float* b, float* save_mean, float* save_invstd, int C, hipStream_t s);
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
                          long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s);
+int hn_launch_bn_bwd_pool(const void* dpool_h, const void* pidx, int B, int Hi, int Wi, const unsigned char* bmask, const void* z_h,
+                          const float* mean, const float* invstd, const float* gamma, double* S1, double* S2, void* dz_h, int C, int phase,
+                          hipStream_t s);
 int hn_launch_affine_act_bn_pool(const void* z_h, const double* sum, const double* sumsq, double n, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float* a, float* b, float* save_mean,
                                  float* save_invstd, unsigned char* bmask, void* pool_h, void* idx, int B, int Hi, int Wi, int C, hipStream_t s);

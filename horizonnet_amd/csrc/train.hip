@@ -217,7 +217,10 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
 // tensor or null).  Produces dz (gradient w.r.t. the conv output), optional dpre (masked dy, the identity-branch
 // gradient), and the parameter gradients.
 // dy_bf16: dy (and dpre) are bf16 tensors -- every unit in bf16 mode except the stem, whose dy comes from the float32 max-pool adjoint.
-int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0, int dy_bf16 = -1)
+// pool_src (the stem in the bf16 step): `dy` is not materialised -- the BatchNorm adjoint forms the max-pool adjoint of the pooled gradient
+// `pool_src` (bf16 [B][Hi/2][Wi/2][C], position words at pl.pidx) on the fly (hn_launch_bn_bwd_pool)
+int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0, int dy_bf16 = -1,
+                  const float* pool_src = nullptr)
 {
     if (dy_bf16 < 0) dy_bf16 = c.gh() ? 1 : 0;
     // bf16 mode: dz is also written as bf16 (slot 0 / 1 of the staging buffers) for this unit's data-gradient GEMM
@@ -234,6 +237,12 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     // ymask != null: the unit ends in a ReLU; the adjoint reads the bit mask its affine_act pass stored (1/16 of y's bytes)
     const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
+    if (pool_src) {
+        HN_REQUIRE(stem_bf16 && bmask && !dpre && !cl.has_bias, "unit_backward: the pooled-gradient form is the bf16 stem's");
+        if ((rc = hn_launch_bn_bwd_pool(pool_src, c.W + c.pl.pidx, c.B, u.Ho, u.Wo, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds,
+                                        ds + C, dz_h, C, 0, c.s)))
+            return rc;
+    } else
     if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, dy_bf16, c.s))) return rc;
     // S2 / S1 are the BatchNorm weight / bias gradients: double -> float into the flat gradient buffer, deferred to the
     // segment's one batched launch (the sums stay untouched until then) ...
@@ -257,6 +266,12 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     const bool fused_db = cl.has_bias && bf16_gemms && dy_bf16 && !tapped && C % 8 == 0;
     const bool f32_dz_needed = !bf16_gemms || (cl.has_bias && !fused_db) || tapped;
     double* db = ds + 2 * C;
+    if (pool_src) {
+        HN_REQUIRE(!f32_dz_needed && !fused_db, "unit_backward: the pooled-gradient form writes bf16 dz only");
+        if ((rc = hn_launch_bn_bwd_pool(pool_src, c.W + c.pl.pidx, c.B, u.Ho, u.Wo, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds,
+                                        ds + C, dz_h, C, 1, c.s)))
+            return rc;
+    } else
     if ((rc = hn_launch_bn_bwd_apply(dy, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds, ds + C, (double)u.M,
                                      f32_dz_needed ? dz : nullptr, dpre, dz_h, u.M, C, c.e->train_bf16, dy_bf16, fused_db ? db : nullptr,
                                      c.s)))
@@ -478,7 +493,7 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
         // activation of the stem is consumed by the pool only.  HN_FUSE_STEM_BNPOOL=0: the two passes (A/B runs, the bit-equality test)
         static const char* fbp = getenv("HN_FUSE_STEM_BNPOOL");
         const bool stem_tapped_f = e->debug_unit == 0 || e->debug_unit2 == 0;      // a parity test reads this unit's tensors: keep the two-pass form (it writes the bf16 activation)
-        if (e->train_bf16 && !c.bn_eval(u) && !stem_tapped_f && !(fbp && fbp[0] == '0')) {
+        if (e->train_bf16 && !c.bn_eval(u) && !stem_tapped_f && e->fuse_stem_bnpool && !(fbp && fbp[0] == '0')) {
             const ConvLayer& cl = a.convs[u.ci];
             const int C = cl.cout;
             double* ds = reinterpret_cast<double*>(W + pl.dstat) + u.sf;
@@ -756,8 +771,16 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
         // with a debug tap on the stem (parity tests read float32 dy / dz) the float32 form is kept
         const bool stem_tapped = (e->debug_unit >= 0 && &u == &pl.units[e->debug_unit]) || (e->debug_unit2 >= 0 && &u == &pl.units[e->debug_unit2]);
         const int stem_h = (e->train_bf16 && c.gh() && !stem_tapped) ? 1 : 0;
+        // ... and with batch statistics (no eval-mode BatchNorm: that path clears the sums between the two passes) the max-pool adjoint is
+        // never materialised: the BatchNorm adjoint gathers it from the pooled gradient (HN_FUSE_STEM_POOLBWD=0: the separate pass)
+        static const char* fpb = getenv("HN_FUSE_STEM_POOLBWD");
+        const bool pool_fused = stem_h && !c.bn_eval(u) && e->fuse_stem_poolbwd && !(fpb && fpb[0] == '0');
+        if (LIVE && pool_fused) {
+            if ((rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/1, /*pool_src=*/Ga))) return rc;
+        } else {
         if (LIVE && (rc = hn_launch_maxpool_bwd_idx(W + pl.pidx, Ga, Gb, B, 256, 512, 64, c.gh(), s, stem_h))) return rc;     // d(stem y) -> Gb
         if (LIVE && (rc = unit_backward(c, u, Gb, W + u.y, Gc, nullptr, -1, /*dy_bf16=*/stem_h))) return rc;
+        }
     }
     if ((rc = flush(seg))) return rc;
 #undef LIVE

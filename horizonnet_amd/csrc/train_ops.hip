@@ -386,11 +386,46 @@ __device__ __forceinline__ unsigned mask8(const unsigned char* bmask, long e)
     return (m & 0xfu) | ((m >> 4) & 0xf0u);
 }
 
-template <bool MASK>
+// POOL (the stem): dy is not a stored tensor but the max-pool adjoint of the pooled gradient, formed on the fly -- the sum, in
+// maxpool_bwd_idx_kernel's order and with its bf16 rounding, of the pooled gradients of the (up to four) 3x3 / 2 windows whose maximum sat at
+// this input pixel.  Saves writing + twice reading the 1.07 GB (B = 64) gradient of the stem activation.
+struct PoolSrc {
+    const unsigned short* dpool;     // [B][Hi/2][Wi/2][C] bf16
+    const unsigned* pidx;            // position words, one per 4 channels
+    int Hi, Wi;
+};
+__device__ __forceinline__ u32x4_t pool_grad8(const PoolSrc ps, long r, int col, int C)
+{
+    const int Ho = ps.Hi / 2, Wo = ps.Wi / 2;
+    const int wi = (int)(r % ps.Wi);
+    long t = r / ps.Wi;
+    const int hi = (int)(t % ps.Hi);
+    const long b = t / ps.Hi;
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {
+        if (ho >= Ho) continue;
+        for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
+            if (wo >= Wo) continue;
+            const long o = (b * Ho + ho) * Wo + wo;
+            const uint2 a = *reinterpret_cast<const uint2*>(ps.pidx + (o * C + col) / 4);
+            const unsigned me = (unsigned)((hi - (2 * ho - 1)) * 3 + (wi - (2 * wo - 1)));
+            float d[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(ps.dpool + o * C + col), d);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (((a.x >> (8 * k)) & 255u) == me) g[k] += d[k];
+                if (((a.y >> (8 * k)) & 255u) == me) g[4 + k] += d[4 + k];
+            }
+        }
+    }
+    return pack8(g);
+}
+
+template <bool MASK, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_h8_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ bmask,
                                                                const unsigned short* __restrict__ z, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, double* __restrict__ S1,
-                                                               double* __restrict__ S2, long M, int C, int slab)
+                                                               double* __restrict__ S2, long M, int C, int slab, PoolSrc ps = PoolSrc{})
 {
     __shared__ float red[2][256 * 8];
     const int C8 = C / 8;
@@ -427,7 +462,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_h8_kernel(const unsigned sh
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long e = (r + (long)j * RL) * C + col;
-            gv[j] = *reinterpret_cast<const u32x4_t*>(dy + e);
+            gv[j] = POOL ? pool_grad8(ps, r + (long)j * RL, col, C) : *reinterpret_cast<const u32x4_t*>(dy + e);
             zv[j] = *reinterpret_cast<const u32x4_t*>(z + e);
             if (MASK) mk[j] = mask8(bmask, e);
         }
@@ -436,7 +471,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_h8_kernel(const unsigned sh
     }
     for (; r < r1; r += RL) {
         const long e = r * C + col;
-        accum(*reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(z + e), MASK ? mask8(bmask, e) : 0u);
+        accum(POOL ? pool_grad8(ps, r, col, C) : *reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(z + e),
+              MASK ? mask8(bmask, e) : 0u);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -458,13 +494,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_h8_kernel(const unsigned sh
 }
 
 // BIAS: also accumulate the column sums of dz (the conv bias gradient of the height-compression convs) into db
-template <bool MASK, bool BIAS>
+template <bool MASK, bool BIAS, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ bmask,
                                                               const unsigned short* __restrict__ z, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                               const double* __restrict__ S1, const double* __restrict__ S2, double n,
                                                               unsigned short* __restrict__ dpre, unsigned short* __restrict__ dz_h,
-                                                              double* __restrict__ db, long M, int C, int slab)
+                                                              double* __restrict__ db, long M, int C, int slab, PoolSrc ps = PoolSrc{})
 {
     __shared__ float red[BIAS ? 256 * 8 : 1];
     const int C8 = C / 8;
@@ -506,7 +542,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const unsigned sho
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long e = (r + (long)j * RL) * C + col;
-            gv[j] = *reinterpret_cast<const u32x4_t*>(dy + e);
+            gv[j] = POOL ? pool_grad8(ps, r + (long)j * RL, col, C) : *reinterpret_cast<const u32x4_t*>(dy + e);
             zv[j] = *reinterpret_cast<const u32x4_t*>(z + e);
             if (MASK) mk[j] = mask8(bmask, e);
         }
@@ -515,7 +551,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const unsigned sho
     }
     for (; r < r1; r += RL) {
         const long e = r * C + col;
-        one(e, *reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(z + e), MASK ? mask8(bmask, e) : 0u);
+        one(e, POOL ? pool_grad8(ps, r, col, C) : *reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(z + e),
+            MASK ? mask8(bmask, e) : 0u);
     }
     if (BIAS) {
 #pragma unroll
@@ -1039,6 +1076,29 @@ int hn_launch_bn_bwd_apply(const float* dy, const unsigned char* bmask, const fl
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, bmask, z, mean, invstd, gamma, S1, S2, n, dz,
                        dpre, reinterpret_cast<unsigned short*>(dz_h), total4, C / 4, z_bf16, dy_bf16);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The stem's BatchNorm adjoint straight from the POOLED gradient (bf16 training step): dy = max-pool adjoint formed on the fly (PoolSrc).
+// Same sums and the same dz bits as hn_launch_maxpool_bwd_idx (bf16 output) followed by hn_launch_bn_bwd_reduce / _apply.
+int hn_launch_bn_bwd_pool(const void* dpool_h, const void* pidx, int B, int Hi, int Wi, const unsigned char* bmask, const void* z_h,
+                          const float* mean, const float* invstd, const float* gamma, double* S1, double* S2, void* dz_h, int C, int phase,
+                          hipStream_t s)
+{
+    HN_REQUIRE(bmask && h8_shape(C) && C % 8 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "bn_bwd_pool: unsupported shape C=%d", C);
+    const long M = (long)B * Hi * Wi;
+    const int slab8 = h8_slab(M, C);
+    dim3 grid8((unsigned)((M + slab8 - 1) / slab8), (unsigned)((C + 2047) / 2048));
+    const PoolSrc ps = {reinterpret_cast<const unsigned short*>(dpool_h), reinterpret_cast<const unsigned*>(pidx), Hi, Wi};
+    const unsigned short* zh = reinterpret_cast<const unsigned short*>(z_h);
+    if (phase == 0)
+        hipLaunchKernelGGL((bn_bwd_reduce_h8_kernel<true, true>), grid8, dim3(256), 0, s, (const unsigned short*)nullptr, bmask, zh, mean, invstd, S1,
+                           S2, M, C, slab8, ps);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_h8_kernel<true, false, true>), grid8, dim3(256), 0, s, (const unsigned short*)nullptr, bmask, zh, mean, invstd,
+                           gamma, S1, S2, (double)M, (unsigned short*)nullptr, reinterpret_cast<unsigned short*>(dz_h), (double*)nullptr, M, C,
+                           slab8, ps);
     HN_LAUNCH_CHECK();
     return 0;
 }

@@ -115,7 +115,11 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * (float32 accumulation, gates, cell state and outputs); 0 = the float32 recurrence kernel of hn_forward.
  * "fuse_downsample" (default 1): block 0 of a ResNet stage ends in ONE launch for
  * relu(bn3(conv3(t2)) + bn_d(downsample(x))) (model.py:78-81) instead of two (hn_forward: all four stages;
- * hn_forward_bf16: layer1 / layer2); bit-identical results. */
+ * hn_forward_bf16: layer1 / layer2); bit-identical results.
+ * "fuse_stem_bnpool" (default 1): the bf16 training forward runs the stem's BatchNorm + ReLU + max-pool (model.py:73-76) as ONE pass
+ * over z (pooled tensor, position words and ReLU masks are the two-pass form's bit for bit).
+ * "fuse_stem_poolbwd" (default 1): the bf16 training backward never materialises the max-pool adjoint: the stem's BatchNorm adjoint
+ * gathers it from the pooled gradient (same dz bits). */
 int hn_set_option(hn_engine* e, const char* name, int value);
 
 /* Parity-test taps: during the following hn_forward / hn_forward_bf16 calls the named intermediate is copied

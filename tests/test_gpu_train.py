@@ -734,6 +734,7 @@ for prec in %r:
                  "rm": [float(sd[k].double().norm()) for k in sorted(sd) if k.endswith("running_mean")][:12],
                  "rv": [float(sd[k].double().norm()) for k in sorted(sd) if k.endswith("running_var")][:12],
                  "g": [float(p.grad.double().norm()) for n_, p in sorted(net.named_parameters()) if n_.endswith("conv1.weight") or n_.endswith("conv2.weight")][:16],
+                 "stem": [float(p.grad.double().norm()) for n_, p in sorted(net.named_parameters()) if n_.startswith("feature_extractor.encoder.conv1.") or n_.startswith("feature_extractor.encoder.bn1.")],
                  "status": int(net.hip_status(torch.device("cuda:0")))}
 print("RESULT " + json.dumps(out))
 ''' % (ROOT, tuple(precs), B)
@@ -783,3 +784,36 @@ def test_fused_stem_batchnorm_pool_equals_the_two_passes():
     fused = _train_probe_in_subprocess({"HN_FUSE_STEM_BNPOOL": "1"}, 2, ("bf16",))["bf16"]
     _assert_probes_agree(base, fused, "bf16", 1e-2)
     assert abs(base["rm"][0] - fused["rm"][0]) <= 1e-6 * abs(base["rm"][0]) and abs(base["rv"][0] - fused["rv"][0]) <= 1e-6 * abs(base["rv"][0])   # the stem's own running statistics
+
+
+def test_stem_batchnorm_adjoint_from_the_pooled_gradient_equals_the_separate_pass():
+    """hn_launch_bn_bwd_pool (the stem's BatchNorm adjoint gathers the max-pool adjoint from the pooled gradient: bn_bwd_*_h8_kernel<.., POOL>)
+    against maxpool_bwd_idx_kernel + the plain adjoint (engine option "fuse_stem_poolbwd" = 0): TWO backward passes over the activations of ONE
+    bf16 training forward, so everything upstream of the stem is the same up to the atomics' order; the stem's dz is the same bits, its
+    conv / BatchNorm gradients agree to that noise."""
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(61, "random"))
+    net = net.to(DEV).train()
+    net.train_precision = "bf16"
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(62)).to(DEV)
+    bon, cor = net(x)
+    loss = bon.abs().sum() + cor.sum()
+    names = ["feature_extractor.encoder.conv1.1.weight", "feature_extractor.encoder.bn1.weight", "feature_extractor.encoder.bn1.bias",
+             "feature_extractor.encoder.layer1.0.conv1.weight"]
+    params = dict(net.named_parameters())
+    got = {}
+    for mode in (0, 1, 0):
+        net.set_engine_option("fuse_stem_poolbwd", mode)
+        for p in net.parameters():
+            p.grad = None
+        loss.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        got.setdefault(mode, []).append({k: params[k].grad.detach().double().clone() for k in names})
+    assert net.hip_status(DEV) == 0
+    noise = {k: float((got[0][0][k] - got[0][1][k]).norm() / got[0][0][k].norm()) for k in names}       # the separate pass against itself
+    diff = {k: float((got[0][0][k] - got[1][0][k]).norm() / got[0][0][k].norm()) for k in names}
+    print("[parity] stem adjoint from the pooled gradient: relative L2 difference", diff, "| run-to-run noise of the separate pass", noise)
+    for k in names:
+        assert diff[k] <= max(3.0 * noise[k], 1e-5), (k, diff[k], noise[k])
