@@ -684,22 +684,32 @@ __global__ __launch_bounds__(256) void upsample_flatten_bwd_kernel(const float* 
     const int i = blockIdx.x;            // input column
     const int b = blockIdx.y;
     const int n = cq * hq;
+    // which of the 256 output columns t touch input column i, and with which weights: computed ONCE per workgroup (one t per thread)
+    // instead of by every element for every t (the float index arithmetic x 256 was the kernel: 0.63 ms per step for 17 MB of output)
+    __shared__ unsigned char hit[256];
+    __shared__ float wt0[256], wt1[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        const float src = (1.0f / (float)f) * ((float)(t + f) + 0.5f) - 0.5f;
+        const int i0p = (int)src;
+        const float w1 = src - (float)i0p, w0 = 1.0f - w1;
+        int i0 = i0p - 1;
+        i0 = i0 < 0 ? i0 + Wq : i0;
+        int i1 = i0p;
+        i1 = i1 >= Wq ? i1 - Wq : i1;
+        hit[t] = (unsigned char)((i0 == i ? 1 : 0) | (i1 == i ? 2 : 0));
+        wt0[t] = w0;
+        wt1[t] = w1;
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int c = e % cq, h = e / cq;
         float g = 0.f;
-        // outputs t whose footprint can touch column i: padded source index src(t) in [i, i+2)
-        for (int t = 0; t < 256; ++t) {
-            const float src = (1.0f / (float)f) * ((float)(t + f) + 0.5f) - 0.5f;
-            const int i0p = (int)src;
-            const float w1 = src - (float)i0p, w0 = 1.0f - w1;
-            int i0 = i0p - 1;
-            i0 = i0 < 0 ? i0 + Wq : i0;
-            int i1 = i0p;
-            i1 = i1 >= Wq ? i1 - Wq : i1;
-            if (i0 != i && i1 != i) continue;
+        for (int t = 0; t < 256; ++t) {            // same terms in the same order as before
+            const unsigned m = hit[t];
+            if (m == 0) continue;
             const float d = dseq[((long)t * B + b) * 1024 + col0 + c * hq + h];
-            if (i0 == i) g += w0 * d;
-            if (i1 == i) g += w1 * d;
+            if (m & 1u) g += wt0[t] * d;
+            if (m & 2u) g += wt1[t] * d;
         }
         const long o = (((long)b * hq + h) * Wq + i) * cq + c;
         if (out_bf16) {
