@@ -122,6 +122,9 @@ int hn_launch_bn_eval_affine(const float* gamma, const float* beta, const float*
                               float* b, float* save_mean, float* save_invstd, int C, hipStream_t s);
 int hn_launch_affine_act(const float* z, const float* a, const float* b, const float* res, float* y, unsigned char* bmask, void* y_h,
                          long M, int C, int relu, int z_bf16, int res_bf16, hipStream_t s);
+int hn_launch_bn_bwd_dual(const void* dy_h, const unsigned char* bmask, const void* za_h, const float* mean_a, const float* invstd_a,
+                          const float* gamma_a, double* S1a, double* S2a, void* dza_h, const void* zb_h, const float* mean_b, const float* invstd_b,
+                          const float* gamma_b, double* S1b, double* S2b, void* dzb_h, long M, int C, int phase, hipStream_t s);
 int hn_launch_bn_bwd_pool(const void* dpool_h, const void* pidx, int B, int Hi, int Wi, const unsigned char* bmask, const void* z_h,
                           const float* mean, const float* invstd, const float* gamma, double* S1, double* S2, void* dz_h, int C, int phase,
                           hipStream_t s);

@@ -219,8 +219,10 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
 // dy_bf16: dy (and dpre) are bf16 tensors -- every unit in bf16 mode except the stem, whose dy comes from the float32 max-pool adjoint.
 // pool_src (the stem in the bf16 step): `dy` is not materialised -- the BatchNorm adjoint forms the max-pool adjoint of the pooled gradient
 // `pool_src` (bf16 [B][Hi/2][Wi/2][C], position words at pl.pidx) on the fly (hn_launch_bn_bwd_pool)
+// bn_done: the BatchNorm adjoint of this unit (its sums and its bf16 dz in staging slot dzh_slot) was already produced by
+// bn_backward_dual below; only the parameter gradients remain (dy / dz / dpre are not touched)
 int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0, int dy_bf16 = -1,
-                  const float* pool_src = nullptr)
+                  const float* pool_src = nullptr, int bn_done = 0)
 {
     if (dy_bf16 < 0) dy_bf16 = c.gh() ? 1 : 0;
     // bf16 mode: dz is also written as bf16 (slot 0 / 1 of the staging buffers) for this unit's data-gradient GEMM
@@ -237,6 +239,9 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     // ymask != null: the unit ends in a ReLU; the adjoint reads the bit mask its affine_act pass stored (1/16 of y's bytes)
     const unsigned char* bmask = ymask ? reinterpret_cast<const unsigned char*>(c.W + u.mk) : nullptr;
     int rc;
+    if (bn_done) {
+        HN_REQUIRE(dz_h && !u.stem && !cl.has_bias && !c.bn_eval(u), "unit_backward: bn_done needs the plain bf16 unit");
+    } else
     if (pool_src) {
         HN_REQUIRE(stem_bf16 && bmask && !dpre && !cl.has_bias, "unit_backward: the pooled-gradient form is the bf16 stem's");
         if ((rc = hn_launch_bn_bwd_pool(pool_src, c.W + c.pl.pidx, c.B, u.Ho, u.Wo, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds,
@@ -266,6 +271,9 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
     const bool fused_db = cl.has_bias && bf16_gemms && dy_bf16 && !tapped && C % 8 == 0;
     const bool f32_dz_needed = !bf16_gemms || (cl.has_bias && !fused_db) || tapped;
     double* db = ds + 2 * C;
+    if (bn_done) {
+        HN_REQUIRE(!f32_dz_needed && !fused_db, "unit_backward: bn_done units read their bf16 dz only");
+    } else
     if (pool_src) {
         HN_REQUIRE(!f32_dz_needed && !fused_db, "unit_backward: the pooled-gradient form writes bf16 dz only");
         if ((rc = hn_launch_bn_bwd_pool(pool_src, c.W + c.pl.pidx, c.B, u.Ho, u.Wo, bmask, c.W + u.z, st, st + C, c.bound(cl.bnkey + ".weight"), ds,
@@ -319,6 +327,40 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
         return 0;
     }
     return hn_launch_unpack_conv(scratch, c.grad(cl.wkey + ".weight"), cl.cout, cl.cin, cl.k, cl.k, u.stem ? 8 : 0, c.s);
+}
+
+// Block 0 of a ResNet stage (bf16 step): conv3's BatchNorm (ua, ends in the block's ReLU) and the downsample branch's (ub) see the same masked
+// gradient: one reduce + one apply pass for both (hn_launch_bn_bwd_dual) -> their sums in the two units' slots, bf16 dz of ua / ub in staging
+// slots slot_a / slot_b; the masked gradient itself (dpre) is not written.  unit_backward(..., bn_done = 1) then adds the parameter gradients.
+bool bn_dual_ok(const Ctx& c, const Unit& ua, const Unit& ub)
+{
+    static const char* env = getenv("HN_FUSE_BN_DUAL");          // "0": two separate adjoints (A/B runs)
+    const int C = c.a.convs[ua.ci].cout;
+    auto tapped = [&](const Unit& u) {
+        return (c.e->debug_unit >= 0 && &u == &c.pl.units[c.e->debug_unit]) || (c.e->debug_unit2 >= 0 && &u == &c.pl.units[c.e->debug_unit2]);
+    };
+    return c.e->train_bf16 && c.gh() && c.e->fuse_bn_dual && !(env && env[0] == '0') && !c.bn_eval(ua) && !c.bn_eval(ub) && !tapped(ua) && !tapped(ub) &&
+           c.a.convs[ub.ci].cout == C && ua.M == ub.M && C % 64 == 0 && c.a.convs[ua.ci].cin % 64 == 0 && c.a.convs[ub.ci].cin % 64 == 0 &&
+           !c.a.convs[ua.ci].has_bias && !c.a.convs[ub.ci].has_bias;
+}
+
+int bn_backward_dual(const Ctx& c, const Unit& ua, const Unit& ub, const float* dy, int slot_a, int slot_b)
+{
+    const ConvLayer& ca = c.a.convs[ua.ci];
+    const ConvLayer& cb = c.a.convs[ub.ci];
+    const int C = ca.cout;
+    double* dsa = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + ua.sb;
+    double* dsb = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + ub.sb;
+    const float* sta = c.W + ua.st;
+    const float* stb = c.W + ub.st;
+    const unsigned char* bmask = reinterpret_cast<const unsigned char*>(c.W + ua.mk);
+    for (int phase = 0; phase < 2; ++phase) {
+        if (int rc = hn_launch_bn_bwd_dual(dy, bmask, c.W + ua.z, sta, sta + C, c.bound(ca.bnkey + ".weight"), dsa, dsa + C, c.W + c.pl.dzh[slot_a],
+                                           c.W + ub.z, stb, stb + C, c.bound(cb.bnkey + ".weight"), dsb, dsb + C, c.W + c.pl.dzh[slot_b], ua.M, C, phase,
+                                           c.s))
+            return rc;
+    }
+    return 0;
 }
 
 // data gradient of one unit: dx = conv^T(dz) (+ add), one launch per stride-parity class
@@ -745,6 +787,11 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             const Unit& u2 = pl.units[i1 + 1];
             const Unit& u3 = pl.units[i1 + (j == 0 ? 3 : 2)];
             // conv3 + bn3 + (add) + relu: mask = block output
+            const bool dual = j == 0 && bn_dual_ok(c, u3, pl.units[pl.dsu[li]]);
+            if (LIVE && dual) {      // block 0: bn3 and the downsample BatchNorm in one reduce + one apply pass (slots 0 and 1)
+                if ((rc = bn_backward_dual(c, u3, pl.units[pl.dsu[li]], Ga, 0, 1))) return rc;
+                if ((rc = unit_backward(c, u3, Ga, W + u3.y, Gb, nullptr, 0, -1, nullptr, /*bn_done=*/1))) return rc;
+            } else
             if (LIVE && (rc = unit_backward(c, u3, Ga, W + u3.y, Gb, Gc))) return rc;       // dz3 -> Gb, identity grad -> Gc
             if (LIVE && (rc = unit_dgrad(c, u3, Gb, nullptr, Gd))) return rc;               // d(t2) -> Gd
             if (LIVE && (rc = unit_backward(c, u2, Gd, W + u2.y, Ga, nullptr))) return rc;  // dz2 -> Ga
@@ -752,6 +799,9 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             if (LIVE && (rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> Gd
             if (j == 0) {
                 const Unit& ud = pl.units[pl.dsu[li]];
+                if (LIVE && dual) {
+                    if ((rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr, 1, -1, nullptr, /*bn_done=*/1))) return rc;      // its dz has been in slot 1 since bn_backward_dual
+                } else
                 if (LIVE && (rc = unit_backward(c, ud, Gc, nullptr, Ga, nullptr, 1))) return rc;   // dz_ds -> Ga (bf16 slot 1: slot 0 still holds dz1)
                 // (+ the height-compression branch's gradient of this block input, C_{li-1}: it rides as the data gradient's
                 //  identity input instead of a separate read-modify-write pass over the largest gradient tensors)

@@ -567,6 +567,143 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h8_kernel(const unsigned sho
     }
 }
 
+// ---- block 0 of a ResNet stage: bn3 and the downsample branch's BatchNorm see the SAME masked gradient g = dOut * relu'(block output) ----
+// (model.py:78-81: out = relu(bn3(conv3(t2)) + bn_d(downsample(x)))).  As two adjoints the second one read the masked gradient the
+// first one had written (dpre); here ONE reduce pass and ONE apply pass serve both: dOut and the mask are read once per pass, dpre is
+// not written at all (nothing else reads it in block 0).  Same per-element arithmetic as bn_bwd_{reduce,apply}_h8_kernel.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_dual_h8_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ bmask,
+                                                                    const unsigned short* __restrict__ za_, const float* __restrict__ mean_a,
+                                                                    const float* __restrict__ invstd_a, const unsigned short* __restrict__ zb_,
+                                                                    const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
+                                                                    double* __restrict__ S1a, double* __restrict__ S2a, double* __restrict__ S1b,
+                                                                    double* __restrict__ S2b, long M, int C, int slab)
+{
+    __shared__ float red[3][256 * 8];
+    const int C8 = C / 8;
+    const int CO = C8 < 256 ? C8 : 256;
+    const int RL = 256 / CO;
+    const int co = threadIdx.x % CO, rl = threadIdx.x / CO;
+    const int col = blockIdx.y * 2048 + co * 8;
+    const long r0 = (long)blockIdx.x * slab;
+    long r1 = r0 + slab;
+    if (r1 > M) r1 = M;
+    float ia[8], oa[8], ib[8], ob[8], s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        ia[k] = invstd_a[col + k]; oa[k] = -mean_a[col + k] * ia[k];
+        ib[k] = invstd_b[col + k]; ob[k] = -mean_b[col + k] * ib[k];
+        s0[k] = s1[k] = s2[k] = 0.f;
+    }
+    auto accum = [&](const u32x4_t gv, const u32x4_t av, const u32x4_t bv, unsigned mk) __attribute__((always_inline)) {
+        float g[8], a[8], b[8];
+        unpack8(gv, g);
+        unpack8(av, a);
+        unpack8(bv, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = ((mk >> k) & 1u) ? g[k] : 0.f;
+            s0[k] += gk;
+            s1[k] += gk * (a[k] * ia[k] + oa[k]);
+            s2[k] += gk * (b[k] * ib[k] + ob[k]);
+        }
+    };
+    long r = r0 + rl;
+    for (; r + 1L * RL < r1; r += 2L * RL) {        // 2 rows per trip: 6 sixteen-byte loads in flight per lane
+        u32x4_t gv[2], av[2], bv[2];
+        unsigned mk[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long e = (r + (long)j * RL) * C + col;
+            gv[j] = *reinterpret_cast<const u32x4_t*>(dy + e);
+            av[j] = *reinterpret_cast<const u32x4_t*>(za_ + e);
+            bv[j] = *reinterpret_cast<const u32x4_t*>(zb_ + e);
+            mk[j] = mask8(bmask, e);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accum(gv[j], av[j], bv[j], mk[j]);
+    }
+    for (; r < r1; r += RL) {
+        const long e = r * C + col;
+        accum(*reinterpret_cast<const u32x4_t*>(dy + e), *reinterpret_cast<const u32x4_t*>(za_ + e), *reinterpret_cast<const u32x4_t*>(zb_ + e),
+              mask8(bmask, e));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][threadIdx.x * 8 + k] = s0[k];
+        red[1][threadIdx.x * 8 + k] = s1[k];
+        red[2][threadIdx.x * 8 + k] = s2[k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CO * 8; t += 256) {
+        const int q = t / 8, k = t % 8;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int j = 0; j < RL; ++j) {
+            t0 += red[0][(j * CO + q) * 8 + k];
+            t1 += red[1][(j * CO + q) * 8 + k];
+            t2 += red[2][(j * CO + q) * 8 + k];
+        }
+        const int c = blockIdx.y * 2048 + q * 8 + k;
+        atomicAdd(S1a + c, (double)t0);
+        atomicAdd(S2a + c, (double)t1);
+        atomicAdd(S1b + c, (double)t0);
+        atomicAdd(S2b + c, (double)t2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_dual_h8_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ bmask,
+                                                                   const unsigned short* __restrict__ za_, const float* __restrict__ mean_a,
+                                                                   const float* __restrict__ invstd_a, const float* __restrict__ gamma_a,
+                                                                   const double* __restrict__ S1a, const double* __restrict__ S2a,
+                                                                   const unsigned short* __restrict__ zb_, const float* __restrict__ mean_b,
+                                                                   const float* __restrict__ invstd_b, const float* __restrict__ gamma_b,
+                                                                   const double* __restrict__ S1b, const double* __restrict__ S2b, double n,
+                                                                   unsigned short* __restrict__ dza_h, unsigned short* __restrict__ dzb_h, long M,
+                                                                   int C, int slab)
+{
+    const int C8 = C / 8;
+    const int CO = C8 < 256 ? C8 : 256;
+    const int RL = 256 / CO;
+    const int co = threadIdx.x % CO, rl = threadIdx.x / CO;
+    const int col = blockIdx.y * 2048 + co * 8;
+    const long r0 = (long)blockIdx.x * slab;
+    long r1 = r0 + slab;
+    if (r1 > M) r1 = M;
+    float ka[8], kza[8], kca[8], kb[8], kzb[8], kcb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {       // bn_bwd_apply_h8_kernel's coefficients, per branch
+        {
+            const float is = invstd_a[col + k], mu = mean_a[col + k];
+            const float m1 = (float)(S1a[col + k] / n), m2 = (float)(S2a[col + k] / n);
+            ka[k] = gamma_a[col + k] * is;
+            kza[k] = -ka[k] * is * m2;
+            kca[k] = -ka[k] * m1 - kza[k] * mu;
+        }
+        {
+            const float is = invstd_b[col + k], mu = mean_b[col + k];
+            const float m1 = (float)(S1b[col + k] / n), m2 = (float)(S2b[col + k] / n);
+            kb[k] = gamma_b[col + k] * is;
+            kzb[k] = -kb[k] * is * m2;
+            kcb[k] = -kb[k] * m1 - kzb[k] * mu;
+        }
+    }
+    for (long r = r0 + rl; r < r1; r += RL) {
+        const long e = r * C + col;
+        float g[8], a[8], b[8], oa[8], ob[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(dy + e), g);
+        unpack8(*reinterpret_cast<const u32x4_t*>(za_ + e), a);
+        unpack8(*reinterpret_cast<const u32x4_t*>(zb_ + e), b);
+        const unsigned mk = mask8(bmask, e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = ((mk >> k) & 1u) ? g[k] : 0.f;
+            oa[k] = ka[k] * gk + (kza[k] * a[k] + kca[k]);
+            ob[k] = kb[k] * gk + (kzb[k] * b[k] + kcb[k]);
+        }
+        *reinterpret_cast<u32x4_t*>(dza_h + e) = pack8(oa);
+        *reinterpret_cast<u32x4_t*>(dzb_h + e) = pack8(ob);
+    }
+}
+
 __global__ __launch_bounds__(256) void d2f_kernel(const double* in, float* out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1109,6 +1246,28 @@ int hn_launch_bn_bwd_pool(const void* dpool_h, const void* pidx, int B, int Hi, 
         hipLaunchKernelGGL((bn_bwd_apply_h8_kernel<true, false, true>), grid8, dim3(256), 0, s, (const unsigned short*)nullptr, bmask, zh, mean, invstd,
                            gamma, S1, S2, (double)M, (unsigned short*)nullptr, reinterpret_cast<unsigned short*>(dz_h), (double*)nullptr, M, C,
                            slab8, ps);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// phase 0: the sums of both branches (S1 / S2 of each, zeroed by the caller); phase 1: both dz as bf16.  All operands bf16, M rows of C channels.
+int hn_launch_bn_bwd_dual(const void* dy_h, const unsigned char* bmask, const void* za_h, const float* mean_a, const float* invstd_a,
+                          const float* gamma_a, double* S1a, double* S2a, void* dza_h, const void* zb_h, const float* mean_b, const float* invstd_b,
+                          const float* gamma_b, double* S1b, double* S2b, void* dzb_h, long M, int C, int phase, hipStream_t s)
+{
+    HN_REQUIRE(bmask && h8_shape(C), "bn_bwd_dual: unsupported shape C=%d", C);
+    const int slab8 = h8_slab(M, C);
+    dim3 grid8((unsigned)((M + slab8 - 1) / slab8), (unsigned)((C + 2047) / 2048));
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(dy_h);
+    const unsigned short* zah = reinterpret_cast<const unsigned short*>(za_h);
+    const unsigned short* zbh = reinterpret_cast<const unsigned short*>(zb_h);
+    if (phase == 0)
+        hipLaunchKernelGGL(bn_bwd_reduce_dual_h8_kernel, grid8, dim3(256), 0, s, dyh, bmask, zah, mean_a, invstd_a, zbh, mean_b, invstd_b, S1a, S2a, S1b,
+                           S2b, M, C, slab8);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_dual_h8_kernel, grid8, dim3(256), 0, s, dyh, bmask, zah, mean_a, invstd_a, gamma_a, S1a, S2a, zbh, mean_b,
+                           invstd_b, gamma_b, S1b, S2b, (double)M, reinterpret_cast<unsigned short*>(dza_h), reinterpret_cast<unsigned short*>(dzb_h),
+                           M, C, slab8);
     HN_LAUNCH_CHECK();
     return 0;
 }

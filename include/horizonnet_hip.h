@@ -119,7 +119,9 @@ int hn_check_status(hn_engine* e, void* workspace, int* status_out);
  * "fuse_stem_bnpool" (default 1): the bf16 training forward runs the stem's BatchNorm + ReLU + max-pool (model.py:73-76) as ONE pass
  * over z (pooled tensor, position words and ReLU masks are the two-pass form's bit for bit).
  * "fuse_stem_poolbwd" (default 1): the bf16 training backward never materialises the max-pool adjoint: the stem's BatchNorm adjoint
- * gathers it from the pooled gradient (same dz bits). */
+ * gathers it from the pooled gradient (same dz bits).
+ * "fuse_bn_dual" (default 1): bf16 training backward, block 0 of every ResNet stage: the BatchNorm adjoints of conv3 and of the
+ * downsample branch (model.py:78-81: both see dOut * relu'(block output)) share one reduce and one apply pass. */
 int hn_set_option(hn_engine* e, const char* name, int value);
 
 /* Parity-test taps: during the following hn_forward / hn_forward_bf16 calls the named intermediate is copied

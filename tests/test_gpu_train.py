@@ -817,3 +817,41 @@ def test_stem_batchnorm_adjoint_from_the_pooled_gradient_equals_the_separate_pas
     print("[parity] stem adjoint from the pooled gradient: relative L2 difference", diff, "| run-to-run noise of the separate pass", noise)
     for k in names:
         assert diff[k] <= max(3.0 * noise[k], 1e-5), (k, diff[k], noise[k])
+
+
+def test_dual_batchnorm_adjoint_equals_two_adjoints():
+    """hn_launch_bn_bwd_dual (block 0 of every ResNet stage: conv3's and the downsample branch's BatchNorm adjoints in one reduce + one
+    apply pass, the masked gradient never written) against the two separate adjoints (engine option "fuse_bn_dual" = 0): two backward
+    passes over ONE bf16 training forward; the affected parameter gradients agree to the run-to-run noise of the separate form."""
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(71, "random"))
+    net = net.to(DEV).train()
+    net.train_precision = "bf16"
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(72)).to(DEV)
+    bon, cor = net(x)
+    loss = bon.abs().sum() + cor.sum()
+    enc = "feature_extractor.encoder."
+    names = []
+    for li in (1, 2, 3, 4):
+        names += [enc + "layer%d.0.conv3.weight" % li, enc + "layer%d.0.bn3.weight" % li, enc + "layer%d.0.bn3.bias" % li,
+                  enc + "layer%d.0.downsample.0.weight" % li, enc + "layer%d.0.downsample.1.weight" % li, enc + "layer%d.0.downsample.1.bias" % li,
+                  enc + "layer%d.0.conv1.weight" % li]
+    names.append(enc + "conv1.1.weight")
+    params = dict(net.named_parameters())
+    got = {}
+    for mode in (0, 1, 0):
+        net.set_engine_option("fuse_bn_dual", mode)
+        for p in net.parameters():
+            p.grad = None
+        loss.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        got.setdefault(mode, []).append({k: params[k].grad.detach().double().clone() for k in names})
+    assert net.hip_status(DEV) == 0
+    noise = {k: float((got[0][0][k] - got[0][1][k]).norm() / got[0][0][k].norm()) for k in names}
+    diff = {k: float((got[0][0][k] - got[1][0][k]).norm() / got[0][0][k].norm()) for k in names}
+    worst = max(names, key=lambda k: diff[k] / max(noise[k], 1e-7))
+    print("[parity] dual BatchNorm adjoint: worst relative L2 difference %.2e (%s; run-to-run noise there %.2e)" % (diff[worst], worst, noise[worst]))
+    for k in names:
+        assert diff[k] <= max(4.0 * noise[k], 2e-5), (k, diff[k], noise[k])
