@@ -40,6 +40,13 @@ struct WgradArgsH {
     int KW, sh, sw, ph, pw;
     int M, K, mchunk;
     int xstride, dzstride;   // elements between input pixels / between dz rows (>= Cin / Cout: column views of wider matrices)
+    // FOLD instantiations only (the BatchNorm-folded adjoint of the 1x1 convs, train.hip: bn_fold_*): the dz operand is dy * ReLU mask
+    // formed on load (bmask: 4 mask bits per byte, element e -> byte e >> 2, as affine_act_kernel stores them; null = no mask), the masked
+    // rows are written back in place (dz_wb = dz, by the kt == 0 tiles; null = no write-back) and the column sums of the (masked) dz
+    // operand are added to colsum_dz[Cout] (doubles, kt == 0 tiles; null = not wanted)
+    const unsigned char* bmask;
+    u16* dz_wb;
+    double* colsum_dz;
 };
 
 __device__ __forceinline__ u32x4 hbuf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff)
@@ -74,10 +81,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int l
 // row 7 / window pixel 0 / channel 3 are padding): the A image row of output pixel (ho, wo) is, per filter row dh, the 64
 // contiguous bytes of the NHWC4 input at row 2 ho - 3 + dh, pixels 2 wo - 4 .. 2 wo + 3 (circular) -- four 16-byte pieces; window
 // pixel t holds filter tap dw = t - 1 (the bf16 forward's stem layout), so callers un-pack from dw_packed + 4 floats.
-template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false>
+template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 {
     static_assert(NW == 4 || NW == 8, "waves");
+    static_assert(!(FOLD && STEM), "the folded adjoint is the 1x1 convs'");
     static_assert(!STEM || (TN == 64 && TK == 256), "stem tile");
     constexpr int THREADS = NW * 64;
     constexpr int WAVES_N = NW / 2;                  // waves along n; 2 along k'
@@ -148,12 +156,29 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
     const bool wide = p.Wo >= WCHB;
 
     u32x4 rdz[N_PS], ra[K_PS];
+    unsigned rmk[FOLD ? N_PS : 1];       // FOLD: the 8 ReLU mask bits of rdz[q] (applied in stage(), so the loads stay in flight)
+    int rm[FOLD ? N_PS : 1];             // ... and the byte offset it came from (OOB: past the range)
+    float csum[FOLD ? 8 : 1];            // ... column sums of this thread's 8 columns over all its rows
+    if (FOLD) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum[k] = 0.f;
+    }
+    const bool fold_owner = FOLD && kt == 0;     // the one workgroup per (n tile, m range) that writes back / sums
+    const bool has_mask = FOLD && p.bmask != nullptr;
+    const bool do_wb = has_mask && p.dz_wb != nullptr;       // (dz_wb == dz: the masked rows replace the rows they were read from)
+    // mask bytes of the range's first row (element e -> byte e >> 2); 2-byte loads at (dz byte offset) >> 3
+    const __amdgpu_buffer_rsrc_t rsrc_mk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(FOLD && p.bmask ? p.bmask + (((size_t)mlo * p.dzstride) >> 2) : nullptr), 0, 0x7fffffff, 0x00020000);
     auto fetch = [&](int mc) {
 #pragma unroll
         for (int q = 0; q < N_PS; ++q) {
             const int m = mc + n_row + q * N_RPP;
             const unsigned off = m < mhi ? (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 2u : OOB;
             rdz[q] = hbuf_load16(rsrc_dz, off);
+            if (FOLD) {     // branch-free: a row past the range reads mask 0 through the bounds check (its data is 0 anyway) and its write-back is dropped
+                rm[q] = m < mhi ? (int)off : (int)OOB;
+                rmk[q] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc_mk, m < mhi ? (off >> 3) : OOB, 0, 0) : 0xffffu;
+            }
         }
 #pragma unroll
         for (int q = 0; q < K_PS; ++q) {
@@ -193,6 +218,29 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
         }
     };
     auto stage = [&](int buf) {
+        if (FOLD) {
+#pragma unroll
+            for (int q = 0; q < N_PS; ++q) {
+                u32x4 v = rdz[q];
+                const unsigned mk = (rmk[q] & 0xfu) | ((rmk[q] >> 4) & 0xf0u);      // two mask bytes (4 bits each) -> 8 bits
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned keep = (((mk >> (2 * k)) & 1u) ? 0x0000ffffu : 0u) | (((mk >> (2 * k + 1)) & 1u) ? 0xffff0000u : 0u);
+                    v[k] &= keep;
+                }
+                rdz[q] = v;
+                if (fold_owner) {
+                    if (do_wb) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_dz, (unsigned)rm[q], 0, 0);
+                    if (p.colsum_dz) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            csum[2 * k] += __builtin_bit_cast(float, v[k] << 16);
+                            csum[2 * k + 1] += __builtin_bit_cast(float, v[k] & 0xffff0000u);
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < N_PS; ++q)
             *reinterpret_cast<u32x4*>(s_dz0 + buf * IMG_N + (n_row + q * N_RPP) * PN + n_col * 2) = rdz[q];
@@ -235,6 +283,20 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
         buf ^= 1;
     }
 
+    if (FOLD && fold_owner && p.colsum_dz) {
+        // the N_RPP threads that staged the same 8 columns combine through LDS (free after the loop's last barrier): one double atomic per column
+        float* red = reinterpret_cast<float*>(hsmem);        // [N_RPP][TN]
+        static_assert((size_t)N_RPP * TN * 4 <= 2 * (size_t)IMG_N, "column-sum scratch fits the dz images");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[n_row * TN + n_col + k] = csum[k];
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.f;
+            for (int r = 0; r < N_RPP; ++r) t += red[r * TN + tid];
+            atomicAdd(p.colsum_dz + n0 + tid, (double)t);
+        }
+    }
+
     const int fr = lane & 31;
     const int fh = lane >> 5;
 #pragma unroll
@@ -249,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
             }
 }
 
-template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false>
+template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false>
 int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
 {
     const int NT = a.Cout / TN, KT = a.K / TK;
@@ -261,7 +323,7 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
     split = (a.M + mchunk - 1) / mchunk;
     a.mchunk = (int)mchunk;
     const size_t lds = 2 * (size_t)WCHB * (pitch_of(TN) + pitch_of(TK));
-    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW, STEM>;
+    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW, STEM, FOLD>;
     if (lds > 65536) {
         static bool attr_done[64] = {};   // per instantiation, per device
         int dev = 0;
@@ -311,6 +373,7 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     a.mchunk = 0;
     a.xstride = xstride ? xstride : Cin;
     a.dzstride = dzstride ? dzstride : Cout;
+    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr;
     HN_REQUIRE(a.xstride >= Cin && a.dzstride >= Cout && a.xstride % 8 == 0 && a.dzstride % 8 == 0, "wgrad bf16: bad strides");
     HN_REQUIRE((double)B * Hi * Wi * a.xstride * 2.0 < 2147483648.0 && (double)a.M * a.dzstride * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
@@ -342,6 +405,48 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     return launch_wgrad_h<64, 64>(a, s);
 }
 
+// P[n][k] = sum_m g[m][n] * a[m][k] for the BatchNorm-folded adjoint of a 1x1 / stride-1 conv (train.hip: bn_fold_*): the weight-gradient
+// GEMM above with g = dy * ReLU mask formed on load.  a_h [M][Cin] bf16, dy_h [M][Cout] bf16 (masked IN PLACE when bmask is given: the
+// rows leave as g), p_out [Cout][Cin] floats (accumulated; zeroed here unless prezeroed), colsum [Cout] doubles (accumulated: sum_m g[m][n]).
+// bmask == null: plain operands (the Gram matrix a^T a of an activation with its column sums: a_h == dy_h, Cin == Cout).
+int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
+                                   double* colsum, hipStream_t s, int prezeroed)
+{
+    HN_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad bf16 fold: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
+    HN_REQUIRE(M > 0 && (double)M * Cin * 2.0 < 2147483648.0 && (double)M * Cout * 2.0 < 4294967296.0, "wgrad bf16 fold: batch too large for 32-bit tile offsets");
+    WgradArgsH a;
+    a.x = reinterpret_cast<const u16*>(a_h); a.dz = reinterpret_cast<const u16*>(dy_h); a.dw = p_out;
+    a.Hi = 1; a.Wi = (int)M; a.Cin = Cin; a.Cout = Cout; a.KW = 1; a.sh = 1; a.sw = 1; a.ph = 0; a.pw = 0;
+    a.Ho = 1; a.Wo = (int)M;
+    a.M = (int)M;
+    a.K = Cin;
+    a.mchunk = 0;
+    a.xstride = Cin; a.dzstride = Cout;
+    a.bmask = bmask; a.dz_wb = bmask ? reinterpret_cast<u16*>(dy_h) : nullptr; a.colsum_dz = colsum;
+    {   // timing experiments only (results are wrong): 1 = no write-back, 2 = no mask loads, 4 = no column sums
+        static const char* dbg = getenv("HN_FOLD_DEBUG");
+        const int f = dbg ? atoi(dbg) : 0;
+        if (f & 1) a.dz_wb = nullptr;
+        if (f & 2) a.bmask = nullptr;
+        if (f & 4) a.colsum_dz = nullptr;
+    }
+    if (!prezeroed) HN_HIP(hipMemsetAsync(p_out, 0, (size_t)Cout * Cin * sizeof(float), s));
+    // These GEMMs are HBM-bound (K <= 512 per output channel, and the masked rows are written back), so they want MANY small workgroups
+    // in flight, not big tiles: the 8-wave 256-wide tile (one workgroup per CU, one chunk of loads in flight) took 300 us where the
+    // bytes need 120 (layer3 at B = 64); 4-wave tiles with 32-row chunks run 4 workgroups per CU.  HN_FOLD_WCH / HN_FOLD_WGS: A/B switches.
+    static const char* envc = getenv("HN_FOLD_WCH");
+    static const char* envw = getenv("HN_FOLD_WGS");
+    const int wch = envc ? atoi(envc) : 32;
+    const long target = envw ? atol(envw) : 1024;
+    if (Cout % 128 == 0 && Cin % 128 == 0)
+        return wch == 64 ? launch_wgrad_h_w<128, 128, 64, 4, false, true>(a, s, target) : launch_wgrad_h_w<128, 128, 32, 4, false, true>(a, s, target);
+    if (Cout % 128 == 0)
+        return wch == 64 ? launch_wgrad_h_w<128, 64, 64, 4, false, true>(a, s, target) : launch_wgrad_h_w<128, 64, 32, 4, false, true>(a, s, target);
+    if (Cin % 128 == 0)
+        return wch == 64 ? launch_wgrad_h_w<64, 128, 64, 4, false, true>(a, s, target) : launch_wgrad_h_w<64, 128, 32, 4, false, true>(a, s, target);
+    return wch == 64 ? launch_wgrad_h_w<64, 64, 64, 4, false, true>(a, s, 2 * target) : launch_wgrad_h_w<64, 64, 32, 4, false, true>(a, s, 2 * target);
+}
+
 // The stem's weight gradient on the bf16 matrix cores (train_precision bf16): x4_h = the NHWC4 bf16 input the bf16 forward read
 // ([B][Hi][Wi][4]), dz_h = bf16 gradient w.r.t. the stem conv output ([B][Hi/2][Wi/2][64]), dw_packed = [64][256] floats in the
 // stem's packed K order (8 filter rows x 8 window pixels x 4 channels; tap dw sits at window pixel dw + 1: un-pack with
@@ -358,6 +463,7 @@ int hn_launch_stem_wgrad_bf16(const void* x4_h, const void* dz_h, float* dw_pack
     a.K = 256;
     a.mchunk = 0;
     a.xstride = 4; a.dzstride = 64;
+    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr;
     HN_REQUIRE((double)B * Hi * Wi * 8.0 < 2147483648.0 && (double)a.M * 128.0 < 4294967296.0, "stem wgrad bf16: batch too large for 32-bit tile offsets");
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)64 * 256 * sizeof(float), s));
     return launch_wgrad_h_w<64, 256, 32, 4, true>(a, s, 512);

@@ -168,6 +168,16 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s);
 int hn_launch_pack_conv_bf16(const float* w, void* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
                               int sh, int sw, hipStream_t s, int prezeroed = 0, int xstride = 0, int dzstride = 0);
+// BatchNorm-folded adjoint of the 1x1 convs (bn_fold.hip, conv_wgrad_bf16.hip)
+int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
+                                   double* colsum, hipStream_t s, int prezeroed);
+size_t hn_bn_fold_scratch_bytes(int N, int K);
+size_t hn_bn_fold_zero_bytes(int K);
+float* hn_bn_fold_gram(void* ws, int K);
+double* hn_bn_fold_colsum(void* ws, int K);
+int hn_launch_bn_fold_finish(float* P, const double* S1_in, double* S1_out, double* S2, const void* w_h, const float* mean, const float* invstd,
+                             const float* gamma, double M, int N, int K, void* ws, const float* ones, const float* zeros, const void** wa,
+                             const float** shift_a, const void** wb, hipStream_t s);
 int hn_launch_conv_dgrad_bf16(const ConvDesc& fwd, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
                               const float* ones, const float* zeros, hipStream_t s, int grad_bf16 = 0);
 int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);

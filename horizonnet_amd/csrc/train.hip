@@ -363,6 +363,68 @@ int bn_backward_dual(const Ctx& c, const Unit& ua, const Unit& ub, const float* 
     return 0;
 }
 
+// ---- BatchNorm-folded adjoint of a 1x1 / stride-1 conv unit (bn_fold.hip): no reduce pass, no apply pass, no dz tensor ----
+// Eligible: bf16 step with bf16 gradients, batch statistics, the deferred-job backward, no debug tap anywhere (the taps read dz).
+bool bn_fold_ok(const Ctx& c, const Unit& u)
+{
+    static const char* env = getenv("HN_BN_FOLD");            // "0": the classical two-pass adjoint everywhere (A/B runs)
+    const ConvLayer& cl = c.a.convs[u.ci];
+    return c.e->train_bf16 && c.gh() && c.e->fuse_bn_fold && !(env && env[0] == '0') && c.jobs != nullptr && c.e->debug_unit < 0 &&
+           c.e->debug_unit2 < 0 && !c.bn_eval(u) && cl.k == 1 && u.sh == 1 && u.sw == 1 && !cl.has_bias && !u.stem && cl.cin % 64 == 0 &&
+           cl.cout % 64 == 0 && (double)u.M * cl.cout * 2.0 < 4294967296.0;
+}
+
+struct FoldOut {
+    const void* wa;          // [K][N] bf16: weights of the data-gradient conv on g
+    const float* shift_a;    // [K]
+    const void* wb;          // [K][K] bf16: weights of the correction conv on the unit's input
+};
+
+// g_io: the gradient w.r.t. the unit's BatchNorm output side [M][N] bf16 -- with `bmask` it arrives as dy of the block output and LEAVES
+// as g = dy * relu'(block output) (masked in place); without, it is read as is.  s1_src: null = this unit sums g itself (into its S1
+// slot), else the slot of the unit that already did (block 0: conv3 and the downsample branch see the same g).
+// ws: scratch of hn_bn_fold_scratch_bytes (one of the plan's two packed-weight scratches).
+int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* bmask, const double* s1_src, float* ws, FoldOut* out)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    const int N = cl.cout, K = cl.cin;
+    double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + u.sb;      // [S1 | S2 | -], zeroed at the start of the pass
+    const float* st = c.W + u.st;
+    float* G = hn_bn_fold_gram(ws, K);
+    double* A = hn_bn_fold_colsum(ws, K);
+    HN_REQUIRE(hn_bn_fold_scratch_bytes(N, K) <= ((size_t)1024 * 18432 + 64) * sizeof(float), "bn_fold_unit: scratch too small");
+    int rc;
+    HN_HIP(hipMemsetAsync(ws, 0, hn_bn_fold_zero_bytes(K), c.s));      // G, Q and A
+    // Gram matrix + column sums of the unit's input activation
+    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, const_cast<float*>(c.W + u.xh), G, u.M, K, K, nullptr, A, c.s, 1))) return rc;
+    // P = g^T a into the unit's weight-gradient scratch (zeroed with all the others at the start of the pass)
+    float* P = c.W + u.wg;
+    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, g_io, P, u.M, K, N, bmask, s1_src ? nullptr : ds, c.s, 1))) return rc;
+    const void* wh = reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci);
+    if ((rc = hn_launch_bn_fold_finish(P, s1_src ? s1_src : ds, ds, ds + N, wh, st, st + N, c.bound(cl.bnkey + ".weight"), (double)u.M, N, K, ws,
+                                       c.P + c.a.ones_off, c.P + c.a.zeros_off, &out->wa, &out->shift_a, &out->wb, c.s)))
+        return rc;
+    c.jobs->push_back(mj_make(MJ_D2F, ds + N, c.grad(cl.bnkey + ".weight"), N));
+    c.jobs->push_back(mj_make(MJ_D2F, ds, c.grad(cl.bnkey + ".bias"), N));
+    c.jobs->push_back(mj_unpack(P, c.grad(cl.wkey + ".weight"), N, K, 1, 1, 0));
+    return 0;
+}
+
+// da = g (c1 * W) - a Q - r (+ add): two plain 1x1 convs; tmp and out are [M][K] bf16 gradient buffers (tmp != out)
+int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g, float* tmp, float* out)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    const int N = cl.cout, K = cl.cin;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = c.B; d.Hi = u.Ho; d.Wi = u.Wo; d.Ho = u.Ho; d.Wo = u.Wo; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1; d.relu = 0;
+    d.scale = c.P + c.a.ones_off;
+    d.x = g; d.w = reinterpret_cast<const float*>(f.wa); d.shift = f.shift_a; d.res = nullptr; d.y = tmp; d.Cin = N; d.Cout = K; d.ldy = K;
+    if (int rc = hn_launch_conv_bf16(d, 0, c.s)) return rc;
+    d.x = c.W + u.xh; d.w = reinterpret_cast<const float*>(f.wb); d.shift = c.P + c.a.zeros_off; d.res = tmp; d.y = out; d.Cin = K; d.Cout = K; d.ldy = K;
+    return hn_launch_conv_bf16(d, 0, c.s);
+}
+
 // data gradient of one unit: dx = conv^T(dz) (+ add), one launch per stride-parity class
 int unit_dgrad(const Ctx& c, const Unit& u, const float* dz, const float* add, float* dx, int dzh_slot = 0)
 {
@@ -787,6 +849,28 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             const Unit& u2 = pl.units[i1 + 1];
             const Unit& u3 = pl.units[i1 + (j == 0 ? 3 : 2)];
             // conv3 + bn3 + (add) + relu: mask = block output
+            // BatchNorm-folded adjoint (bn_fold.hip): blocks 1.. of every stage, and block 0 where the downsample branch is stride 1 too (layer1)
+            const bool fold3 = bn_fold_ok(c, u3) && (j > 0 || bn_fold_ok(c, pl.units[pl.dsu[li]]));
+            if (fold3) {
+                FoldOut f3, fd;
+                const Unit* ud = j == 0 ? &pl.units[pl.dsu[li]] : nullptr;
+                double* ds3 = reinterpret_cast<double*>(W + pl.dstat) + pl.stat_bwd_first + u3.sb;
+                if (LIVE && (rc = bn_fold_unit(c, u3, Ga, reinterpret_cast<const unsigned char*>(W + u3.mk), nullptr, W + pl.wsA, &f3))) return rc;   // Ga: dOut -> g
+                if (LIVE && ud && (rc = bn_fold_unit(c, *ud, Ga, nullptr, ds3, W + pl.wsB, &fd))) return rc;
+                if (LIVE && (rc = bn_fold_dgrad(c, u3, f3, Ga, Gb, Gd))) return rc;             // d(t2) -> Gd
+                if (LIVE && (rc = unit_backward(c, u2, Gd, W + u2.y, Gc, nullptr))) return rc;  // dz2 -> staging slot 0 (bf16 step: Gc is not written)
+                if (LIVE && (rc = unit_dgrad(c, u2, Gc, nullptr, Gb))) return rc;               // d(t1) -> Gb
+                if (LIVE && (rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> staging slot 0
+                if (ud) {
+                    if (LIVE && (rc = bn_fold_dgrad(c, *ud, fd, Ga, Gb, Gd))) return rc;        // downsample path -> Gd   (layer1: no height-compression add)
+                    HN_REQUIRE(li == 0, "train_backward: the folded downsample adjoint is layer1's");
+                    if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gd, Gc))) return rc;                // + conv1 path -> Gc
+                } else {
+                    if (LIVE && (rc = unit_dgrad(c, u1, Gd, Ga, Gc))) return rc;                // conv1 path + identity (g) -> Gc
+                }
+                float* t = Ga; Ga = Gc; Gc = t;
+                continue;
+            }
             const bool dual = j == 0 && bn_dual_ok(c, u3, pl.units[pl.dsu[li]]);
             if (LIVE && dual) {      // block 0: bn3 and the downsample BatchNorm in one reduce + one apply pass (slots 0 and 1)
                 if ((rc = bn_backward_dual(c, u3, pl.units[pl.dsu[li]], Ga, 0, 1))) return rc;

@@ -855,3 +855,53 @@ def test_dual_batchnorm_adjoint_equals_two_adjoints():
     print("[parity] dual BatchNorm adjoint: worst relative L2 difference %.2e (%s; run-to-run noise there %.2e)" % (diff[worst], worst, noise[worst]))
     for k in names:
         assert diff[k] <= max(4.0 * noise[k], 2e-5), (k, diff[k], noise[k])
+
+
+@pytest.mark.gpu
+def test_bn_folded_adjoint_equals_classical_adjoint():
+    """bn_fold.hip (the conv3 / stride-1 downsample units of the bf16 step: BatchNorm adjoint folded algebraically into the weight-
+    gradient GEMM and two 1x1 data-gradient convs -- no reduce pass, no apply pass, no dz tensor) against the classical two-pass adjoint
+    (engine option "fuse_bn_fold" = 0): two backward passes over ONE bf16 training forward.  The two forms round at different places
+    (the classical one rounds z and dz to bf16 per element, the folded one rounds c1 * W and Q), so equality is checked where both see
+    IDENTICAL inputs -- the first folded unit of the backward order, layer4.2.conv3 + bn3 (its incoming gradient comes from the
+    height-compression branch, which the fold does not touch) and the unit that consumes its data gradient (layer4.2.conv2 / bn2) --
+    at the level of bf16's own rounding; tensors behind the fold in the backward order (height compression, LSTM, head) must
+    agree to the run-to-run noise; everything downstream is bounded loosely (a batch of 2 through 50 batch-statistics BatchNorms
+    amplifies any rounding difference: the classical form differs from the float32 step by O(1) there)."""
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(71, "random"))
+    net = net.to(DEV).train()
+    net.train_precision = "bf16"
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(72)).to(DEV)
+    bon, cor = net(x)
+    loss = bon.abs().sum() + cor.sum()
+    params = dict(net.named_parameters())
+    names = list(params.keys())
+    got = {}
+    for mode in (0, 1, 0):
+        net.set_engine_option("fuse_bn_fold", mode)
+        for p in net.parameters():
+            p.grad = None
+        loss.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        got.setdefault(mode, []).append({k: params[k].grad.detach().double().clone() for k in names})
+    assert net.hip_status(DEV) == 0
+    enc = "feature_extractor.encoder."
+    rel = lambda a, b: float((a - b).norm() / max(float(b.norm()), 1e-30))
+    noise = {k: rel(got[0][1][k], got[0][0][k]) for k in names}
+    diff = {k: rel(got[1][0][k], got[0][0][k]) for k in names}
+    behind = [k for k in names if not k.startswith(enc)]
+    for k in behind:
+        assert diff[k] <= max(4.0 * noise[k], 2e-5), (k, diff[k], noise[k])
+    first = [enc + "layer4.2." + t for t in ("conv3.weight", "bn3.weight", "bn3.bias", "conv2.1.weight", "bn2.weight", "bn2.bias")]
+    print("[parity] folded BatchNorm adjoint vs classical: first folded unit " + ", ".join("%s %.1e" % (k.split("layer4.2.")[1], diff[k]) for k in first) +
+          "; all encoder tensors: median %.1e, max %.1e (%s)" % (sorted(diff[k] for k in names if k.startswith(enc))[len([k for k in names if k.startswith(enc)]) // 2],
+                                                                 max(diff[k] for k in names if k.startswith(enc)), max((k for k in names if k.startswith(enc)), key=lambda k: diff[k])))
+    for k in first[:3]:
+        assert diff[k] <= 4e-3, (k, diff[k])
+    for k in first[3:]:
+        assert diff[k] <= 8e-3, (k, diff[k])
+    encd = sorted(diff[k] for k in names if k.startswith(enc))
+    assert encd[len(encd) // 2] <= 0.03 and encd[-1] <= 0.3, (encd[len(encd) // 2], encd[-1])
