@@ -82,8 +82,54 @@ __global__ __launch_bounds__(256) void bn_fold_coef_kernel(FoldArgs p)
     }
     for (int k = lane; k < p.K; k += 64) {
         const float w = bf2f(p.Wh[(size_t)n * p.K + k]);
-        p.Wf[(size_t)n * p.K + k] = w;
+        p.Wf[(size_t)n * p.K + k] = w;          // (already there when the forward was folded too: same bits)
         p.eW[(size_t)n * p.K + k] = (float)(e * (double)w);
+    }
+}
+
+// ---- forward: the batch statistics of z = a W^T from G and A (no pass over z; z itself is never stored) ----
+__global__ __launch_bounds__(256) void bn_fold_widen_kernel(const u16* __restrict__ wh, float* __restrict__ wf, long n)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) wf[i] = bf2f(wh[i]);
+}
+
+// one wave per channel n: mean = W[n][:] A / M,  E[z^2] = W[n][:] G W[n][:]^T / M = (W G)[n][:] W[n][:]^T / M  ->  the affine, the saved
+// mean / invstd and the running-statistics update exactly as affine_act_bn_kernel derives them from its sums (train_ops.hip)
+__global__ __launch_bounds__(256) void bn_fold_stats_kernel(const float* __restrict__ Wf, const float* __restrict__ WG, const double* __restrict__ A,
+                                                            double M, int N, int K, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* running_mean, float* running_var, float momentum, float* a_out, float* b_out,
+                                                            float* save_mean, float* save_invstd)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double w = (double)Wf[(size_t)n * K + k];
+        s1 += w * A[k];
+        s2 += w * (double)WG[(size_t)n * K + k];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) {
+        const double m = s1 / M;
+        double var = s2 / M - m * m;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float aa = gamma[n] * invstd;
+        const float bb = beta[n] - (float)m * aa;
+        a_out[n] = aa;
+        b_out[n] = bb;
+        save_mean[n] = (float)m;
+        save_invstd[n] = invstd;
+        if (running_mean) {
+            const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+            running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)m;
+            running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+        }
     }
 }
 
@@ -124,52 +170,90 @@ __global__ __launch_bounds__(256) void bn_fold_finish_kernel(FoldArgs p)
 
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
+// W G on the float32 matrix cores: WG[n][k] = sum_kk Wf[n][kk] G[k][kk]   (G is symmetric: its rows are the GEMM's packed weights [K][K])
+int gemm_wg(const float* Wf, const float* G, float* WG, int N, int K, const float* ones, const float* zeros, hipStream_t s)
+{
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = Wf; d.w = G; d.scale = ones; d.shift = zeros; d.res = nullptr; d.y = WG;
+    d.B = 1; d.Hi = 1; d.Wi = N; d.Cin = K; d.Cout = K; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1; d.Ho = 1; d.Wo = N; d.relu = 0; d.ldy = K;
+    return hn_launch_conv(d, s);
+}
+
 }  // namespace
 
-// Scratch of the whole folded adjoint of one unit behind `ws` (bytes): [G | Qf] floats + A doubles (the caller zeroes this head: the first
-// hn_bn_fold_zero_bytes) + Wf, eW, WG floats + coef doubles + WA, WB bf16 + shiftA floats.
-size_t hn_bn_fold_zero_bytes(int K) { return al256((2 * (size_t)K * K) * sizeof(float) + (size_t)K * sizeof(double)); }
+// Per-unit storage kept from the forward to the backward (floats): G [K][K] | A [K] doubles | Wf [N][K] | WG [N][K]
+size_t hn_bn_fold_keep_floats(int N, int K) { return (size_t)K * K + 2 * (size_t)K + 2 * (size_t)N * K; }
+static float* keep_G(float* keep, int K) { (void)K; return keep; }
+static double* keep_A(float* keep, int K) { return reinterpret_cast<double*>(keep + (size_t)K * K); }
+static float* keep_Wf(float* keep, int N, int K) { (void)N; return keep + (size_t)K * K + 2 * (size_t)K; }
+static float* keep_WG(float* keep, int N, int K) { return keep + (size_t)K * K + 2 * (size_t)K + (size_t)N * K; }
+
+// Backward scratch of one unit behind `ws` (bytes): Qf floats (the caller zeroes this head: hn_bn_fold_zero_bytes) + eW floats + coef doubles +
+// WA, WB bf16 + shiftA floats.
+size_t hn_bn_fold_zero_bytes(int K) { return al256((size_t)K * K * sizeof(float)); }
 size_t hn_bn_fold_scratch_bytes(int N, int K)
 {
-    return hn_bn_fold_zero_bytes(K) + 3 * al256((size_t)N * K * sizeof(float)) + al256(4 * (size_t)N * sizeof(double)) + al256((size_t)K * N * 2) +
+    return hn_bn_fold_zero_bytes(K) + al256((size_t)N * K * sizeof(float)) + al256(4 * (size_t)N * sizeof(double)) + al256((size_t)K * N * 2) +
            al256((size_t)K * K * 2) + al256((size_t)K * sizeof(float));
 }
-float* hn_bn_fold_gram(void* ws, int K) { (void)K; return reinterpret_cast<float*>(ws); }
-double* hn_bn_fold_colsum(void* ws, int K) { return reinterpret_cast<double*>(reinterpret_cast<float*>(ws) + 2 * (size_t)K * K); }
 
-// P (in place -> dW), and in ws G / A as left by hn_launch_conv_wgrad_bf16_fold (zeroed head!); w_h: the unit's packed bf16 forward
-// weights [N][K].  Outputs: S2 / S1_out (the BatchNorm weight / bias gradient sums), dW over P, and in ws the two data-gradient weight
-// matrices + shift (pointers returned through wa / shift_a / wb).  ones / zeros: >= K floats of 1.0 / 0.0.
-int hn_launch_bn_fold_finish(float* P, const double* S1_in, double* S1_out, double* S2, const void* w_h, const float* mean, const float* invstd,
-                             const float* gamma, double M, int N, int K, void* ws, const float* ones, const float* zeros, const void** wa,
-                             const float** shift_a, const void** wb, hipStream_t s)
+// G = a^T a and A = column sums of the activation a [M][K] (bf16) into the unit's keep storage.  slab (slab_floats of scratch): the run-to-run
+// reproducible form (partial tiles per row range, added in order in double precision) -- the training FORWARD's batch statistics come from
+// G and A, and float atomics in arrival order would make every forward differ in the last bits of every BatchNorm; null: atomics (adjoint-only use).
+int hn_launch_bn_fold_gram(const void* a_h, long M, int K, float* keep, hipStream_t s, float* slab, size_t slab_floats)
+{
+    if (!slab) HN_HIP(hipMemsetAsync(keep, 0, ((size_t)K * K + 2 * (size_t)K) * sizeof(float), s));
+    return hn_launch_conv_wgrad_bf16_fold(a_h, const_cast<void*>(a_h), keep_G(keep, K), M, K, K, nullptr, keep_A(keep, K), s, 1, slab, slab_floats);
+}
+
+// Forward of a folded unit, between hn_launch_bn_fold_gram and the fused conv: Wf, WG into `keep`, then the BatchNorm affine (a_out / b_out =
+// the fused conv's scale / shift), the saved mean / invstd and the running-statistics update.
+int hn_launch_bn_fold_forward_stats(float* keep, const void* w_h, double M, int N, int K, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float* a_out, float* b_out, float* save_mean, float* save_invstd,
+                                    const float* ones, const float* zeros, hipStream_t s)
+{
+    HN_REQUIRE(N % 64 == 0 && K % 64 == 0 && N > 0 && K > 0, "bn fold stats: N=%d K=%d", N, K);
+    float* Wf = keep_Wf(keep, N, K);
+    float* WG = keep_WG(keep, N, K);
+    const long nk = (long)N * K;
+    long g = (nk + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(bn_fold_widen_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const u16*>(w_h), Wf, nk);
+    HN_LAUNCH_CHECK();
+    if (int rc = gemm_wg(Wf, keep_G(keep, K), WG, N, K, ones, zeros, s)) return rc;
+    hipLaunchKernelGGL(bn_fold_stats_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Wf, WG, keep_A(keep, K), M, N, K, gamma, beta, running_mean,
+                       running_var, momentum, a_out, b_out, save_mean, save_invstd);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
+// P (in place -> dW); keep: G / A as left by hn_launch_bn_fold_gram (+ Wf / WG when wg_ready: the forward was folded); ws: scratch with a
+// zeroed head; w_h: the unit's packed bf16 forward weights [N][K].  Outputs: S2 / S1_out (the BatchNorm weight / bias gradient sums), dW over
+// P, and in ws the two data-gradient weight matrices + shift (returned through wa / shift_a / wb).  ones / zeros: >= K floats of 1.0 / 0.0.
+int hn_launch_bn_fold_finish(float* P, float* keep, int wg_ready, const double* S1_in, double* S1_out, double* S2, const void* w_h, const float* mean,
+                             const float* invstd, const float* gamma, double M, int N, int K, void* ws, const float* ones, const float* zeros,
+                             const void** wa, const float** shift_a, const void** wb, hipStream_t s)
 {
     HN_REQUIRE(N % 64 == 0 && K % 64 == 0 && N > 0 && K > 0 && K <= 4096, "bn fold: N=%d K=%d", N, K);
     FoldArgs p;
     char* q = reinterpret_cast<char*>(ws);
-    float* G = reinterpret_cast<float*>(q);
-    float* Qf = G + (size_t)K * K;
-    p.A = reinterpret_cast<const double*>(Qf + (size_t)K * K);
-    q += hn_bn_fold_zero_bytes(K);
-    p.Wf = reinterpret_cast<float*>(q); q += al256((size_t)N * K * sizeof(float));
+    float* Qf = reinterpret_cast<float*>(q); q += hn_bn_fold_zero_bytes(K);
     p.eW = reinterpret_cast<float*>(q); q += al256((size_t)N * K * sizeof(float));
-    float* WG = reinterpret_cast<float*>(q); q += al256((size_t)N * K * sizeof(float));
     p.coef = reinterpret_cast<double*>(q); q += al256(4 * (size_t)N * sizeof(double));
     p.WA = reinterpret_cast<u16*>(q); q += al256((size_t)K * N * 2);
     p.WB = reinterpret_cast<u16*>(q); q += al256((size_t)K * K * 2);
     p.shiftA = reinterpret_cast<float*>(q);
+    p.A = keep_A(keep, K);
+    p.Wf = keep_Wf(keep, N, K);
+    float* WG = keep_WG(keep, N, K);
     p.P = P; p.S1_in = S1_in; p.S1_out = S1_out; p.S2 = S2; p.Wh = reinterpret_cast<const u16*>(w_h);
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.M = M; p.N = N; p.K = K; p.WG = WG; p.Qf = Qf;
     *wa = p.WA; *shift_a = p.shiftA; *wb = p.WB;
     hipLaunchKernelGGL(bn_fold_coef_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, p);
     HN_LAUNCH_CHECK();
-    {   // WG[n][k] = sum_kk Wf[n][kk] G[k][kk]   (G is symmetric: its rows are the GEMM's packed weights [K][K])
-        ConvDesc d;
-        memset(&d, 0, sizeof(d));
-        d.x = p.Wf; d.w = G; d.scale = ones; d.shift = zeros; d.res = nullptr; d.y = WG;
-        d.B = 1; d.Hi = 1; d.Wi = N; d.Cin = K; d.Cout = K; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1; d.Ho = 1; d.Wo = N; d.relu = 0; d.ldy = K;
-        if (int rc = hn_launch_conv(d, s)) return rc;
-    }
+    if (!wg_ready)
+        if (int rc = gemm_wg(p.Wf, keep_G(keep, K), WG, N, K, ones, zeros, s)) return rc;
     // Q[k][j] = sum_n eW[n][k] Wf[n][j]   (the float32 weight-gradient GEMM with the channel index n as its reduction index)
     if (int rc = hn_launch_conv_wgrad(p.Wf, p.eW, Qf, 1, 1, N, K, K, 1, 1, 1, 1, 0, 0, 0, s, /*prezeroed=*/1)) return rc;
     const long nk = (long)N * K;

@@ -30,6 +30,7 @@ struct ConvArgsH {
     int sh_log2, sw_log2;
     int ca, cb, cHo, cWo;
     int tdh[3], tdw[3], ntdh, ntdw;
+    unsigned char* mask_out;   // optional (4-wave kernel, bf16 output, ReLU): the ReLU bit mask of the stored rows, 4 bits per byte (element e -> byte e >> 2)
 #ifdef HN_CONV_TRACE
     unsigned long long* trace = nullptr;   // throw-away measurement builds only (tools/conv_trace.py): 8 stamps per workgroup / tile
 #endif

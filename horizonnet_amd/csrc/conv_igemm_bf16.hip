@@ -330,6 +330,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                         o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                         o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
                         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + out_pix(m) * p.ldy + n0 + ccol) = o;
+                        if (p.mask_out) {        // (wave-uniform) the training forward's fused BatchNorm + ReLU: the adjoint's bit mask, v > 0 as affine_act_kernel has it
+                            unsigned mk = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) mk |= (v0[k] > 0.f ? 1u : 0u) << k | (v1[k] > 0.f ? 1u : 0u) << (8 + k);
+                            *reinterpret_cast<unsigned short*>(p.mask_out + ((out_pix(m) * p.ldy + n0 + ccol) >> 2)) = (unsigned short)mk;
+                        }
                     }
                 }
             }
@@ -1551,6 +1557,8 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.ksplit = 1;
     a.sh_log2 = a.sw_log2 = a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
     for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;
+    a.mask_out = d.mask_out;
+    HN_REQUIRE(!d.mask_out || (!out_f32 && d.relu && !d.stem && !d.stat_sum && d.Cout % 8 == 0), "conv bf16: mask_out goes with a bf16 ReLU output");
 #ifdef HN_CONV_TRACE
     a.trace = g_conv_trace;
 #endif
@@ -1622,7 +1630,7 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
             return 0;
         }
     }
-    {
+    if (!d.mask_out) {       // (the mask store lives in the 4-wave kernel's epilogue only)
         bool taken = false;
         const int rc = out_f32 ? dispatch_w8<true>(a, d.Cout, s, &taken) : dispatch_w8<false>(a, d.Cout, s, &taken);
         if (taken) return rc;

@@ -47,6 +47,11 @@ struct WgradArgsH {
     const unsigned char* bmask;
     u16* dz_wb;
     double* colsum_dz;
+    // ... and, for a run-to-run reproducible result (the Gram matrix behind the training FORWARD's batch statistics), `slab` != null: every
+    // workgroup stores its partial tile to slab[sp][Cout][K] and its partial column sums to slab_cs[sp][Cout] (plain stores, no atomics);
+    // wgrad_slab_reduce_kernel adds the m splits in index order in double precision.
+    float* slab;
+    float* slab_cs;
 };
 
 __device__ __forceinline__ u32x4 hbuf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff)
@@ -293,7 +298,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
         if (tid < TN) {
             float t = 0.f;
             for (int r = 0; r < N_RPP; ++r) t += red[r * TN + tid];
-            atomicAdd(p.colsum_dz + n0 + tid, (double)t);
+            if (p.slab_cs) p.slab_cs[(size_t)sp * p.Cout + n0 + tid] = t;
+            else atomicAdd(p.colsum_dz + n0 + tid, (double)t);
         }
     }
 
@@ -307,8 +313,45 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wi_ * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int k = k0 + wj_ * WK + j * 32 + fr;
-                __hip_atomic_fetch_add(p.dw + (size_t)n * p.K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (FOLD && p.slab) p.slab[((size_t)sp * p.Cout + n) * p.K + k] = acc[i][j][r];
+                else __hip_atomic_fetch_add(p.dw + (size_t)n * p.K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+}
+
+// out[i] = sum_sp slab[sp][i] (float) and cs_out[c] = sum_sp slab_cs[sp][c] (double), in double precision and in a FIXED order: a workgroup
+// owns 16 elements, its 16 split lanes add splits l, l + 16, ... (eight loads in flight each), the lanes are combined 0..15 through LDS.
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n, int splits,
+                                                                const float* __restrict__ slab_cs, double* __restrict__ cs_out, int C)
+{
+    __shared__ double red[256];
+    const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long nb = (n + 15) / 16;                       // element groups of the tiles; the column sums follow as further groups
+    const long cb = cs_out ? (C + 15) / 16 : 0;
+    for (long b = blockIdx.x; b < nb + cb; b += gridDim.x) {
+        const bool cs = b >= nb;
+        const long i = (cs ? b - nb : b) * 16 + il;
+        const long lim = cs ? C : n;
+        const float* src = cs ? slab_cs : slab;
+        double t = 0.0;
+        if (i < lim) {
+            int sp = sl;
+            for (; sp + 7 * 16 < splits; sp += 8 * 16) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(sp + 16 * q) * lim + i];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += (double)v[q];
+            }
+            for (; sp < splits; sp += 16) t += (double)src[(size_t)sp * lim + i];
+        }
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (sl == 0 && i < lim) {
+            for (int q = 1; q < 16; ++q) t += red[q * 16 + il];
+            if (cs) cs_out[i] = t; else out[i] = (float)t;
+        }
+        __syncthreads();
+    }
 }
 
 template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false>
@@ -333,8 +376,22 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
             attr_done[dev] = true;
         }
     }
+    if (FOLD && a.slab) {
+        // slab[split][Cout][K] + slab_cs[split][Cout] must fit the caller's scratch (slab_cs = the float count handed in through its pointer difference)
+        const size_t need = (size_t)split * a.Cout * a.K + (size_t)split * a.Cout;
+        HN_REQUIRE(need <= (size_t)(a.slab_cs - a.slab), "wgrad bf16 fold: %zu floats of reduction scratch needed, %zu given", need, (size_t)(a.slab_cs - a.slab));
+        a.slab_cs = a.slab + (size_t)split * a.Cout * a.K;
+        // a workgroup whose m range is empty returns without storing: the ranges are [sp * mchunk, ..) with split = ceil(M / mchunk), none is empty
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(NT * KT * split)), dim3(NW * 64), lds, s, a);
     HN_LAUNCH_CHECK();
+    if (FOLD && a.slab) {
+        const long n = (long)a.Cout * a.K;
+        long g = (n + 15) / 16 + (a.Cout + 15) / 16;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a.slab, a.dw, n, (int)split, a.slab_cs, a.colsum_dz, a.Cout);
+        HN_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -373,7 +430,7 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     a.mchunk = 0;
     a.xstride = xstride ? xstride : Cin;
     a.dzstride = dzstride ? dzstride : Cout;
-    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr;
+    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr; a.slab = nullptr; a.slab_cs = nullptr;
     HN_REQUIRE(a.xstride >= Cin && a.dzstride >= Cout && a.xstride % 8 == 0 && a.dzstride % 8 == 0, "wgrad bf16: bad strides");
     HN_REQUIRE((double)B * Hi * Wi * a.xstride * 2.0 < 2147483648.0 && (double)a.M * a.dzstride * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
@@ -410,7 +467,7 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
 // rows leave as g), p_out [Cout][Cin] floats (accumulated; zeroed here unless prezeroed), colsum [Cout] doubles (accumulated: sum_m g[m][n]).
 // bmask == null: plain operands (the Gram matrix a^T a of an activation with its column sums: a_h == dy_h, Cin == Cout).
 int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
-                                   double* colsum, hipStream_t s, int prezeroed)
+                                   double* colsum, hipStream_t s, int prezeroed, float* slab, size_t slab_floats)
 {
     HN_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad bf16 fold: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
     HN_REQUIRE(M > 0 && (double)M * Cin * 2.0 < 2147483648.0 && (double)M * Cout * 2.0 < 4294967296.0, "wgrad bf16 fold: batch too large for 32-bit tile offsets");
@@ -423,6 +480,10 @@ int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, lo
     a.mchunk = 0;
     a.xstride = Cin; a.dzstride = Cout;
     a.bmask = bmask; a.dz_wb = bmask ? reinterpret_cast<u16*>(dy_h) : nullptr; a.colsum_dz = colsum;
+    // slab != null (slab_floats of scratch): the reproducible form -- partial tiles stored per m split and added in order (p_out and colsum are
+    // then OVERWRITTEN, not accumulated); the launcher places slab_cs behind the tiles
+    a.slab = slab; a.slab_cs = slab ? slab + slab_floats : nullptr;
+    HN_REQUIRE(!slab || colsum, "wgrad bf16 fold: the slab form also produces the column sums");
     {   // timing experiments only (results are wrong): 1 = no write-back, 2 = no mask loads, 4 = no column sums
         static const char* dbg = getenv("HN_FOLD_DEBUG");
         const int f = dbg ? atoi(dbg) : 0;
@@ -430,7 +491,7 @@ int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, lo
         if (f & 2) a.bmask = nullptr;
         if (f & 4) a.colsum_dz = nullptr;
     }
-    if (!prezeroed) HN_HIP(hipMemsetAsync(p_out, 0, (size_t)Cout * Cin * sizeof(float), s));
+    if (!prezeroed && !slab) HN_HIP(hipMemsetAsync(p_out, 0, (size_t)Cout * Cin * sizeof(float), s));
     // These GEMMs are HBM-bound (K <= 512 per output channel, and the masked rows are written back), so they want MANY small workgroups
     // in flight, not big tiles: the 8-wave 256-wide tile (one workgroup per CU, one chunk of loads in flight) took 300 us where the
     // bytes need 120 (layer3 at B = 64); 4-wave tiles with 32-row chunks run 4 workgroups per CU.  HN_FOLD_WCH / HN_FOLD_WGS: A/B switches.
@@ -463,7 +524,7 @@ int hn_launch_stem_wgrad_bf16(const void* x4_h, const void* dz_h, float* dw_pack
     a.K = 256;
     a.mchunk = 0;
     a.xstride = 4; a.dzstride = 64;
-    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr;
+    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr; a.slab = nullptr; a.slab_cs = nullptr;
     HN_REQUIRE((double)B * Hi * Wi * 8.0 < 2147483648.0 && (double)a.M * 128.0 < 4294967296.0, "stem wgrad bf16: batch too large for 32-bit tile offsets");
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)64 * 256 * sizeof(float), s));
     return launch_wgrad_h_w<64, 256, 32, 4, true>(a, s, 512);

@@ -87,6 +87,7 @@ struct ConvDesc {
                          // memory side (0.06-0.25 ms per layer1 conv).  0 / 1: straight into [sum | sq].  The slot must be zero at launch.
     float* splitk_ws;    // optional scratch for split-K partial tiles (bf16 forward; see hn_launch_conv_bf16)
     size_t splitk_ws_floats;
+    unsigned char* mask_out;   // bf16 convs only: also store the ReLU bit mask of the output (affine_act_kernel's format); forces the 4-wave kernel
     int transposed;      // 1 = data-gradient mode: x = dY [B][Hi][Wi][Cin(=Cout of the fwd conv)], y = dX [B][Ho][Wo][Cout(=Cin fwd)],
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
 };
@@ -170,14 +171,17 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
                               int sh, int sw, hipStream_t s, int prezeroed = 0, int xstride = 0, int dzstride = 0);
 // BatchNorm-folded adjoint of the 1x1 convs (bn_fold.hip, conv_wgrad_bf16.hip)
 int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
-                                   double* colsum, hipStream_t s, int prezeroed);
-size_t hn_bn_fold_scratch_bytes(int N, int K);
+                                   double* colsum, hipStream_t s, int prezeroed, float* slab = nullptr, size_t slab_floats = 0);
+size_t hn_bn_fold_scratch_bytes(int N, int K);      // backward scratch of one unit (its head of hn_bn_fold_zero_bytes must be zeroed)
 size_t hn_bn_fold_zero_bytes(int K);
-float* hn_bn_fold_gram(void* ws, int K);
-double* hn_bn_fold_colsum(void* ws, int K);
-int hn_launch_bn_fold_finish(float* P, const double* S1_in, double* S1_out, double* S2, const void* w_h, const float* mean, const float* invstd,
-                             const float* gamma, double M, int N, int K, void* ws, const float* ones, const float* zeros, const void** wa,
-                             const float** shift_a, const void** wb, hipStream_t s);
+size_t hn_bn_fold_keep_floats(int N, int K);         // per-unit storage kept from the forward to the backward: G | A | Wf | WG
+int hn_launch_bn_fold_gram(const void* a_h, long M, int K, float* keep, hipStream_t s, float* slab = nullptr, size_t slab_floats = 0);
+int hn_launch_bn_fold_forward_stats(float* keep, const void* w_h, double M, int N, int K, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float* a_out, float* b_out, float* save_mean, float* save_invstd,
+                                    const float* ones, const float* zeros, hipStream_t s);
+int hn_launch_bn_fold_finish(float* P, float* keep, int wg_ready, const double* S1_in, double* S1_out, double* S2, const void* w_h, const float* mean,
+                             const float* invstd, const float* gamma, double M, int N, int K, void* ws, const float* ones, const float* zeros,
+                             const void** wa, const float** shift_a, const void** wb, hipStream_t s);
 int hn_launch_conv_dgrad_bf16(const ConvDesc& fwd, const void* dz_h, const float* w_oihw, const float* add, float* dx, void* w_scratch,
                               const float* ones, const float* zeros, hipStream_t s, int grad_bf16 = 0);
 int hn_launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);

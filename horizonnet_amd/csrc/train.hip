@@ -24,6 +24,7 @@ struct Unit {
     int keep_y32;                  // bf16 mode: 1 = a float32 consumer of y exists (max-pool, up-sampling, an f32 weight-gradient fallback)
     size_t sf, sb;                 // this unit's slots in the statistics arena (doubles): forward [sum | sumsq], backward [S1 | S2 | dbias]
     size_t wg;                     // float offset of this unit's packed weight-gradient scratch (un-packed in one batch per segment)
+    size_t fold;                   // float offset of the unit's BatchNorm-fold storage (bn_fold.hip: G | A | Wf | WG), 0 = the unit is never folded
     long M;
 };
 
@@ -68,6 +69,7 @@ TrainPlan make_train_plan(int B)
         u.yh = take((size_t)u.M * c.cout / 2);
         u.sf = stat_f; stat_f += hn_stat_slot_doubles(c.cout, u.M);     // [sum | sq][C] (+ replicas), see ConvDesc::stat_rep
         u.sb = stat_b; stat_b += 3 * (size_t)c.cout;
+        u.fold = 0;
         p.units.push_back(u);
         return (int)p.units.size() - 1;
     };
@@ -87,6 +89,9 @@ TrainPlan make_train_plan(int B)
             H /= stride;
             W /= stride;
             const int c3 = add_unit(a.block_first[li][j] + 2, p.units[c2].y, p.units[c2].yh, H, W, 1, 1, 0, 0);
+            // conv3 of every block and a stride-1 downsample conv (layer1) may run through the BatchNorm-folded form (bn_fold.hip)
+            for (int fu : {c3, (j == 0 && stride == 1) ? p.dsu[li] : -1})
+                if (fu >= 0) p.units[fu].fold = take(hn_bn_fold_keep_floats(a.convs[p.units[fu].ci].cout, a.convs[p.units[fu].ci].cin));
             p.blk[li][j] = c1;                    // c2 = c1 + 1; (ds = c1 + 2 when j == 0); c3 = last
             cur = p.units[c3].y;
             curh = p.units[c3].yh;
@@ -211,6 +216,42 @@ int bn_forward(const Ctx& c, const Unit& u, const float* res, int relu, float mo
                                        c.bound(cl.bnkey + ".running_var"), st + 2 * C, st + 3 * C, st, st + C, C, c.s)))
         return rc;
     return hn_launch_affine_act(c.W + u.z, st + 2 * C, st + 3 * C, res, y32, mk, yh, u.M, C, relu, c.e->train_bf16, res_bf16, c.s);
+}
+
+// ---- BatchNorm-folded form of a 1x1 / stride-1 conv unit (bn_fold.hip) ----
+// Eligible: bf16 step with bf16 gradients, batch statistics, no debug tap anywhere (the taps read z / dz, which this form never stores).
+bool bn_fold_ok(const Ctx& c, const Unit& u)
+{
+    static const char* env = getenv("HN_BN_FOLD");            // "0": the classical passes everywhere (A/B runs); "b": folded adjoint only
+    const ConvLayer& cl = c.a.convs[u.ci];
+    return u.fold != 0 && c.e->train_bf16 && c.gh() && c.e->fuse_bn_fold && !(env && env[0] == '0') && c.e->debug_unit < 0 && c.e->debug_unit2 < 0 &&
+           !c.bn_eval(u) && cl.k == 1 && u.sh == 1 && u.sw == 1 && !cl.has_bias && !u.stem && !u.keep_y32 && cl.cin % 64 == 0 && cl.cout % 64 == 0 &&
+           (double)u.M * cl.cout * 2.0 < 4294967296.0;
+}
+
+// Forward: y = act(bn(conv(x)) (+ res)) WITHOUT storing z: batch statistics from the Gram matrix of the input (G, A kept for the adjoint),
+// then the conv with BatchNorm, residual, ReLU and the ReLU bit mask in its epilogue.  Instead of conv (writes z) + affine pass (reads z,
+// res; writes y): the unit's input is read twice more (a quarter of y's size in the backbone), z (as large as y) is neither written nor read.
+int bn_fold_forward(const Ctx& c, const Unit& u, const float* res_h, int relu, float momentum)
+{
+    const ConvLayer& cl = c.a.convs[u.ci];
+    const int N = cl.cout, K = cl.cin;
+    float* keep = c.W + u.fold;
+    float* st = c.W + u.st;
+    const void* wh = reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci);
+    int rc;
+    // (the two packed-weight scratches of the plan are idle during the backbone's forward: one contiguous range for the Gram partials)
+    if ((rc = hn_launch_bn_fold_gram(c.W + u.xh, u.M, K, keep, c.s, c.W + c.pl.wsA, (size_t)(c.pl.wsB - c.pl.wsA) + (size_t)1024 * 18432))) return rc;
+    if ((rc = hn_launch_bn_fold_forward_stats(keep, wh, (double)u.M, N, K, c.bound(cl.bnkey + ".weight"), c.bound(cl.bnkey + ".bias"),
+                                              c.bound_mut(cl.bnkey + ".running_mean"), c.bound_mut(cl.bnkey + ".running_var"), momentum, st + 2 * N,
+                                              st + 3 * N, st, st + N, c.P + c.a.ones_off, c.P + c.a.zeros_off, c.s)))
+        return rc;
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = c.W + u.xh; d.w = reinterpret_cast<const float*>(wh); d.scale = st + 2 * N; d.shift = st + 3 * N; d.res = res_h; d.y = c.W + u.yh;
+    d.B = c.B; d.Hi = u.Hi; d.Wi = u.Wi; d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1; d.Ho = u.Ho; d.Wo = u.Wo; d.relu = relu; d.ldy = N;
+    d.mask_out = relu ? reinterpret_cast<unsigned char*>(c.W + u.mk) : nullptr;
+    return hn_launch_conv_bf16(d, 0, c.s);
 }
 
 // BN + conv-weight adjoint of one unit.  dy: gradient w.r.t. the tensor the mask refers to (ymask = post-ReLU
@@ -364,14 +405,11 @@ int bn_backward_dual(const Ctx& c, const Unit& ua, const Unit& ub, const float* 
 }
 
 // ---- BatchNorm-folded adjoint of a 1x1 / stride-1 conv unit (bn_fold.hip): no reduce pass, no apply pass, no dz tensor ----
-// Eligible: bf16 step with bf16 gradients, batch statistics, the deferred-job backward, no debug tap anywhere (the taps read dz).
-bool bn_fold_ok(const Ctx& c, const Unit& u)
+// did hn_train_forward run this unit through bn_fold_forward (z was never stored: the adjoint MUST be the folded one)?
+bool fwd_folded(const Ctx& c, const Unit& u)
 {
-    static const char* env = getenv("HN_BN_FOLD");            // "0": the classical two-pass adjoint everywhere (A/B runs)
-    const ConvLayer& cl = c.a.convs[u.ci];
-    return c.e->train_bf16 && c.gh() && c.e->fuse_bn_fold && !(env && env[0] == '0') && c.jobs != nullptr && c.e->debug_unit < 0 &&
-           c.e->debug_unit2 < 0 && !c.bn_eval(u) && cl.k == 1 && u.sh == 1 && u.sw == 1 && !cl.has_bias && !u.stem && cl.cin % 64 == 0 &&
-           cl.cout % 64 == 0 && (double)u.M * cl.cout * 2.0 < 4294967296.0;
+    const size_t i = (size_t)(&u - c.pl.units.data());
+    return i < c.e->fold_fwd.size() && c.e->fold_fwd[i] != 0;
 }
 
 struct FoldOut {
@@ -390,18 +428,17 @@ int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* 
     const int N = cl.cout, K = cl.cin;
     double* ds = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + u.sb;      // [S1 | S2 | -], zeroed at the start of the pass
     const float* st = c.W + u.st;
-    float* G = hn_bn_fold_gram(ws, K);
-    double* A = hn_bn_fold_colsum(ws, K);
-    HN_REQUIRE(hn_bn_fold_scratch_bytes(N, K) <= ((size_t)1024 * 18432 + 64) * sizeof(float), "bn_fold_unit: scratch too small");
+    float* keep = c.W + u.fold;
+    HN_REQUIRE(c.jobs != nullptr && hn_bn_fold_scratch_bytes(N, K) <= ((size_t)1024 * 18432 + 64) * sizeof(float), "bn_fold_unit: scratch too small");
     int rc;
-    HN_HIP(hipMemsetAsync(ws, 0, hn_bn_fold_zero_bytes(K), c.s));      // G, Q and A
-    // Gram matrix + column sums of the unit's input activation
-    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, const_cast<float*>(c.W + u.xh), G, u.M, K, K, nullptr, A, c.s, 1))) return rc;
+    const int fwd = fwd_folded(c, u);            // the forward of this step was folded too: G, A, Wf, WG are in the unit's keep storage
+    HN_HIP(hipMemsetAsync(ws, 0, hn_bn_fold_zero_bytes(K), c.s));      // Q
+    if (!fwd && (rc = hn_launch_bn_fold_gram(c.W + u.xh, u.M, K, keep, c.s))) return rc;
     // P = g^T a into the unit's weight-gradient scratch (zeroed with all the others at the start of the pass)
     float* P = c.W + u.wg;
     if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, g_io, P, u.M, K, N, bmask, s1_src ? nullptr : ds, c.s, 1))) return rc;
     const void* wh = reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci);
-    if ((rc = hn_launch_bn_fold_finish(P, s1_src ? s1_src : ds, ds, ds + N, wh, st, st + N, c.bound(cl.bnkey + ".weight"), (double)u.M, N, K, ws,
+    if ((rc = hn_launch_bn_fold_finish(P, keep, fwd, s1_src ? s1_src : ds, ds, ds + N, wh, st, st + N, c.bound(cl.bnkey + ".weight"), (double)u.M, N, K, ws,
                                        c.P + c.a.ones_off, c.P + c.a.zeros_off, &out->wa, &out->shift_a, &out->wb, c.s)))
         return rc;
     c.jobs->push_back(mj_make(MJ_D2F, ds + N, c.grad(cl.bnkey + ".weight"), N));
@@ -619,6 +656,9 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
         }
     }
     // backbone + height compression
+    static const char* fold_env = getenv("HN_BN_FOLD");
+    const bool fold_fwd_on = !(fold_env && fold_env[0] == 'b') && e->fuse_bn_fold == 1;       // "b" / option value 2: classical forward (z stored), folded adjoint
+    e->fold_fwd.assign(pl.units.size(), 0);
     for (int li = 0; li < 4; ++li) {
         for (int j = 0; j < kBlocks[li]; ++j) {
             const int i1 = pl.blk[li][j];
@@ -629,11 +669,20 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
             if ((rc = conv_z(c, u2)) || (rc = bn_forward(c, u2, nullptr, 1, bn_momentum))) return rc;
             // identity branch of the block: float32, or (bf16 mode) the bf16 copy the previous pass wrote anyway
             const float* idt = e->train_bf16 ? W + u1.xh : W + u1.x;
+            // the folded form (bn_fold.hip) where the ADJOINT will be folded: same rule as train_backward_impl
+            const bool fold3 = fold_fwd_on && bn_fold_ok(c, u3) && (j > 0 || bn_fold_ok(c, pl.units[pl.dsu[li]]));
             if (j == 0) {
                 const Unit& ud = pl.units[pl.dsu[li]];
-                if ((rc = conv_z(c, ud)) || (rc = bn_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
+                if (fold3) {
+                    if ((rc = bn_fold_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
+                    e->fold_fwd[pl.dsu[li]] = 1;
+                } else if ((rc = conv_z(c, ud)) || (rc = bn_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
                 idt = e->train_bf16 ? W + ud.yh : W + ud.y;
             }
+            if (fold3) {
+                if ((rc = bn_fold_forward(c, u3, idt, 1, bn_momentum))) return rc;
+                e->fold_fwd[i1 + (j == 0 ? 3 : 2)] = 1;
+            } else
             if ((rc = conv_z(c, u3)) || (rc = bn_forward(c, u3, idt, 1, bn_momentum, e->train_bf16))) return rc;
         }
         for (int k = 0; k < 4; ++k) {
@@ -851,6 +900,8 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             // conv3 + bn3 + (add) + relu: mask = block output
             // BatchNorm-folded adjoint (bn_fold.hip): blocks 1.. of every stage, and block 0 where the downsample branch is stride 1 too (layer1)
             const bool fold3 = bn_fold_ok(c, u3) && (j > 0 || bn_fold_ok(c, pl.units[pl.dsu[li]]));
+            HN_REQUIRE(fold3 || !fwd_folded(c, u3), "hn_train_backward: the forward ran %s through the BatchNorm-folded form (no z stored) but the adjoint "
+                       "cannot (a debug tap or an option changed in between): set the option fuse_bn_fold = 0 BEFORE the forward", a.convs[u3.ci].wkey.c_str());
             if (fold3) {
                 FoldOut f3, fd;
                 const Unit* ud = j == 0 ? &pl.units[pl.dsu[li]] : nullptr;

@@ -452,6 +452,7 @@ def test_bf16_train_units_locally_consistent():
     net.bi_rnn.dropout = 0.0
     net.drop_out.p = 0.0
     net.train_precision = "bf16"
+    net.set_engine_option("fuse_bn_fold", 0)      # this test reads z / dz of conv3 units, which the folded form never stores (its own test: test_bn_folded_forward_unit)
     L = lib()
     names = [c[0] for c in conv_specs()]
     out8 = (ctypes.c_int64 * 8)()
@@ -875,13 +876,14 @@ def test_bn_folded_adjoint_equals_classical_adjoint():
     net.bi_rnn.dropout = 0.0
     net.drop_out.p = 0.0
     x = torch.rand(2, 3, 512, 1024, generator=torch.Generator().manual_seed(72)).to(DEV)
+    net.set_engine_option("fuse_bn_fold", 2)       # classical forward (z is stored, so both adjoints can run over it); 1 would fold the forward too
     bon, cor = net(x)
     loss = bon.abs().sum() + cor.sum()
     params = dict(net.named_parameters())
     names = list(params.keys())
     got = {}
     for mode in (0, 1, 0):
-        net.set_engine_option("fuse_bn_fold", mode)
+        net.set_engine_option("fuse_bn_fold", 2 * mode)
         for p in net.parameters():
             p.grad = None
         loss.backward(retain_graph=True)
@@ -905,3 +907,74 @@ def test_bn_folded_adjoint_equals_classical_adjoint():
         assert diff[k] <= 8e-3, (k, diff[k])
     encd = sorted(diff[k] for k in names if k.startswith(enc))
     assert encd[len(encd) // 2] <= 0.03 and encd[-1] <= 0.3, (encd[len(encd) // 2], encd[-1])
+
+
+@pytest.mark.gpu
+def test_bn_folded_forward_unit():
+    """bn_fold_forward (bf16 training forward of the conv3 units: batch statistics from the Gram matrix of the input, BatchNorm + residual
+    + ReLU + mask in the conv epilogue, z never stored) on the engine's OWN tensors: for layer3.2 and layer1.1, from the bf16 input of
+    conv3 and the bf16 block input read out of the workspace,
+      * saved mean / invstd == batch statistics of conv(bf16 input, bf16 w) in float32
+      * the stored block output == bf16(relu(bn(z) + residual)) to one bf16 ulp
+      * the stored ReLU bit mask == (block output > 0)."""
+    import ctypes
+    from oracle.weights import conv_specs
+    B = 2
+    sd = make_state_dict(11, "random")
+    x = torch.rand(B, 3, 512, 1024, generator=torch.Generator().manual_seed(12)).to(DEV)
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    net.train_precision = "bf16"
+    L = lib()
+    names = [c[0] for c in conv_specs()]
+    out8 = (ctypes.c_int64 * 8)()
+    L.hn_train_debug_unit(B, 0, out8)
+    info = []
+    for u in range(out8[7]):
+        L.hn_train_debug_unit(B, u, out8)
+        info.append(tuple(out8))
+    unit_of = lambda name: [i for i, t in enumerate(info) if names[t[0]].endswith(name)][0]      # noqa: E731
+    bon, cor = net(x)
+    torch.cuda.synchronize()
+    st = net._hip_states[0]
+    ws8 = st.train_workspace(B)
+    ws = ws8.view(torch.float32)
+    enc = "feature_extractor.encoder."
+
+    def yh(u, shape):
+        off = L.hn_train_debug_unit_yh(B, u)
+        n = int(np.prod(shape))
+        return ws8[off * 4:off * 4 + 2 * n].view(torch.bfloat16).float().cpu().view(shape)
+
+    ok = True
+    for blk, prev, hw, kc, nc in (("layer3.2", "layer3.1", (32, 64), 256, 1024), ("layer1.1", "layer1.0", (128, 256), 64, 256)):
+        u3, u2, up = unit_of(enc + blk + ".conv3"), unit_of(enc + blk + ".conv2.1"), unit_of(enc + prev + ".conv3")
+        a2 = yh(u2, (B,) + hw + (kc,))
+        res = yh(up, (B,) + hw + (nc,))
+        got = yh(u3, (B,) + hw + (nc,))
+        w = sd[enc + blk + ".conv3.weight"].bfloat16().float().view(nc, kc)
+        z = a2.view(-1, kc).double() @ w.double().t()
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        stt = ws[info[u3][6]:info[u3][6] + 2 * nc].cpu().double()
+        ok &= report("fold fwd mean   %s" % blk, stt[:nc].numpy(), mean.numpy(), 1e-4 * float(z.abs().max()))
+        ok &= report("fold fwd invstd %s" % blk, stt[nc:].numpy(), inv.numpy(), 1e-3 * float(inv.abs().max()))
+        gam, bet = sd[enc + blk + ".bn3.weight"].double(), sd[enc + blk + ".bn3.bias"].double()
+        want = torch.relu((z - mean) * inv * gam + bet + res.view(-1, nc).double()).float()
+        ok &= report("fold fwd y      %s" % blk, got.view(-1, nc).numpy(), want.numpy(), 2.0 ** -7 * float(want.abs().max()))
+        C4 = info[u3][1] * info[u3][2] // 4
+        mk_off = None
+        # the mask sits behind the unit's [mean|invstd|a|b] block (train.hip: add_unit takes st = 4 C floats, rounded up to 64, then mk)
+        mk_off = info[u3][6] + (4 * nc + 63) // 64 * 64
+        mk = ws8[mk_off * 4:mk_off * 4 + C4].cpu().numpy()
+        bits = np.stack([(mk >> k) & 1 for k in range(4)], axis=1).reshape(-1)
+        pos = (got.view(-1).numpy() > 0).astype(np.uint8)
+        # (a value that is positive in float32 but rounds to a bf16 zero cannot occur: bf16 keeps float32's exponent range)
+        mism = int((bits != pos).sum())
+        print("[parity] fold fwd mask %s: %d of %d bits differ from (stored y > 0)" % (blk, mism, bits.size))
+        ok &= mism == 0
+    assert net.hip_status(DEV) == 0
+    assert ok
