@@ -64,6 +64,28 @@ def conv_table():
     return rows
 
 
+def f32_mixed_roofline(B, peak_flops=PEAK_F32_MFMA_TFLOPS * 1e12, hbm=8e12):
+    """The same per-layer max(flops / MFMA peak, unfused bytes / HBM) sum for the float32 forward (4-byte activations and weights): the
+    layer1 1x1 convs are HBM-bound even in float32 (1.34 GB per launch at B = 32), so the pure-MFMA bound the headline divides by is a
+    little generous; printed beside it.  -> (seconds per batch, flops, bytes, seconds of the HBM-bound layers)."""
+    t = fl = by = t_hbm = 0.0
+    for _, cin, cout, k, H, W, sh, sw in conv_table():
+        Ho, Wo = H // sh, W // sw
+        f = 2.0 * Ho * Wo * cout * cin * k * k * B
+        b = (H * W * cin + Ho * Wo * cout) * 4.0 * B + cout * cin * k * k * 4.0
+        t += max(f / peak_flops, b / hbm)
+        t_hbm += b / hbm if b / hbm > f / peak_flops else 0.0
+        fl += f
+        by += b
+    rows = 256.0 * B
+    for _ in range(2):
+        f = 2.0 * rows * 1024 * 4096 + 2.0 * rows * 512 * 2048 * 2
+        t += f / peak_flops
+        fl += f
+        by += rows * (1024 + 4096) * 4 + 4096 * 1024 * 4
+    return t, fl, by, t_hbm
+
+
 def bf16_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
     """BASELINE.md section 3 / SURVEY.md 8(d): the bf16 forward's governing roofline is MIXED -- per layer
     max(flops / MFMA peak, unfused bytes / HBM bandwidth), summed (stem / layer1 / layer2 are HBM-bound in bf16).
@@ -91,13 +113,17 @@ def bf16_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
     return t, fl, by, t_hbm
 
 
-def train_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
+def train_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12, fused_minimum=False):
     """The bf16 TRAINING step's governing roofline, the forward's model extended to the passes a training step cannot avoid
     (train.py:259-281 on model.py:216-281): per conv three GEMMs -- forward, data gradient (not for the stem: the image needs none),
     weight gradient -- each max(flops / MFMA peak, bytes / HBM) with bytes = the two activation-sized operands x 2 B + the weights
     (bf16 read, float32 gradient write); per BatchNorm the passes batch statistics force: forward normalise + ReLU (read z, write a;
     + the identity branch for conv3), backward reduce (read dy, z) and apply (read dy, z, write dz) -- 7 (8) activation-sized
     transfers of 2 B, HBM-bound; max-pool, the LSTM at 3 x its forward flops, Adam at 28 B per parameter.
+    fused_minimum: the harder bound of a design that fuses every BatchNorm pass into its neighbours: per BatchNorm only
+    "read z once forward, read dy + z once backward" = 3 activation-sized transfers instead of 7 / 8 -- what normalise-on-load in the
+    consuming conv and dz-on-load in both gradient GEMMs would leave (the engine's BatchNorm-folded 1x1 units, bn_fold.hip, go below
+    even that for conv3: they never store z).
     -> (seconds per batch, flops, bytes, seconds of the HBM-bound passes)."""
     t = fl = by = t_hbm = 0.0
     for name, cin, cout, k, H, W, sh, sw in conv_table():
@@ -110,7 +136,7 @@ def train_mixed_roofline(B, peak_flops=PEAK_BF16_MFMA_TFLOPS * 1e12, hbm=8e12):
             t_hbm += b / hbm if b / hbm > f / peak_flops else 0.0
             fl += f
             by += b
-        bn = a_out * (8.0 if name.endswith("conv3") else 7.0)
+        bn = a_out * (3.0 if fused_minimum else (8.0 if name.endswith("conv3") else 7.0))
         t += bn / hbm
         t_hbm += bn / hbm
         by += bn
@@ -168,34 +194,55 @@ def cpu_baseline(seconds_budget=12.0):
 
 def pano_stretch_leg(dev, n_img=64, iters=10):
     """Second boundary (misc/panostretch.py:81-102): batched HIP gather vs the oracle on one host core.
-    Algorithmic bytes: 512*1024*3*(4+4) = 12,582,912 per image (f32 HWC read + f32 HWC write)."""
+    Algorithmic bytes: 512*1024*3*(4+4) = 12,582,912 per image (f32 HWC read + f32 HWC write).
+    Every timed iteration warps the batch with FRESH per-image factors, as dataset.py:70-82 draws them per sample, so nothing a real
+    batch pays is outside the timed region: `device_coordinates` (hn_pano_stretch -- north_star's form: lon / lat generated on the fly
+    in the kernel, nothing but 2 x 64 doubles cross the boundary) and `host_tables` (hn_pano_stretch_tables -- the bit-exact variant:
+    per-column terms from numpy, 64 x 1024 arctan2 / sin + a 1.5 MB upload per batch, all inside the timed region; wall-clock, since
+    host work is part of it).  `kernel_only_same_factors` is the round-4 figure (tables cached across iterations) for comparison."""
     from horizonnet_amd import pano_stretch_batch
     from oracle import panostretch_ref
     g = torch.Generator().manual_seed(5)
     imgs = torch.rand(n_img, 512, 1024, 3, generator=g).to(dev)
     rng = np.random.RandomState(5)
-    kx, ky = rng.uniform(0.5, 2.0, n_img), rng.uniform(0.5, 2.0, n_img)
+    draws = [(rng.uniform(0.5, 2.0, n_img), rng.uniform(0.5, 2.0, n_img)) for _ in range(iters + 1)]
     out = torch.empty_like(imgs)
-    pano_stretch_batch(imgs, kx, ky, out=out)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        pano_stretch_batch(imgs, kx, ky, out=out)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / iters
-    gbs = n_img * 12_582_912 / (ms * 1e-3) / 1e9
+    bytes_per_batch = n_img * 12_582_912
+
+    def timed(host_tables, fresh):
+        kx, ky = draws[0]
+        pano_stretch_batch(imgs, kx, ky, out=out, host_tables=host_tables)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for it in range(iters):
+            kx, ky = draws[1 + it] if fresh else draws[0]
+            pano_stretch_batch(imgs, kx, ky, out=out, host_tables=host_tables)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        gbs = bytes_per_batch / (ms * 1e-3) / 1e9
+        return {"images_per_s": round(n_img / (ms * 1e-3), 1), "ms_per_batch": round(ms, 4),
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}}
+
+    dev_form = timed(False, True)
+    host_form = timed(True, True)
+    cached = timed(True, False)
+    kx, ky = draws[iters]
     img = imgs[0].cpu().numpy()
     t0 = time.perf_counter()
     ref, _ = panostretch_ref.pano_stretch(img, np.zeros((1, 2), np.float32), float(kx[0]), float(ky[0]))
     cpu_s = time.perf_counter() - t0
-    err = float(np.abs(out[0].cpu().numpy() - ref).max())
-    return {"images_per_s": round(n_img / (ms * 1e-3), 1), "ms_per_batch": round(ms, 4), "batch": n_img,
-            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)},
-            "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "images/s", "cores": 1, "kind": "port",
-                             "sample": "1 image 512x1024x3 through oracle.panostretch_ref.pano_stretch (numpy, 1 thread)"},
-            "max_abs_vs_oracle": err}
+    chk = pano_stretch_batch(imgs[:1], kx[:1], ky[:1], host_tables=True)[0].cpu().numpy()
+    err_host = float(np.abs(chk - ref).max())
+    chk = pano_stretch_batch(imgs[:1], kx[:1], ky[:1], host_tables=False)[0].cpu().numpy()
+    err_dev = float(np.abs(chk - ref).max())
+    res = dict(dev_form)
+    res.update({"batch": n_img, "form": "device_coordinates (hn_pano_stretch), fresh factors every iteration, wall-clock",
+                "host_tables": dict(host_form, form="hn_pano_stretch_tables, fresh factors every iteration: numpy column terms + upload inside the timed region"),
+                "kernel_only_same_factors": dict(cached, form="hn_pano_stretch_tables, the same factors every iteration (tables cached): the kernel alone"),
+                "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "images/s", "cores": 1, "kind": "port",
+                                 "sample": "1 image 512x1024x3 through oracle.panostretch_ref.pano_stretch (numpy, 1 thread)"},
+                "max_abs_vs_oracle": err_dev, "max_abs_vs_oracle_host_tables": err_host})
+    return res
 
 
 def augment_leg(dev, n_img=64, iters=10):
@@ -447,8 +494,8 @@ def train_roofline(dtype, B, s_per_step, achieved_tflops, peak):
                 "note": "per GPU, against the dense fp32 matrix peak (157.3 TF)"}
     t_mixed, fl, by, t_hbm = train_mixed_roofline(B)
     traffic = stale = note = None
-    tpath = os.path.join(ROOT, "profiles", "r4_pmc_train.json")
-    if B == 64 and os.path.exists(tpath):
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_train.json", "r4_pmc_train.json")) if os.path.exists(q)), "")
+    if B == 64 and tpath:
         from horizonnet_amd import _lib as _l
         rec = json.load(open(tpath))
         traffic = rec["total_bytes"]
@@ -461,6 +508,10 @@ def train_roofline(dtype, B, s_per_step, achieved_tflops, peak):
                      "statistics force, LSTM x 3, Adam)",
             "achieved": round(B / s_per_step, 1), "peak": round(B / t_mixed, 1), "unit": "panoramas/s", "frac": round(t_mixed / s_per_step, 4),
             "mixed_roofline_ms_per_step": round(t_mixed * 1e3, 2), "hbm_bound_passes_ms": round(t_hbm * 1e3, 2),
+            "fused_minimum": (lambda tf: {"peak": round(B / tf[0], 1), "frac": round(tf[0] / s_per_step, 4), "ms_per_step": round(tf[0] * 1e3, 2),
+                                          "model_bytes_per_step": tf[2],
+                                          "note": "BatchNorm = read z once forward, read dy + z once backward (3 transfers instead of 7 / 8)"})(
+                                              train_mixed_roofline(B, fused_minimum=True)),
             "model_flop_per_step": fl, "model_bytes_per_step": by, "traffic": traffic, "traffic_stale": stale, "traffic_note": note,
             "mfma_only": {"achieved_tflops": round(achieved_tflops, 2), "peak": peak, "frac": round(achieved_tflops / peak, 4)}}
 
@@ -920,6 +971,12 @@ def main():
             t_mixed = bf16_mixed_roofline(B)[0]
             out["roofline"]["mixed_per_layer"] = {"peak_panoramas_per_s": round(B / t_mixed, 1), "frac": round(B / (ms_per_fwd * 1e-3) / (B / t_mixed), 4),
                                                   "note": "the governing roofline of the bf16 mode (BASELINE.md section 3)"}
+        else:
+            t_mixed, _, _, t_hbm = f32_mixed_roofline(B)
+            out["roofline"]["mixed_per_layer"] = {"peak_panoramas_per_s": round(B / t_mixed, 1), "frac": round(t_mixed / (ms_per_fwd * 1e-3), 4),
+                                                  "hbm_bound_layers_ms": round(t_hbm * 1e3, 3),
+                                                  "note": "per layer max(flops / 157.3 TF, unfused float32 bytes / 8 TB/s), summed: the bound that also charges the "
+                                                          "HBM-bound layer1 1x1 convs their bytes; `frac` above stays the pure-MFMA figure SURVEY 8(d) names"}
         if plain_rec is not None:
             out["plain_forward"] = plain_rec
         if rccl is not None:

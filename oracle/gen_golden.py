@@ -455,6 +455,47 @@ def gen_train():
         json.dump({"names": names, "B": B, "weights_seed": 31, "data_seed": 32}, f)
 
 
+def gen_train_big():
+    """One training step (train.py:44-58: L1 + BCE-with-logits, train-mode BatchNorm, dropout off) of the UNMODIFIED reference in float32
+    at the LARGEST batch this 62 GB build container holds (B = 16; the reference's autograd keeps ~2 GB per panorama, so BASELINE
+    configs[2]'s B = 64 does not fit), on the TRAINED config-5 checkpoint and 16 of its synthetic Structured3D-shaped panoramas: loss,
+    outputs and the norm of every parameter gradient.  The engine's bf16 training step at the same batch is held against it
+    (tests/test_gpu_train.py: test_train_step_bf16_b16_vs_reference) -- a well-conditioned network, unlike the B = 2 seeded-random
+    fixtures where fifty batch-statistics BatchNorms over two panoramas amplify any rounding."""
+    import torch.nn.functional as F
+    import model as ref_model
+    from tools import c5_common as c5
+    B = int(os.environ.get("HN_GOLDEN_BIG_B", "16"))
+    sd = c5.decode_state_dict()
+    rooms = list(range(B))
+    imgs = np.stack([c5.make_room(c5.room_jobs(1, c5.VAL_SEED0, i)[0])[0] for i in rooms])
+    x = torch.FloatTensor(imgs.transpose(0, 3, 1, 2) / 255)
+    g = torch.Generator().manual_seed(52)
+    y_bon = (torch.rand(B, 2, 1024, generator=g) - 0.5) * 1.2
+    y_cor = (torch.rand(B, 1, 1024, generator=g) < 0.05).float()
+    net = ref_model.HorizonNet("resnet50", True)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.bi_rnn.dropout = 0.0
+    net.drop_out.p = 0.0
+    bon, cor = net(x)
+    loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+    loss.backward()
+    names = [k for k, _ in net.named_parameters()]
+    grads = {k: p.grad.detach() for k, p in net.named_parameters()}
+    out = {"loss": np.float64(float(loss)), "bon": bon.detach().numpy(), "cor": cor.detach().numpy(),
+           "grad_norm": np.array([float(grads[k].double().norm()) for k in names], np.float64),
+           "rooms": np.array(rooms), "crc": np.array([c5.image_crc(im) for im in imgs], np.uint32)}
+    for k in ("linear.weight", "feature_extractor.encoder.layer4.2.conv3.weight", "feature_extractor.encoder.layer1.1.conv3.weight",
+              "feature_extractor.encoder.layer1.0.downsample.0.weight", "feature_extractor.encoder.conv1.1.weight"):
+        t = grads[k].flatten()
+        out["grad:" + k] = t[:: max(1, t.numel() // 4096)].numpy().copy()
+    print("train step B=%d on the trained checkpoint: loss %.6f, |grad| total %.4e" % (B, float(loss), float(np.sqrt((out["grad_norm"] ** 2).sum()))))
+    np.savez_compressed(os.path.join(GOLD, "train_step_trained_b%d.npz" % B), **out)
+    with open(os.path.join(GOLD, "train_step_trained_b%d.json" % B), "w") as f:
+        json.dump({"names": names, "B": B, "data_seed": 52}, f)
+
+
 def gen_train_frozen():
     """train.py:200-208,245-256 (--freeze_earlier_blocks 1): the parameters of blocks 0..1 (stem, layer1) have
     requires_grad False AND those modules are put in eval() every epoch, so their BatchNorms normalise with the running
@@ -598,6 +639,8 @@ if __name__ == "__main__":
         gen_train()
     if "train_frozen" in which:
         gen_train_frozen()
+    if "train_big" in which:
+        gen_train_big()
     if "traincurve" in which:
         gen_traincurve()
     if "dataset" in which:

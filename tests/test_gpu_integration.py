@@ -306,11 +306,11 @@ def test_bench_self_launch_under_rccl():
     assert rec["rccl"]["backend"] == "nccl" and rec["rccl"]["world_size_seen_by_rccl"] == 1 and rec["value"] > 0
 
 
-def _bench_two_ranks(extra, timeout=1200):
+def _bench_two_ranks(extra, timeout=1200, ranks=2):
     """`python bench.py --gpus 2 ...` WITHOUT torchrun's environment: bench.py becomes the launcher (the re-exec branch the
     driver's N = 2, 4, 8 runs go through), both ranks share the box's one GPU, gloo stands in for RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"] + extra,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--share-gpu"] + extra,
                          capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -356,6 +356,40 @@ def test_bench_two_rank_self_launch_layout():
     par = rec["iou3d_parity_vs_reference_inference"]
     assert par["f32"]["iou3d_failed"] == 0 and par["f32"]["iou3d_mean"] > 0.9999 and par["f32"]["corner_count_mismatches"] == 0
     assert par["bf16"]["iou3d_mean"] > 0.99
+
+
+# ---- world size 8 without an 8-GPU node: the driver's N = 8 command line, eight processes on the box's one GPU ----
+def test_bench_eight_rank_self_launch_forward():
+    """`bench.py --gpus 8` re-exec, rendezvous of eight ranks on 127.0.0.1, pin_rank_affinity at (cores / 8) per rank, eight engines and
+    workspaces alive together, shard_for_rank over 8, barrier + max-over-ranks timing, one JSON line, clean teardown."""
+    rec = _bench_two_ranks(["--batch", "2", "--steps", "2", "--warmup", "1"], ranks=8)
+    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 16 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["rccl"]["world_size_seen_by_rccl"] == 8 and len(rec["rccl"]["devices"]) == 8
+    assert rec["config"]["parallelism"].startswith("dp8")
+
+
+def test_bench_eight_rank_self_launch_train():
+    """configs[3] at world size 8 (B = 1 per rank, bf16 step, gradients on the wire as bf16, deferred mean): per-rank rooms, broadcast of
+    rank 0's weights, the five-segment backward with its seven all-reduce buckets (traced table), the status word MAX-reduced, teardown."""
+    rec = _bench_two_ranks(["--mode", "train", "--dtype", "bf16", "--allreduce-dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"],
+                           ranks=8, timeout=1800)
+    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 8 and rec["value"] > 0 and np.isfinite(rec["final_loss"])
+    assert rec["rccl"]["world_size_seen_by_rccl"] == 8
+    tr = rec["allreduce_overlap"]["traced_step"]
+    # (64 MB buckets: 7 when the gradients travel as float32 -- 326 MB --, 6 on the bf16 wire: the height-compression range is 91 MB = 2 buckets)
+    assert len(tr["segment_kernels_done_ms"]) == 5 and len(tr["buckets"]) == 6, [b["MB"] for b in tr["buckets"]]
+    assert sum(b["MB"] for b in tr["buckets"]) == pytest.approx(163.1, abs=1.0)
+    print("[parity] 8 ranks on one GPU, train: buckets (MB) %s, host cores per rank %s" % ([b["MB"] for b in tr["buckets"]], rec.get("host_cores_per_rank")))
+
+
+def test_bench_eight_rank_self_launch_layout():
+    """configs[4] over 8 ranks: this host's cores / 8 per rank for the layout fit -- the rate a first 8-GPU run of the layout leg should be
+    compared with (the forward does not depend on host cores; the fit does)."""
+    rec = _bench_two_ranks(["--mode", "layout", "--panoramas", "128", "--batch", "8"], ranks=8, timeout=1800)
+    assert rec["n_gpus"] == 8 and rec["render_crc_mismatches"] == 0 and rec["host_cores_per_rank"] >= 1
+    par = rec["iou3d_parity_vs_reference_inference"]
+    assert par["f32"]["iou3d_failed"] == 0 and par["f32"]["iou3d_mean"] > 0.9999 and par["f32"]["corner_count_mismatches"] == 0
+    print("[parity] 8 ranks on one GPU, layout: host cores per rank %s, %s panoramas/s end to end" % (rec["host_cores_per_rank"], rec["value"]))
 
 
 # ---- inference.py:174-223 call sequence --------------------------------------------------------------------------
@@ -454,10 +488,12 @@ def test_config5_layouts_vs_reference_inference(golden_dir):
     assert bf16["iou3d_mean"] >= 0.999
     # bf16 against the reference's layouts, corner by corner, WRAP-AWARE (a corner at column 1023.6 vs 0.2 is 0.6 px apart, not 1023):
     # measured 1.24 px worst / 0.16 px at the 99th percentile over the 999 panoramas whose corner counts agree, 1 panorama with another
-    # count (its IoU 0.986 is the run's minimum).  Bounds = 2 x measured; the forward is deterministic, so these are regression bounds.
+    # count (its IoU 0.986 is the run's minimum); the 1-D signals sit 0.030 max-abs from the reference's.  Bounds = ~1.3 x measured (VERDICT r4
+    # item 4b: a kernel change that doubles the bf16 error must fail here); the forward is deterministic, so these are regression bounds.
     assert bf16["corner_count_mismatches"] <= 1, bf16["corner_count_mismatch_panoramas"]
-    assert bf16["cor_id_max_abs_px_seam_aware"] <= 2.5 and bf16["cor_id_p99_px_seam_aware"] <= 0.35, bf16
-    assert bf16["iou3d_min"] >= 0.97 and bf16["iou3d_below_0.99"] <= 1
+    assert bf16["cor_id_max_abs_px_seam_aware"] <= 1.6 and bf16["cor_id_p99_px_seam_aware"] <= 0.22, bf16
+    assert bf16["iou3d_min"] >= 0.98 and bf16["iou3d_below_0.99"] <= 1
+    assert bf16["signal_max_abs_vs_reference"] <= 0.04, bf16["signal_max_abs_vs_reference"]
     assert f32["cor_id_max_abs_px_seam_aware"] <= 0.01                                 # measured 0.0008 px
 
 
