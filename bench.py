@@ -336,6 +336,7 @@ def loss_curve_check(dev, dtype):
     import torch.nn.functional as F
     from horizonnet_amd import utils as hutils
     from horizonnet_amd.dataset import DeviceBatcher
+    from horizonnet_amd.train import objective
     g = np.load(os.path.join(ROOT, "tests", "golden", "traincurve_seed41.npz"))
     net = seeded_net_from_state(int(g["weights_seed"])).to(dev).train()
     net.bi_rnn.dropout, net.drop_out.p = 0.0, 0.0
@@ -351,7 +352,7 @@ def loss_curve_check(dev, dtype):
         x, y_bon, y_cor = data.batch(np.random.randint(len(data), size=int(g["B"])))
         opt.zero_grad()
         bon, cor = net(x)
-        loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+        loss = objective(bon, y_bon, cor, y_cor)["total"]
         loss.backward()
         opt.step()
         got.append(float(loss))
@@ -389,6 +390,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
     net.allreduce_dtype = allreduce_dtype   # "bf16": the gradient ranges travel as bf16 (163 MB instead of 326 MB over xGMI)
     broadcast_module_(net)
     from horizonnet_amd.optim import FusedAdam
+    from horizonnet_amd.train import objective
     opt = FusedAdam(net, lr=1e-4, betas=(0.9, 0.999))     # one hn_adam_step launch over the flat gradient buffer (train.py:216-225,279)
     rng = np.random.RandomState(2000 + rank)
     total_iters = max(1, warmup + steps + max(2, steps // 2) + 1)
@@ -410,7 +412,7 @@ def train_leg(dev, world, rank, B, steps, warmup, dist, dtype, rccl, rooms, with
         x, y_bon, y_cor = next(batches)
         state["host_s"] += time.perf_counter() - th
         bon, cor = net(x)
-        loss = F.l1_loss(bon, y_bon) + F.binary_cross_entropy_with_logits(cor, y_cor)
+        loss = objective(bon, y_bon, cor, y_cor)["total"]
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256) void labels_rasterise_kernel(const float* __re
     auto rows_at = [&](int k, int c, double& ya, double& yb) -> int {
         const float* e = seg_s + k * LB_SEG;
         if (e[0] != 0.f) {
-            if ((double)e[1] != (double)c) return 0;
+            // a vertical edge sits on ONE column: an integral x, taken modulo W exactly as the host half marks it covered
+            // (labels.device_label_record: covered[int(x) % W]); a fractional x touches no integer column
+            const double xe = (double)e[1];
+            if (xe != floor(xe)) return 0;
+            double xw = fmod(xe, (double)W);
+            if (xw < 0.0) xw += (double)W;
+            if (xw != (double)c) return 0;
             ya = (double)e[2]; yb = (double)e[3];
             return 2;
         }

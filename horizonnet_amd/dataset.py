@@ -156,6 +156,7 @@ class DeviceBatcher:
     def __init__(self, root_dir=None, images=None, corners=None, device="cuda", flip=False, rotate=False, gamma=False,
                  stretch=False, p_base=0.96, max_stretch=2.0, device_labels=True):
         self.device_labels = bool(device_labels)
+        self._unexpected_flags = None                      # device scalar: kernel-flagged rows the host half had not predicted (unexpected_label_flags)
         if root_dir is not None:
             img_dir, cor_dir, names, labels = _list_samples(root_dir)
             images = np.stack([_decode(os.path.join(img_dir, n)) for n in names])
@@ -234,6 +235,13 @@ class DeviceBatcher:
                     d_bon[row].copy_(torch.from_numpy(hb))
                     d_cor[row].copy_(torch.from_numpy(hc))
             self.last_label_status = status             # device int32 [B]: 1 = a column without a trace point (tests read it)
+            # The host half predicts which outlines the kernel cannot close (`on_host` rows, rasterised there and copied in above); a row the
+            # KERNEL flags but the host did not predict would carry a wrong boundary label silently.  Counted on the device (no sync here),
+            # read once per epoch by the training loop (unexpected_label_flags), which refuses to go on.
+            unexpected = status.clone()
+            if y_cor:
+                unexpected[torch.tensor(sorted(y_cor.keys()), dtype=torch.long, device=dev)] = 0
+            self._unexpected_flags = unexpected.sum() if self._unexpected_flags is None else self._unexpected_flags + unexpected.sum()
             return x, d_bon, d_cor
         slot["bon"][:B].copy_(torch.from_numpy(bon))
         slot["cor"][:B].copy_(torch.from_numpy(y_cor))
@@ -242,6 +250,13 @@ class DeviceBatcher:
             d_cor = slot["cor"][:B].to(dev, non_blocking=True)
             slot["done"].record()
         return x, d_bon, d_cor
+
+    def unexpected_label_flags(self):
+        """Panoramas (since the last call) whose device-rasterised labels had a column without a trace point although the host half had
+        predicted a closed outline -- must be 0; synchronises with the device (call it once per epoch, not per batch)."""
+        n = 0 if self._unexpected_flags is None else int(self._unexpected_flags.item())
+        self._unexpected_flags = None
+        return n
 
     def batch(self, indices, rng=np.random):
         return self.device_half(*self.host_half(indices, rng))

@@ -521,4 +521,9 @@ def inference_stream(net, batches, device, flip=False, rotate=[], force_cuboid=F
         # the generator was closed early (or a stage raised): the forward of `sub` is still writing its outputs from the engine's own
         # stream -- collect it before its tensors go back to the allocator (PendingForward.__del__ does the same as a last resort)
         if sub is not None and sub[0].get("pending") is not None:
-            sub[0]["pending"].result()
+            try:
+                sub[0]["pending"].result()
+            except Exception as exc:        # noqa: BLE001 -- never replace the exception that is already propagating (or surface one from close())
+                import warnings
+                warnings.warn("inference_stream: collecting the in-flight forward during clean-up failed: %s: %s" % (type(exc).__name__, exc),
+                              RuntimeWarning)

@@ -261,7 +261,7 @@ class PendingForward:
                 if self._check:
                     self._st.post_status_read(self._ws, self._status_off)
             self._done = True
-        return self._bon, self._cor
+        return _follow_autocast(self._bon, self._cor)          # same dtype rule as forward() (the pipelined entry is forward() split in two)
 
     def __del__(self):
         # bon / cor / the workspace are torch allocations of the CALLER's stream, written by the engine-owned head stream the caching
@@ -408,7 +408,7 @@ def _follow_autocast(bon, cor):
     autocast ``nn.Linear`` (model.py:266), so its outputs arrive in the autocast dtype; the engine computes its head in float32
     and casts the two outputs here (differentiably), so that code written against the reference sees the same dtypes."""
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
         return bon.to(dt), cor.to(dt)
     return bon, cor
 
@@ -422,7 +422,8 @@ def _guard_data_parallel():
         return
     orig = nn.DataParallel.__init__
 
-    def checked_init(self, module, device_ids=None, output_device=None, dim=0):
+    def checked_init(self, module, *args, **kwargs):          # (signature-agnostic: whatever torch's DataParallel takes is passed on untouched)
+        device_ids = kwargs.get("device_ids", args[0] if args else None)
         ids = device_ids if device_ids is not None else list(range(torch.cuda.device_count()))
         if isinstance(module, HorizonNet) and len(ids) > 1:
             raise RuntimeError(
@@ -430,7 +431,7 @@ def _guard_data_parallel():
                 "GPU.  Launch the same script with\n    python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
                 "train.py ...\n(horizonnet_amd.train / horizonnet_amd.parallel shard the batches and all-reduce the gradients over RCCL); "
                 "nn.DataParallel(net, device_ids=[one device]) keeps working." % (len(ids), len(ids)))
-        orig(self, module, device_ids, output_device, dim)
+        orig(self, module, *args, **kwargs)
 
     checked_init._horizonnet_amd_guard = True
     nn.DataParallel.__init__ = checked_init

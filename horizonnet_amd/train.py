@@ -74,12 +74,53 @@ def build_parser():
     return p
 
 
-def feed_forward(net, x, y_bon, y_cor):
-    """train.py:44-58: L1 on the two boundaries + BCE-with-logits on the corner channel."""
-    y_bon_, y_cor_ = net(x)
+class _FusedObjective(torch.autograd.Function):
+    """train.py:53-56 as ONE HIP launch (hn_loss_l1_bce: both means, their sum and both gradients) + one launch in the backward
+    (hn_scale2: the incoming adjoint, read on the device) -- instead of the ~12 elementwise / reduce launches of the two torch losses."""
+
+    @staticmethod
+    def forward(ctx, bon, y_bon, cor, y_cor):
+        from . import _lib
+        dev = bon.device
+        bon, y_bon, cor, y_cor = bon.contiguous(), y_bon.contiguous(), cor.contiguous(), y_cor.contiguous()
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        dbon, dcor = torch.empty_like(bon), torch.empty_like(cor)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().hn_loss_l1_bce(_lib.ptr(bon), _lib.ptr(y_bon), bon.numel(), _lib.ptr(cor), _lib.ptr(y_cor), cor.numel(),
+                                                  _lib.ptr(losses), _lib.ptr(total), _lib.ptr(dbon), _lib.ptr(dcor), _lib.stream_ptr(dev)), "hn_loss_l1_bce")
+        ctx.save_for_backward(dbon, dcor)
+        ctx.mark_non_differentiable(losses)
+        return total, losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        from . import _lib
+        dbon, dcor = ctx.saved_tensors
+        g = g_total.contiguous().float()
+        with torch.cuda.device(dbon.device):
+            _lib.check(_lib.load().hn_scale2(_lib.ptr(dbon), dbon.numel(), _lib.ptr(dcor), dcor.numel(), _lib.ptr(g), _lib.stream_ptr(dbon.device)),
+                       "hn_scale2")
+        return dbon, None, dcor, None
+
+
+def objective(y_bon_, y_bon, y_cor_, y_cor):
+    """-> {"bon", "cor", "total"} of reference train.py:53-56; "total" carries the gradient.  Float32 ROCm tensors go through the fused HIP
+    objective (a second backward through the same graph is not supported: it scales its saved gradients in place); anything else (the outputs
+    under torch.autocast arrive in the autocast dtype; CPU tensors in the host-side tests) through the reference's two torch calls."""
+    if (y_bon_.is_cuda and y_bon_.dtype == torch.float32 and y_cor_.dtype == torch.float32 and y_bon.dtype == torch.float32 and y_cor.dtype == torch.float32
+            and y_bon.shape == y_bon_.shape and y_cor.shape == y_cor_.shape and y_bon.device == y_bon_.device and y_cor.device == y_bon_.device):
+        total, parts = _FusedObjective.apply(y_bon_, y_bon, y_cor_, y_cor)
+        return {"bon": parts[0], "cor": parts[1], "total": total}
     losses = {"bon": F.l1_loss(y_bon_, y_bon), "cor": F.binary_cross_entropy_with_logits(y_cor_, y_cor)}
     losses["total"] = losses["bon"] + losses["cor"]
     return losses
+
+
+def feed_forward(net, x, y_bon, y_cor):
+    """train.py:44-58: L1 on the two boundaries + BCE-with-logits on the corner channel."""
+    y_bon_, y_cor_ = net(x)
+    return objective(y_bon_, y_bon, y_cor_, y_cor)
 
 
 def freeze_blocks(net, upto, set_eval_only=False):
@@ -215,6 +256,11 @@ def main(argv=None):
         batches.close()
         torch.cuda.synchronize(device)
         status = int(net.hip_status(device) != 0)
+        bad_labels = train.unexpected_label_flags() if hasattr(train, "unexpected_label_flags") else 0
+        if bad_labels:                                      # (same exit path as the status word: every rank leaves together)
+            print("horizonnet_amd.train: %d panoramas of epoch %d were rasterised on the device with an uncovered column the host half had not "
+                  "predicted (labels.device_label_record vs csrc/labels.hip disagree)" % (bad_labels, epoch), flush=True)
+            status = 1
         if world > 1:                                       # EVERY rank must leave together: the collectives below would otherwise
             flag = torch.tensor([status], dtype=torch.int32, device=device)       # block the healthy ranks until the process-group time-out
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)

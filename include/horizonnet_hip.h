@@ -263,6 +263,13 @@ int hn_adam_step(float* const* params, const long long* offsets, const long long
                  float* m, float* v, long long total, float lr, float beta1, float beta2, float eps, float weight_decay,
                  int step, float grad_scale, void* stream);
 
+/* The training objective of reference train.py:53-56 in ONE launch: losses3 = {mean |bon - y_bon|, mean BCE-with-logits(cor, y_cor), their
+ * sum} (device floats; `total`, optional, receives the sum once more in its own allocation) and the gradients of the two means w.r.t. bon / cor (dbon [n_bon], dcor [n_cor]); all pointers are device float32.
+ * hn_scale2: a[i] *= *scale_dev, b[i] *= *scale_dev (the objective's incoming adjoint, read on the device). */
+int hn_loss_l1_bce(const float* bon, const float* y_bon, long long n_bon, const float* cor, const float* y_cor, long long n_cor,
+                   float* losses3, float* total, float* dbon, float* dcor, void* stream);
+int hn_scale2(float* a, long long na, float* b, long long nb, const float* scale_dev, void* stream);
+
 /* debug taps used by the parity tests (see train.hip) */
 int hn_train_debug_unit(int B, int unit, int64_t* out8);
 int64_t hn_train_debug_unit_yh(int B, int unit);   /* float offset of the unit's bf16 copy of y (bf16 mode) */

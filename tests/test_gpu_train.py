@@ -1038,3 +1038,28 @@ def test_train_step_bf16_b16_vs_reference(golden_dir):
         ok &= abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) and d_out <= 0.012
         ok &= abs(tot - 1.0) <= tot_b and float(rel[big].max()) <= worst_b and float(np.median(rel[big])) <= 1.6e-3
     assert ok
+
+
+@pytest.mark.gpu
+def test_fused_objective_equals_torch_losses():
+    """hn_loss_l1_bce (train.py:53-56 in one launch: both means, their sum, both gradients) against F.l1_loss +
+    F.binary_cross_entropy_with_logits and their autograd, incl. exact zeros in the L1 difference (sign(0) = 0) and a scaled adjoint."""
+    from horizonnet_amd.train import objective
+    g = torch.Generator().manual_seed(5)
+    for B in (1, 7, 64):
+        bon = ((torch.rand(B, 2, 1024, generator=g) - 0.5) * 2).to(DEV).requires_grad_(True)
+        y_bon = ((torch.rand(B, 2, 1024, generator=g) - 0.5) * 2).to(DEV)
+        with torch.no_grad():
+            y_bon[:, :, ::17] = bon[:, :, ::17]                    # exact ties
+        cor = ((torch.rand(B, 1, 1024, generator=g) - 0.5) * 30).to(DEV).requires_grad_(True)
+        y_cor = torch.rand(B, 1, 1024, generator=g).to(DEV)
+        got = objective(bon, y_bon, cor, y_cor)
+        (got["total"] * 3.0).backward()
+        gb, gc = bon.grad.clone(), cor.grad.clone()
+        bon.grad = cor.grad = None
+        wb, wc = F.l1_loss(bon, y_bon), F.binary_cross_entropy_with_logits(cor, y_cor)
+        ((wb + wc) * 3.0).backward()
+        assert abs(float(got["bon"]) - float(wb)) <= 2e-6 * abs(float(wb)) and abs(float(got["cor"]) - float(wc)) <= 2e-6 * abs(float(wc))
+        assert abs(float(got["total"]) - float(wb + wc)) <= 2e-6 * abs(float(wb + wc))
+        assert torch.equal(gb, bon.grad), float((gb - bon.grad).abs().max())
+        assert float((gc - cor.grad).abs().max()) <= 1e-6 * float(cor.grad.abs().max())

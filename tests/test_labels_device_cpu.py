@@ -25,7 +25,8 @@ def kernel_in_numpy(rec, p_base=0.96):
         for k in range(ne[bd]):
             e = rec[8 + (bd * lb.LABEL_MAX_EDGES + k) * 8:][:8]
             if e[0] != 0:
-                m = cols.astype(np.float64) == np.float64(e[1])
+                xe = np.float64(e[1])             # a vertical edge: an integral x, modulo W (csrc/labels.hip rows_at); a fractional x touches no column
+                m = (cols.astype(np.float64) == np.mod(xe, W)) if xe == np.floor(xe) else np.zeros(len(cols), bool)
                 cand += [(m, np.full(W, np.float64(e[2]))), (m, np.full(W, np.float64(e[3])))]
                 extra += [np.float64(e[2]), np.float64(e[3])]
                 continue

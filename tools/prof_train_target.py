@@ -9,6 +9,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 from bench import seeded_net  # noqa: E402
 from horizonnet_amd.optim import FusedAdam  # noqa: E402
+from horizonnet_amd.train import objective  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
@@ -27,7 +28,7 @@ for i in range(N + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
     bon, cor = net(x)
-    loss = F.l1_loss(bon, yb) + F.binary_cross_entropy_with_logits(cor, yc)
+    loss = objective(bon, yb, cor, yc)["total"]
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
