@@ -1611,6 +1611,9 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     if (!out_f32 && !d.res && !d.stat_sum && d.splitk_ws && d.Cout % 128 == 0 && d.B > 0) {
         static const char* sk_env = getenv("HN_BF16_SPLITK");
         const long per_image = (long)d.Ho * d.Wo;
+        // (unlike the float32 path -- hn_launch_conv's interactive regime -- the bf16 slice count never looks at the actual batch: a different
+        //  float32 summation order flips bf16 roundings, and test_forward_bf16_batch32_consistency / test_dw_reuse_split_k pin "same bits at any
+        //  batch size"; measured gain of a B = 1 regime: 2.51 -> 2.26 ms per forward, not taken)
         const long t32 = (long)hn_cdiv(32 * per_image, 128) * (d.Cout / 128);
         int S = t32 >= 192 ? 1 : (int)(256 / t32);
         if (S > 8) S = 8;

@@ -791,7 +791,11 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     // on the actual M: the summation order -- and every output bit -- is the same for any batch size.
     if (!d.res && !d.stat_sum && d.splitk_ws && d.Cout % 128 == 0 && !force_tile) {
         static const int sk_on = env_flag("HN_F32_SPLITK", 1);
-        const long t32 = (long)hn_cdiv(32L * d.Ho * d.Wo, 64) * (d.Cout / 128);
+        // ... with ONE exception, the interactive regime (reference inference.py:187-209 runs B = 1 + test-time augmentation): for B = 1 and
+        // for B = 2..4 the nominal batch is 1 / 4 -- a single panorama gives ghc3.0 four tiles of 64 rows x 8 column tiles on 256 CUs
+        // (505 us for 9.7 GFLOP); bits are the same within a regime, and differ between regimes only in the float32 summation order
+        const long nominal = d.B == 1 ? 1 : (d.B <= 4 ? 4 : 32);
+        const long t32 = (long)hn_cdiv(nominal * d.Ho * d.Wo, 64) * (d.Cout / 128);
         int S = t32 >= 192 ? 1 : (int)(256 / t32);
         if (S > 8) S = 8;
         while (S > 1 && a.nk / S < 16) --S;

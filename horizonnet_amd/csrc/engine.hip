@@ -128,6 +128,12 @@ struct Plan {
 };
 
 constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 8 * 128 * 256;   // up to 8 slices of the largest split layer per panorama
+// ... but never less than 8 slices of the largest tile set the interactive regime (B <= 4) splits: layer4's 3x3 convs / ghc3.0 at 4 panoramas
+inline size_t splitk_ws_floats(int B)
+{
+    const size_t per = SPLITK_WS_FLOATS_PER_PANO * (size_t)B, floor_ = (size_t)8 * 4 * 512 * 512;
+    return per > floor_ ? per : floor_;
+}
 
 Plan make_plan(int B)
 {
@@ -150,7 +156,7 @@ Plan make_plan(int B)
     p.gx = take((size_t)T_COLS * b * 4096);
     p.y1 = take((size_t)T_COLS * b * 1024);
     p.y2 = take((size_t)T_COLS * b * 1024);
-    p.sk = take(SPLITK_WS_FLOATS_PER_PANO * b);      // split-K partial tiles (conv_igemm_f32.hip)
+    p.sk = take(splitk_ws_floats((int)b));           // split-K partial tiles (conv_igemm_f32.hip)
     p.total = off;
     return p;
 }
@@ -427,8 +433,12 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
             const ConvLayer& c2 = a.convs[a.block_first[li][j] + 1];
             const ConvLayer& c3 = a.convs[a.block_first[li][j] + 2];
             float* out = (cur == W + pl.p0) ? W + pl.p1 : W + pl.p0;
-            if ((rc = run_conv(e, P, c1, cur, W + pl.t1, nullptr, B, H, Wd, 1, 1, 1, s))) return rc;
-            if ((rc = run_conv(e, P, c2, W + pl.t1, W + pl.t2, nullptr, B, H, Wd, stride, stride, 1, s))) return rc;
+            // interactive regime (B <= 4): the deep-K convs of the stages give a 256-CU part 32 .. 128 tiles -- split-K like the height-compression
+            // tails (same scratch: everything here is on stream s); at larger batches nothing changes
+            float* sk = B <= 4 ? W + pl.sk : nullptr;
+            const size_t skf = B <= 4 ? splitk_ws_floats(B) : 0;
+            if ((rc = run_conv(e, P, c1, cur, W + pl.t1, nullptr, B, H, Wd, 1, 1, 1, s, sk, skf))) return rc;
+            if ((rc = run_conv(e, P, c2, W + pl.t1, W + pl.t2, nullptr, B, H, Wd, stride, stride, 1, s, sk, skf))) return rc;
             const float* idt = cur;
             // block 0: downsample + conv3 + add + ReLU as ONE dual-accumulator launch (conv1x1_dual_f32_kernel): the
             // downsample output never goes to HBM; bit-identical to the two-launch form (option "fuse_downsample")
@@ -463,7 +473,7 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
         for (int k = 0; k < 4; ++k) {
             const ConvLayer& gc = a.convs[a.ghc_first[li] + k];
             float* gout = gbuf[k & 1];
-            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s, W + pl.sk, SPLITK_WS_FLOATS_PER_PANO * (size_t)B))) return rc;
+            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s, W + pl.sk, splitk_ws_floats(B)))) return rc;
             gin = gout;
             gh /= 2;
         }

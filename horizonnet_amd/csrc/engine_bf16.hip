@@ -47,6 +47,7 @@ size_t hn_bf16_whh_offset(int l, int d) { return hoff().whh[l][d]; }
 namespace {
 
 constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 2 * 256 * 1024;   // 2 slices of ghc3.0's 256 pixels x 1024 channels per panorama (= 4 of ghc3.1, 2 of layer4.*.conv2)
+inline size_t splitk_floats(int B) { return SPLITK_WS_FLOATS_PER_PANO * (size_t)B; }     // floats of one split-K scratch
 
 struct PlanH {                     // byte offsets
     size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, seq, gx, y1, y1h, y2, xch, sk, sk2, total;
@@ -81,8 +82,8 @@ PlanH make_plan_h(int B)
     p.y1h = take((size_t)T_COLS * b * 1024 * 2);
     p.y2 = take((size_t)T_COLS * b * 1024 * 4);
     p.xch = take(hn_lstm_bf16_xch_bytes());
-    p.sk = take(SPLITK_WS_FLOATS_PER_PANO * b * 4);      // split-K partial tiles of the branch stream (one user at a time)
-    p.sk2 = take(SPLITK_WS_FLOATS_PER_PANO * b * 4);     // ... of the caller's stream (layer4's 3x3 convs run beside the height-compression chains)
+    p.sk = take(splitk_floats(B) * 4);      // split-K partial tiles of the branch stream (one user at a time)
+    p.sk2 = take(splitk_floats(B) * 4);     // ... of the caller's stream (layer4's 3x3 convs run beside the height-compression chains)
     p.total = off;
     return p;
 }
@@ -263,7 +264,7 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
             const bool c1_done = chained_in || (stem_c1 && li == 0 && j == 0);
             if (!c1_done && (rc = run_conv_h(e, a.convs[i1], h.conv[i1], cur, W + pl.t1, nullptr, B, Hh, Wd, 1, 1, 1, s))) return rc;
             if ((rc = run_conv_h(e, a.convs[i1 + 1], h.conv[i1 + 1], W + pl.t1, W + pl.t2, nullptr, B, Hh, Wd, stride, stride, 1, s,
-                                 reinterpret_cast<float*>(W + pl.sk2), SPLITK_WS_FLOATS_PER_PANO * (size_t)B)))
+                                 reinterpret_cast<float*>(W + pl.sk2), splitk_floats(B))))
                 return rc;
             if (chain_out) {
                 const ConvLayer& c3 = a.convs[i1 + 2];
@@ -318,7 +319,7 @@ int run_trunk_h(hn_engine* e, const float* x, int B, int C_in, char* W, const Pl
             const int ig = a.ghc_first[li] + k;
             char* gout = gbuf[k & 1];
             if ((rc = run_conv_h(e, a.convs[ig], h.conv[ig], gin, gout, nullptr, B, gh, Wd, 2, 1, 1, sb, reinterpret_cast<float*>(W + pl.sk),
-                                 SPLITK_WS_FLOATS_PER_PANO * (size_t)B)))
+                                 splitk_floats(B))))
                 return rc;
             gin = gout;
             gh /= 2;
