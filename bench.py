@@ -920,7 +920,7 @@ def main():
         traffic, traffic_note = None, None               # HBM-side bytes per forward from the committed PMC passes of the newest round's kernels
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         traffic_stale = None
-        for tname in ("r4_pmc_forward.json", "r3_pmc_forward.json", "r2_pmc_forward.json"):
+        for tname in ("r5_pmc_forward.json", "r4_pmc_forward.json", "r3_pmc_forward.json", "r2_pmc_forward.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if B == 32 and os.path.exists(tpath):
                 whole = json.load(open(tpath))

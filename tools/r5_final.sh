@@ -1,0 +1,42 @@
+#!/bin/bash
+# round 5, evidence on ONE box: counter passes + kernel stats (forward bf16 / f32, training step), then the default bench line (which quotes
+# those counters: same kernel sources -> traffic_stale false), then the whole GPU suite.  EVERY step under its own timeout (a hung rocprofv3
+# once cost 20 GPU-minutes).   HN_GIT_HEAD=<commit> bash tools/r5_final.sh [nosuite]
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+T=r5
+timeout 300 bash tools/profile_forward.sh bf16 $T > gpurun_out/${T}_prof_bf16.log 2>&1
+timeout 300 bash tools/profile_forward.sh f32 $T > gpurun_out/${T}_prof_f32.log 2>&1
+timeout 60 python tools/merge_pmc.py gpurun_out $T > gpurun_out/${T}_pmc_forward.json 2> gpurun_out/${T}_merge.err
+timeout 400 bash tools/profile_train.sh $T > gpurun_out/${T}_prof_train.log 2>&1
+cp gpurun_out/${T}_pmc_forward.json gpurun_out/${T}_pmc_train.json profiles/ 2>/dev/null
+rm -rf gpurun_out/prof_${T}_bf16 gpurun_out/prof_${T}_f32 gpurun_out/prof_${T}_train
+timeout 600 python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
+python - <<'PY'
+import json
+T = "r5"
+for l in open('gpurun_out/%s_bench_default.json' % T):
+    if l.startswith('{'):
+        d = json.loads(l)
+        r = d['roofline']
+        print('f32', d['value'], d['ms_per_step'], r['frac'], 'traffic', r.get('traffic'), 'stale', r.get('traffic_stale'))
+        b = d.get('bf16_mode', {})
+        print('bf16', b.get('value'), b.get('ms_per_step'), b.get('roofline', {}).get('frac'), b.get('steps'))
+        t = d.get('train_bf16', {})
+        print('train', t.get('value'), t.get('ms_per_step'), {k: t.get('roofline', {}).get(k) for k in ('frac', 'traffic', 'traffic_stale')}, t.get('roofline', {}).get('fused_minimum'))
+        print('layout', d.get('layout', {}).get('value'), 'cpu', d.get('cpu_baseline', {}).get('value'), 'lat', d.get('latency_b1', {}).get('engine'))
+        print('legs', d.get('leg_seconds'))
+try:
+    d = json.load(open('gpurun_out/%s_pmc_forward.json' % T))
+    for p, v in d['precisions'].items():
+        print(p, 'total GB %.1f ratio %.2f' % (v['total_bytes'] / 1e9, v['counter_over_algorithmic']))
+    t = json.load(open('gpurun_out/%s_pmc_train.json' % T))
+    print('train step GB %.1f model %.1f ratio %.2f mfma busy %s' % (t['total_bytes'] / 1e9, t['model_bytes'] / 1e9, t['counter_over_model'], t['mfma_busy_pct_whole_step']))
+except Exception as e:
+    print('pmc summary failed', e)
+PY
+if [ "$1" != "nosuite" ]; then
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/${T}_gpu_tests.txt 2>&1
+grep -n "passed\|failed" gpurun_out/${T}_gpu_tests.txt | tail -3
+fi
