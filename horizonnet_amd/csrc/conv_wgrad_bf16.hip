@@ -318,6 +318,189 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
             }
 }
 
+// ---- 3x3 convs with stride 1 along W: the three taps of a filter ROW on one pass over the operands ("tap reuse", r5) ----
+// As a weight-gradient GEMM per tap, every (n tile, tap, channel tile) workgroup re-reads the same dz rows and a one-pixel-shifted copy of the same
+// input rows: layer1's 64 -> 64 conv moves 18 x 0.27 GB through L2 for 155 GFLOP (0.36 PF, the L2 -> CU path at its ~10 TB/s).  Here a workgroup
+// owns (n tile, filter row dh, channel tile): per chunk of WCHB output pixels -- which never straddles an image row (Wo % WCHB == 0) -- it loads
+// the dz rows ONCE and the input rows of pixels wo0 - 1 .. wo0 + WCHB (circular) ONCE, WCHB + 2 LDS image rows, and the MFMA operand of tap dw is
+// the same image read dw rows further down: three accumulator sets, a third of the operand traffic (190 FLOP per staged byte on 128x128 tiles
+// against 128 for the 256x256 per-tap tile).  Same transposing fragment reads, same float atomics into dW[n][(dh * 3 + dw) * Cin + c].
+template <int TN, int TK, int WCHB>
+__global__ __launch_bounds__(256) void conv_wgrad_row3_bf16_kernel(WgradArgsH p)
+{
+    constexpr int THREADS = 256;
+    constexpr int WN = TN / 2, WK = TK / 2;          // 2 x 2 waves
+    constexpr int TI = WN / 32, TJ = WK / 32;
+    static_assert(TI >= 1 && TJ >= 1, "wave tile");
+    constexpr int N_TPR = TN / 8, K_TPR = TK / 8;
+    constexpr int N_RPP = THREADS / N_TPR, K_RPP = THREADS / K_TPR;
+    constexpr int N_PS = WCHB / N_RPP;
+    constexpr int KROWS = WCHB + 2;
+    constexpr int K_PS = (KROWS + K_RPP - 1) / K_RPP;
+    static_assert(N_PS >= 1, "loader geometry");
+    constexpr int PN = pitch_of(TN), PK = pitch_of(TK);
+    constexpr int IMG_N = WCHB * PN, IMG_K = KROWS * PK;
+
+    extern __shared__ __attribute__((aligned(16))) char hsmem[];
+    char* s_dz0 = hsmem;                             // [2][IMG_N]
+    char* s_a0 = hsmem + 2 * IMG_N;                  // [2][IMG_K]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wi_ = wave >> 1, wj_ = wave & 1;
+
+    const int NT = p.Cout / TN;
+    const int CT = p.Cin / TK;
+    const int KT = 3 * CT;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % NT;
+    bid /= NT;
+    const int kt = bid % KT;
+    const int sp = bid / KT;
+    const int n0 = nt * TN;
+    const int dh = kt / CT;
+    const int c0 = (kt - dh * CT) * TK;
+    const int mlo = sp * p.mchunk;
+    const int mhi = (mlo + p.mchunk) < p.M ? (mlo + p.mchunk) : p.M;
+    if (mlo >= mhi) return;
+
+    const int hw_out = p.Ho * p.Wo;
+    const int b_first = mlo / hw_out;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * p.xstride;
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x + (size_t)b_first * img_elems), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_dz =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.dz + (size_t)mlo * p.dzstride), 0, 0x7fffffff, 0x00020000);
+
+    const int n_row = tid / N_TPR, n_col = (tid % N_TPR) * 8;
+    const int k_row = tid / K_TPR, k_col = (tid % K_TPR) * 8;
+
+    u32x4 rdz[N_PS], ra[K_PS];
+    auto fetch = [&](int mc) {
+#pragma unroll
+        for (int q = 0; q < N_PS; ++q) {
+            const int m = mc + n_row + q * N_RPP;
+            rdz[q] = hbuf_load16(rsrc_dz, (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 2u);
+        }
+        // the chunk's image row (wave-uniform): output pixels (b, ho, wo0 .. wo0 + WCHB - 1); input row hi = ho * sh - 1 + dh
+        const int wo0 = mc % p.Wo;
+        const int t = mc / p.Wo;
+        const int ho = t % p.Ho;
+        const int b = t / p.Ho - b_first;
+        const int hi = ho * p.sh - p.ph + dh;
+        const bool row_ok = (unsigned)hi < (unsigned)p.Hi;                   // zero padding above / below: the whole operand tile is zero
+        const unsigned row_base = (unsigned)((b * p.Hi + hi) * p.Wi);
+#pragma unroll
+        for (int q = 0; q < K_PS; ++q) {
+            const int r = k_row + q * K_RPP;                                 // LDS image row <-> input pixel wo0 - 1 + r (circular)
+            int wi = wo0 - p.pw + r;
+            wi = wi < 0 ? wi + p.Wi : wi;
+            wi = wi >= p.Wi ? wi - p.Wi : wi;
+            const unsigned off = ((row_base + (unsigned)wi) * (unsigned)p.xstride + (unsigned)(c0 + k_col)) * 2u;
+            ra[q] = hbuf_load16(rsrc_x, (row_ok && r < KROWS) ? off : OOB);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < N_PS; ++q)
+            *reinterpret_cast<u32x4*>(s_dz0 + buf * IMG_N + (n_row + q * N_RPP) * PN + n_col * 2) = rdz[q];
+#pragma unroll
+        for (int q = 0; q < K_PS; ++q) {
+            const int r = k_row + q * K_RPP;
+            if (r < KROWS) *reinterpret_cast<u32x4*>(s_a0 + buf * IMG_K + r * PK + k_col * 2) = ra[q];
+        }
+    };
+
+    f32x16 acc[3][TI][TJ];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[d][i][j][r] = 0.f;
+
+    fetch(mlo);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mc = mlo; mc < mhi; mc += WCHB) {
+        const bool more = mc + WCHB < mhi;
+        if (more) fetch(mc + WCHB);
+        const char* dz_s = s_dz0 + buf * IMG_N;
+        const char* a_s = s_a0 + buf * IMG_K;
+#pragma unroll
+        for (int s = 0; s < WCHB / 16; ++s) {
+            bf16x8 fa[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = tr_frag(dz_s, 16 * s, wi_ * WN + i * 32, lane, PN);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                bf16x8 fb[TJ];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) fb[j] = tr_frag(a_s, 16 * s + d, wj_ * WK + j * 32, lane, PK);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[d][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[d][i][j], 0, 0, 0);
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    const int fr = lane & 31;
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wi_ * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int k = (dh * 3 + d) * p.Cin + c0 + wj_ * WK + j * 32 + fr;
+                    __hip_atomic_fetch_add(p.dw + (size_t)n * p.K + k, acc[d][i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+}
+
+template <int TN, int TK, int WCHB>
+int launch_wgrad_row3(WgradArgsH a, hipStream_t s, long target)
+{
+    const int NT = a.Cout / TN, KT = 3 * (a.Cin / TK);
+    long split = target / ((long)NT * KT);
+    if (split < 1) split = 1;
+    long mchunk = (a.M + split - 1) / split;
+    if (mchunk < 8 * WCHB) mchunk = 8 * WCHB;
+    mchunk = (mchunk + WCHB - 1) / WCHB * WCHB;
+    split = (a.M + mchunk - 1) / mchunk;
+    a.mchunk = (int)mchunk;
+    const size_t lds = 2 * ((size_t)WCHB * pitch_of(TN) + (size_t)(WCHB + 2) * pitch_of(TK));
+    auto kern = conv_wgrad_row3_bf16_kernel<TN, TK, WCHB>;
+    if (lds > 65536) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        HN_HIP(hipGetDevice(&dev));
+        if (dev < 64 && !attr_done[dev]) {
+            HN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(NT * KT * split)), dim3(256), lds, s, a);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
+
 // out[i] = sum_sp slab[sp][i] (float) and cs_out[c] = sum_sp slab_cs[sp][c] (double), in double precision and in a FIXED order: a workgroup
 // owns 16 elements, its 16 split lanes add splits l, l + 16, ... (eight loads in flight each), the lanes are combined 0..15 through LDS.
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long n, int splits,
@@ -435,6 +618,28 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     HN_REQUIRE((double)B * Hi * Wi * a.xstride * 2.0 < 2147483648.0 && (double)a.M * a.dzstride * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
+    {
+        // 3x3 convs with stride 1 along W whose image rows are whole chunks: the tap-reuse kernel where it wins.  Per-dispatch durations of the
+        // B = 64 step under both forms (tools/r5_row3.sh): layer1's 64 -> 64 convs 413 -> 291 us, ghc0.0 851 -> 709, ghc2.0 750 -> 703, ghc3.1 318 ->
+        // 232, ghc3.0 1112 -> 729 (on 128x128 tiles: 192 accumulators, one workgroup per CU; the others on 128x64); the 256-channel 3x3 convs of
+        // layer2..4 are a draw (210-220 us either way) and the short tails of the height-compression chains lose 15-40 % (few rows per workgroup, three
+        // accumulator sets to flush), so they keep the per-tap tiles.  HN_WGRAD_ROW3 = 0: never, 1: wherever eligible (tests, A/B); read per call.
+        const char* e3 = getenv("HN_WGRAD_ROW3");
+        const bool eligible = KH == 3 && KW == 3 && sw == 1 && a.Wo % 32 == 0 && a.Wo == Wi && a.xstride == Cin && a.dzstride == Cout;
+        const long cc = (long)Cout * Cin;
+        const bool wins = (Cin == 64 && Cout == 64) || cc >= (1L << 20) || (cc >= (1L << 19) && a.M >= 32768) || (Cin == 256 && Cout == 128 && a.M >= (1L << 20));
+        if (eligible && !(e3 && e3[0] == '0') && (wins || (e3 && e3[0] == '1'))) {
+            const char* e3w = getenv("HN_WGRAD_ROW3_WGS");
+            const char* e3t = getenv("HN_WGRAD_ROW3_TILE");                  // both channel counts % 128: 0 = 128x128, 1 = 128x64, 2 = 64x128
+            const long target = e3w ? atol(e3w) : 1024;
+            const int tile = e3t ? atoi(e3t) : (Cin >= 2048 ? 0 : 1);
+            if (Cout % 128 == 0 && Cin % 128 == 0 && tile == 0) return launch_wgrad_row3<128, 128, 32>(a, s, target);
+            if (Cout % 128 == 0 && Cin % 128 == 0 && tile == 2) return launch_wgrad_row3<64, 128, 32>(a, s, target);
+            if (Cout % 128 == 0) return launch_wgrad_row3<128, 64, 32>(a, s, target);
+            if (Cin % 128 == 0) return launch_wgrad_row3<64, 128, 32>(a, s, target);
+            return launch_wgrad_row3<64, 64, 32>(a, s, 2 * target);
+        }
+    }
     {
         // 8-wave 256-wide tiles where both channel counts allow them (layer3 / layer4, the deep height-compression convs): one
         // workgroup per CU, m split into ~256 workgroups.  HN_WGRAD_W8 = 0 disables, 1 = per-shape choice between 256x256 and 256x128 (default), 2 = 256x128, 3 = 128x256, 4 = 256x256 then 256x128, 5 = 256x256 only

@@ -122,6 +122,31 @@ def test_conv_wgrad_bf16_stage(case):
     assert report("wgrad bf16 " + name, dw.cpu().numpy(), w.grad.numpy(), 3e-5 * max(1.0, float(w.grad.abs().max())))
 
 
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+def test_conv_wgrad_bf16_tap_reuse_kernel(tile, monkeypatch):
+    """conv_wgrad_row3_bf16_kernel (3x3, stride 1 along W: the three taps of a filter row on one pass over the operands) forced on every
+    eligible shape and every tile variant (the dispatcher only takes it where it wins on the B = 64 step): == torch autograd on the
+    bf16-rounded operands, as the per-tap kernel in test_conv_wgrad_bf16_stage -- stride (2,1) with H = 2 (a filter row entirely in the
+    zero padding), circular columns at both ends of an image row, several chunks per row, ragged m split."""
+    monkeypatch.setenv("HN_WGRAD_ROW3", "1")
+    monkeypatch.setenv("HN_WGRAD_ROW3_TILE", tile)
+    r16 = lambda t: t.bfloat16().float()                                                    # noqa: E731
+    cases = [("64->64 W=128", 2, 64, 128, 64, 64, (1, 1)), ("128->128 s(2,1) W=32 H=2", 2, 2, 32, 128, 128, (2, 1)), ("256->128 s(2,1) W=128", 2, 16, 128, 256, 128, (2, 1)),
+             ("128->256 W=64", 3, 8, 64, 128, 256, (1, 1)), ("512->512 W=32", 2, 16, 32, 512, 512, (1, 1)), ("64->128 s(2,1) W=256", 1, 6, 256, 64, 128, (2, 1))]
+    for name, B, H, W, cin, cout, (sh, sw) in cases:
+        x = _rand((B, H, W, cin), 1)
+        w = _rand((cout, cin, 3, 3), 2, 1.0 / np.sqrt(cin * 9)).requires_grad_(True)
+        y = _conv_ref(r16(x), w, (sh, sw))
+        dz = _rand(tuple(y.shape), 3)
+        y.backward(r16(dz))
+        xd, dzd = x.to(DEV), dz.contiguous().to(DEV)
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        scr = torch.empty(cout * 9 * cin + (x.numel() + dz.numel()) // 2 + 256, device=DEV)
+        _lib.check(lib().hn_conv2d_wgrad_nhwc_bf16(P(xd), P(dzd), P(dw), P(scr), B, H, W, cin, cout, 3, 3, sh, sw, sp()), "wgrad bf16 row3")
+        torch.cuda.synchronize()
+        assert report("wgrad bf16 tap reuse (tile %s) %s" % (tile, name), dw.cpu().numpy(), w.grad.numpy(), 3e-5 * max(1.0, float(w.grad.abs().max())))
+
+
 def test_stem_wgrad_stage():
     B, H, W = 2, 32, 64
     x = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5))
