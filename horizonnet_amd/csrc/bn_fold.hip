@@ -133,6 +133,19 @@ __global__ __launch_bounds__(256) void bn_fold_stats_kernel(const float* __restr
     }
 }
 
+// WA[j][n] = bf16(c1[n] * W[n][j]), c1 = gamma * invstd: the data-gradient weights that do not depend on the batch sums (ahead of the P-GEMM when
+// conv A rides in it, conv_wgrad_bf16_kernel<.., FUSEA>); the same values bn_fold_finish_kernel writes
+__global__ __launch_bounds__(256) void bn_fold_wa_kernel(const u16* __restrict__ wh, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                         u16* __restrict__ wa, int N, int K)
+{
+    const long total = (long)N * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (long)n * K);
+        const double c1 = (double)gamma[n] * (double)invstd[n];
+        wa[(size_t)k * N + n] = f2bf((float)(c1 * (double)bf2f(wh[i])));
+    }
+}
+
 // blockIdx.y selects the job: 0: dW over P and WA = (c1 * W)^T (elementwise over [N][K]);  1: WB = -Q (elementwise over [K][K]);
 // 2: shiftA[j] = -sum_n rc[n] W[n][j] (one workgroup per 16 columns, 16 row lanes, combined through LDS)
 __global__ __launch_bounds__(256) void bn_fold_finish_kernel(FoldArgs p)
@@ -205,6 +218,22 @@ int hn_launch_bn_fold_gram(const void* a_h, long M, int K, float* keep, hipStrea
 {
     if (!slab) HN_HIP(hipMemsetAsync(keep, 0, ((size_t)K * K + 2 * (size_t)K) * sizeof(float), s));
     return hn_launch_conv_wgrad_bf16_fold(a_h, const_cast<void*>(a_h), keep_G(keep, K), M, K, K, nullptr, keep_A(keep, K), s, 1, slab, slab_floats);
+}
+
+// where hn_launch_bn_fold_finish keeps WA inside its scratch `ws` (so that it can be filled ahead of the P-GEMM)
+void* hn_bn_fold_wa_ptr(void* ws, int N, int K)
+{
+    return reinterpret_cast<char*>(ws) + hn_bn_fold_zero_bytes(K) + al256((size_t)N * K * sizeof(float)) + al256(4 * (size_t)N * sizeof(double));
+}
+
+int hn_launch_bn_fold_wa(const void* w_h, const float* gamma, const float* invstd, void* wa, int N, int K, hipStream_t s)
+{
+    const long nk = (long)N * K;
+    long g = (nk + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(bn_fold_wa_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const u16*>(w_h), gamma, invstd, reinterpret_cast<u16*>(wa), N, K);
+    HN_LAUNCH_CHECK();
+    return 0;
 }
 
 // Forward of a folded unit, between hn_launch_bn_fold_gram and the fused conv: Wf, WG into `keep`, then the BatchNorm affine (a_out / b_out =

@@ -52,6 +52,10 @@ struct WgradArgsH {
     // wgrad_slab_reduce_kernel adds the m splits in index order in double precision.
     float* slab;
     float* slab_cs;
+    // FUSEA instantiation (TN = Cout = 256, TK = Cin = 64: layer1's conv3 / downsample): the data-gradient conv on g that does not depend on the
+    // batch sums, a_out[m][j] = sum_n g[m][n] wa[j][n] (wa = (c1 * W)^T, [Cin][Cout] bf16; a_out [M][Cin] bf16), rides in this pass over g
+    const u16* wa;
+    u16* a_out;
 };
 
 __device__ __forceinline__ u32x4 hbuf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff)
@@ -86,11 +90,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int mb, int nb, int l
 // row 7 / window pixel 0 / channel 3 are padding): the A image row of output pixel (ho, wo) is, per filter row dh, the 64
 // contiguous bytes of the NHWC4 input at row 2 ho - 3 + dh, pixels 2 wo - 4 .. 2 wo + 3 (circular) -- four 16-byte pieces; window
 // pixel t holds filter tap dw = t - 1 (the bf16 forward's stem layout), so callers un-pack from dw_packed + 4 floats.
-template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false>
+template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false, bool FUSEA = false>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 {
     static_assert(NW == 4 || NW == 8, "waves");
     static_assert(!(FOLD && STEM), "the folded adjoint is the 1x1 convs'");
+    static_assert(!FUSEA || (FOLD && NW == 4 && WCHB == 32 && TK == 64 && TN % 16 == 0), "fused conv A: one 32-row MFMA tile per chunk, 64 output channels");
     static_assert(!STEM || (TN == 64 && TK == 256), "stem tile");
     constexpr int THREADS = NW * 64;
     constexpr int WAVES_N = NW / 2;                  // waves along n; 2 along k'
@@ -162,7 +167,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 
     u32x4 rdz[N_PS], ra[K_PS];
     unsigned rmk[FOLD ? N_PS : 1];       // FOLD: the 8 ReLU mask bits of rdz[q] (applied in stage(), so the loads stay in flight)
-    int rm[FOLD ? N_PS : 1];             // ... and the byte offset it came from (OOB: past the range)
     float csum[FOLD ? 8 : 1];            // ... column sums of this thread's 8 columns over all its rows
     if (FOLD) {
 #pragma unroll
@@ -181,7 +185,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
             const unsigned off = m < mhi ? (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 2u : OOB;
             rdz[q] = hbuf_load16(rsrc_dz, off);
             if (FOLD) {     // branch-free: a row past the range reads mask 0 through the bounds check (its data is 0 anyway) and its write-back is dropped
-                rm[q] = m < mhi ? (int)off : (int)OOB;
                 rmk[q] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc_mk, m < mhi ? (off >> 3) : OOB, 0, 0) : 0xffffu;
             }
         }
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
             }
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, int smc) {      // smc: first row of the chunk being staged (its write-back offsets are recomputed here: registers)
         if (FOLD) {
 #pragma unroll
             for (int q = 0; q < N_PS; ++q) {
@@ -235,7 +238,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
                 }
                 rdz[q] = v;
                 if (fold_owner) {
-                    if (do_wb) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_dz, (unsigned)rm[q], 0, 0);
+                    if (do_wb) {
+                        const int m = smc + n_row + q * N_RPP;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_dz, m < mhi ? (unsigned)((size_t)(m - mlo) * p.dzstride + n0 + n_col) * 2u : OOB, 0, 0);
+                    }
                     if (p.colsum_dz) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -262,8 +268,17 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // FUSEA: waves 0 / 1 hold the (c1 * W)^T fragments of their 32 output channels for the whole m range: lane (j = lane % 32, k half = lane / 32)
+    // of k step ks owns wa[j][16 ks + 8 half .. + 7] -- the MFMA B operand of  a_out tile [32 rows][32 j] += g[32 rows][16 n] x wa^T
+    bf16x8 wfr[FUSEA ? TN / 16 : 1];
+    if (FUSEA && wave < 2) {
+        const u16* wrow = p.wa + (size_t)(wave * 32 + (lane & 31)) * TN + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < TN / 16; ++ks) wfr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wrow + 16 * ks));
+    }
+
     fetch(mlo);
-    stage(0);
+    stage(0, mlo);
     __syncthreads();
     int buf = 0;
     for (int mc = mlo; mc < mhi; mc += WCHB) {
@@ -271,6 +286,27 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
         if (more) fetch(mc + WCHB);
         const char* dz_s = s_dz0 + buf * IMG_N;
         const char* a_s = s_a0 + buf * IMG_K;
+        if (FUSEA && wave < 2) {
+            // the chunk's g rows are in the LDS image as staged (masked): the MFMA A operand is a plain 16-byte read, row = lane % 32
+            f32x16 ca;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ca[r] = 0.f;
+            const char* grow = dz_s + (lane & 31) * PN + 16 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < TN / 16; ++ks) {
+                const bf16x8 ga = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(grow + 32 * ks));
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wfr[ks], ca, 0, 0, 0);
+            }
+            // accumulator r of lane l: row (r & 3) + 8 (r >> 2) + 4 (l / 32), column l % 32 -> 32 lanes store 64 contiguous bytes of one row
+            u16* ao = p.a_out + (size_t)mc * TK + wave * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                unsigned pk;
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(ca[r]), "v"(0.f));
+                if (mc + row < mhi) ao[(size_t)row * TK] = (u16)(pk & 0xffffu);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < WCHB / 16; ++s) {
             bf16x8 fa[TI], fb[TJ];
@@ -283,7 +319,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) stage(buf ^ 1);
+        if (more) stage(buf ^ 1, mc + WCHB);
         __syncthreads();
         buf ^= 1;
     }
@@ -537,7 +573,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
     }
 }
 
-template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false>
+template <int TN, int TK, int WCHB, int NW = 4, bool STEM = false, bool FOLD = false, bool FUSEA = false>
 int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
 {
     const int NT = a.Cout / TN, KT = a.K / TK;
@@ -549,7 +585,7 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
     split = (a.M + mchunk - 1) / mchunk;
     a.mchunk = (int)mchunk;
     const size_t lds = 2 * (size_t)WCHB * (pitch_of(TN) + pitch_of(TK));
-    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW, STEM, FOLD>;
+    auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW, STEM, FOLD, FUSEA>;
     if (lds > 65536) {
         static bool attr_done[64] = {};   // per instantiation, per device
         int dev = 0;
@@ -613,7 +649,7 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
     a.mchunk = 0;
     a.xstride = xstride ? xstride : Cin;
     a.dzstride = dzstride ? dzstride : Cout;
-    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr; a.slab = nullptr; a.slab_cs = nullptr;
+    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr; a.slab = nullptr; a.slab_cs = nullptr; a.wa = nullptr; a.a_out = nullptr;
     HN_REQUIRE(a.xstride >= Cin && a.dzstride >= Cout && a.xstride % 8 == 0 && a.dzstride % 8 == 0, "wgrad bf16: bad strides");
     HN_REQUIRE((double)B * Hi * Wi * a.xstride * 2.0 < 2147483648.0 && (double)a.M * a.dzstride * 2.0 < 4294967296.0,
                "wgrad bf16: batch too large for 32-bit tile offsets");
@@ -672,7 +708,8 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
 // rows leave as g), p_out [Cout][Cin] floats (accumulated; zeroed here unless prezeroed), colsum [Cout] doubles (accumulated: sum_m g[m][n]).
 // bmask == null: plain operands (the Gram matrix a^T a of an activation with its column sums: a_h == dy_h, Cin == Cout).
 int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
-                                   double* colsum, hipStream_t s, int prezeroed, float* slab, size_t slab_floats)
+                                   double* colsum, hipStream_t s, int prezeroed, float* slab, size_t slab_floats, const void* wa, void* a_out,
+                                   int write_back)
 {
     HN_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "wgrad bf16 fold: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
     HN_REQUIRE(M > 0 && (double)M * Cin * 2.0 < 2147483648.0 && (double)M * Cout * 2.0 < 4294967296.0, "wgrad bf16 fold: batch too large for 32-bit tile offsets");
@@ -684,7 +721,10 @@ int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, lo
     a.K = Cin;
     a.mchunk = 0;
     a.xstride = Cin; a.dzstride = Cout;
-    a.bmask = bmask; a.dz_wb = bmask ? reinterpret_cast<u16*>(dy_h) : nullptr; a.colsum_dz = colsum;
+    a.bmask = bmask; a.dz_wb = (bmask && write_back) ? reinterpret_cast<u16*>(dy_h) : nullptr; a.colsum_dz = colsum;
+    // wa / a_out (optional, Cout == 256 and Cin == 64 only: layer1): the conv-A part of the folded data gradient in the same pass (FUSEA)
+    a.wa = reinterpret_cast<const u16*>(wa); a.a_out = reinterpret_cast<u16*>(a_out);
+    HN_REQUIRE((wa == nullptr) == (a_out == nullptr) && (!wa || (Cout == 256 && Cin == 64 && !slab)), "wgrad bf16 fold: the fused conv A is the 256 x 64 shape's");
     // slab != null (slab_floats of scratch): the reproducible form -- partial tiles stored per m split and added in order (p_out and colsum are
     // then OVERWRITTEN, not accumulated); the launcher places slab_cs behind the tiles
     a.slab = slab; a.slab_cs = slab ? slab + slab_floats : nullptr;
@@ -704,6 +744,7 @@ int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, lo
     static const char* envw = getenv("HN_FOLD_WGS");
     const int wch = envc ? atoi(envc) : 32;
     const long target = envw ? atol(envw) : 1024;
+    if (wa) return launch_wgrad_h_w<256, 64, 32, 4, false, true, true>(a, s, target);
     if (Cout % 128 == 0 && Cin % 128 == 0)
         return wch == 64 ? launch_wgrad_h_w<128, 128, 64, 4, false, true>(a, s, target) : launch_wgrad_h_w<128, 128, 32, 4, false, true>(a, s, target);
     if (Cout % 128 == 0)
@@ -729,7 +770,7 @@ int hn_launch_stem_wgrad_bf16(const void* x4_h, const void* dz_h, float* dw_pack
     a.K = 256;
     a.mchunk = 0;
     a.xstride = 4; a.dzstride = 64;
-    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr; a.slab = nullptr; a.slab_cs = nullptr;
+    a.bmask = nullptr; a.dz_wb = nullptr; a.colsum_dz = nullptr; a.slab = nullptr; a.slab_cs = nullptr; a.wa = nullptr; a.a_out = nullptr;
     HN_REQUIRE((double)B * Hi * Wi * 8.0 < 2147483648.0 && (double)a.M * 128.0 < 4294967296.0, "stem wgrad bf16: batch too large for 32-bit tile offsets");
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)64 * 256 * sizeof(float), s));
     return launch_wgrad_h_w<64, 256, 32, 4, true>(a, s, 512);

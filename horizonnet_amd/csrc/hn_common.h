@@ -171,7 +171,10 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
                               int sh, int sw, hipStream_t s, int prezeroed = 0, int xstride = 0, int dzstride = 0);
 // BatchNorm-folded adjoint of the 1x1 convs (bn_fold.hip, conv_wgrad_bf16.hip)
 int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
-                                   double* colsum, hipStream_t s, int prezeroed, float* slab = nullptr, size_t slab_floats = 0);
+                                   double* colsum, hipStream_t s, int prezeroed, float* slab = nullptr, size_t slab_floats = 0,
+                                   const void* wa = nullptr, void* a_out = nullptr, int write_back = 1);
+int hn_launch_bn_fold_wa(const void* w_h, const float* gamma, const float* invstd, void* wa, int N, int K, hipStream_t s);
+void* hn_bn_fold_wa_ptr(void* ws, int N, int K);
 size_t hn_bn_fold_scratch_bytes(int N, int K);      // backward scratch of one unit (its head of hn_bn_fold_zero_bytes must be zeroed)
 size_t hn_bn_fold_zero_bytes(int K);
 size_t hn_bn_fold_keep_floats(int N, int K);         // per-unit storage kept from the forward to the backward: G | A | Wf | WG

@@ -422,7 +422,18 @@ struct FoldOut {
 // as g = dy * relu'(block output) (masked in place); without, it is read as is.  s1_src: null = this unit sums g itself (into its S1
 // slot), else the slot of the unit that already did (block 0: conv3 and the downsample branch see the same g).
 // ws: scratch of hn_bn_fold_scratch_bytes (one of the plan's two packed-weight scratches).
-int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* bmask, const double* s1_src, float* ws, FoldOut* out)
+// a_part (layer1's 256 x 64 shape, HN_FOLD_FUSEA != 0): the conv-A half of the data gradient, g (c1 * W), is taken in the P-GEMM's own pass over g
+// and lands there ([M][K] bf16; bn_fold_dgrad then only runs conv B on top of it); write_back = 0: g is NOT written back over dy (block 0 of layer1,
+// where nothing but the two fused P-GEMMs -- both masking on load -- reads it)
+bool bn_fold_fuse_a(const Ctx& c, const Unit& u)
+{
+    static const char* env = getenv("HN_FOLD_FUSEA");
+    const ConvLayer& cl = c.a.convs[u.ci];
+    return cl.cout == 256 && cl.cin == 64 && !(env && env[0] == '0');
+}
+
+int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* bmask, const double* s1_src, float* ws, FoldOut* out,
+                 float* a_part = nullptr, int write_back = 1)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
     const int N = cl.cout, K = cl.cin;
@@ -436,8 +447,14 @@ int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* 
     if (!fwd && (rc = hn_launch_bn_fold_gram(c.W + u.xh, u.M, K, keep, c.s))) return rc;
     // P = g^T a into the unit's weight-gradient scratch (zeroed with all the others at the start of the pass)
     float* P = c.W + u.wg;
-    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, g_io, P, u.M, K, N, bmask, s1_src ? nullptr : ds, c.s, 1))) return rc;
     const void* wh = reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci);
+    void* wa_early = nullptr;
+    if (a_part) {      // (c1 * W)^T does not depend on the batch sums: into its place in the scratch before the P-GEMM reads it
+        wa_early = hn_bn_fold_wa_ptr(ws, N, K);
+        if ((rc = hn_launch_bn_fold_wa(wh, c.bound(cl.bnkey + ".weight"), st + N, wa_early, N, K, c.s))) return rc;
+    }
+    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, g_io, P, u.M, K, N, bmask, s1_src ? nullptr : ds, c.s, 1, nullptr, 0, wa_early, a_part, write_back)))
+        return rc;
     if ((rc = hn_launch_bn_fold_finish(P, keep, fwd, s1_src ? s1_src : ds, ds, ds + N, wh, st, st + N, c.bound(cl.bnkey + ".weight"), (double)u.M, N, K, ws,
                                        c.P + c.a.ones_off, c.P + c.a.zeros_off, &out->wa, &out->shift_a, &out->wb, c.s)))
         return rc;
@@ -448,7 +465,8 @@ int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* 
 }
 
 // da = g (c1 * W) - a Q - r (+ add): two plain 1x1 convs; tmp and out are [M][K] bf16 gradient buffers (tmp != out)
-int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g, float* tmp, float* out)
+// a_done: tmp already holds g (c1 * W) (bn_fold_unit's a_part); conv B then also applies the shift -r
+int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g, float* tmp, float* out, int a_done = 0)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
     const int N = cl.cout, K = cl.cin;
@@ -456,9 +474,12 @@ int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g,
     memset(&d, 0, sizeof(d));
     d.B = c.B; d.Hi = u.Ho; d.Wi = u.Wo; d.Ho = u.Ho; d.Wo = u.Wo; d.KH = 1; d.KW = 1; d.sh = 1; d.sw = 1; d.relu = 0;
     d.scale = c.P + c.a.ones_off;
-    d.x = g; d.w = reinterpret_cast<const float*>(f.wa); d.shift = f.shift_a; d.res = nullptr; d.y = tmp; d.Cin = N; d.Cout = K; d.ldy = K;
-    if (int rc = hn_launch_conv_bf16(d, 0, c.s)) return rc;
-    d.x = c.W + u.xh; d.w = reinterpret_cast<const float*>(f.wb); d.shift = c.P + c.a.zeros_off; d.res = tmp; d.y = out; d.Cin = K; d.Cout = K; d.ldy = K;
+    if (!a_done) {
+        d.x = g; d.w = reinterpret_cast<const float*>(f.wa); d.shift = f.shift_a; d.res = nullptr; d.y = tmp; d.Cin = N; d.Cout = K; d.ldy = K;
+        if (int rc = hn_launch_conv_bf16(d, 0, c.s)) return rc;
+    }
+    d.x = c.W + u.xh; d.w = reinterpret_cast<const float*>(f.wb); d.shift = a_done ? f.shift_a : c.P + c.a.zeros_off; d.res = tmp; d.y = out;
+    d.Cin = K; d.Cout = K; d.ldy = K;
     return hn_launch_conv_bf16(d, 0, c.s);
 }
 
@@ -906,14 +927,20 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
                 FoldOut f3, fd;
                 const Unit* ud = j == 0 ? &pl.units[pl.dsu[li]] : nullptr;
                 double* ds3 = reinterpret_cast<double*>(W + pl.dstat) + pl.stat_bwd_first + u3.sb;
-                if (LIVE && (rc = bn_fold_unit(c, u3, Ga, reinterpret_cast<const unsigned char*>(W + u3.mk), nullptr, W + pl.wsA, &f3))) return rc;   // Ga: dOut -> g
-                if (LIVE && ud && (rc = bn_fold_unit(c, *ud, Ga, nullptr, ds3, W + pl.wsB, &fd))) return rc;
-                if (LIVE && (rc = bn_fold_dgrad(c, u3, f3, Ga, Gb, Gd))) return rc;             // d(t2) -> Gd
+                const unsigned char* mk3 = reinterpret_cast<const unsigned char*>(W + u3.mk);
+                const bool fa3 = bn_fold_fuse_a(c, u3), fad = ud && bn_fold_fuse_a(c, *ud);
+                // block 0 with both convs A fused (layer1): g has no other reader (no identity branch), so it is never written -- both P-GEMMs mask on load
+                const bool keep_dy = ud && fa3 && fad;
+                if (LIVE && (rc = bn_fold_unit(c, u3, Ga, mk3, nullptr, W + pl.wsA, &f3, fa3 ? Gb : nullptr, keep_dy ? 0 : 1))) return rc;   // Ga: dOut -> g (unless keep_dy)
+                if (LIVE && ud && (rc = bn_fold_unit(c, *ud, Ga, keep_dy ? mk3 : nullptr, ds3, W + pl.wsB, &fd, fad ? Gc : nullptr, 0))) return rc;
+                if (LIVE && (rc = bn_fold_dgrad(c, u3, f3, Ga, Gb, Gd, fa3 ? 1 : 0))) return rc;             // d(t2) -> Gd
                 if (LIVE && (rc = unit_backward(c, u2, Gd, W + u2.y, Gc, nullptr))) return rc;  // dz2 -> staging slot 0 (bf16 step: Gc is not written)
                 if (LIVE && (rc = unit_dgrad(c, u2, Gc, nullptr, Gb))) return rc;               // d(t1) -> Gb
                 if (LIVE && (rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> staging slot 0
                 if (ud) {
-                    if (LIVE && (rc = bn_fold_dgrad(c, *ud, fd, Ga, Gb, Gd))) return rc;        // downsample path -> Gd   (layer1: no height-compression add)
+                    // downsample path -> Gd   (layer1: no height-compression add); its fused conv A has been waiting in Gc (free until the next line's output)
+                    HN_REQUIRE(keep_dy || !fad, "train_backward: a fused conv A of the downsample branch needs the unmasked dOut (keep_dy)");
+                    if (LIVE && (rc = bn_fold_dgrad(c, *ud, fd, Ga, fad ? Gc : Gb, Gd, fad ? 1 : 0))) return rc;
                     HN_REQUIRE(li == 0, "train_backward: the folded downsample adjoint is layer1's");
                     if (LIVE && (rc = unit_dgrad(c, u1, Gd, Gd, Gc))) return rc;                // + conv1 path -> Gc
                 } else {
