@@ -638,13 +638,14 @@ int launch_cfg_d(const ConvArgs& a, hipStream_t s)
 // split-K tail: out[m][n] = act(scale[n] * sum_s partial[s][m][n] + shift[n]), slices summed in index order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const float* __restrict__ part, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ out, long MN4, int N4,
-                                                                long slice_elems, int S, int relu)
+                                                                long slice_elems, int S, int relu, const float* __restrict__ res)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN4; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i % N4) * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         for (int sl = 0; sl < S; ++sl) a += *reinterpret_cast<const f32x4*>(part + sl * slice_elems + i * 4);
         a = a * *reinterpret_cast<const f32x4*>(scale + n) + *reinterpret_cast<const f32x4*>(shift + n);
+        if (res) a += *reinterpret_cast<const f32x4*>(res + i * 4);      // (interactive regime only: the identity branch of a conv3, dense [M][N] rows)
         if (relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], 0.f);
@@ -789,16 +790,20 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
     // Deterministic split-K for the deep-K / tiny-M tails of the height-compression chains (ghc3.3: 16 tiles of 64x128
     // at the nominal batch, K = 4608).  The slice count depends on the layer's shape at the nominal batch of 32 only, never
     // on the actual M: the summation order -- and every output bit -- is the same for any batch size.
-    if (!d.res && !d.stat_sum && d.splitk_ws && d.Cout % 128 == 0 && !force_tile) {
+    // (a residual -- the conv3 units -- only in the interactive regime: at production batches those layers have thousands of tiles)
+    if ((!d.res || d.B <= 4) && !d.stat_sum && d.splitk_ws && d.Cout % 128 == 0 && !force_tile && (d.ldy == 0 || d.ldy == d.Cout)) {
         static const int sk_on = env_flag("HN_F32_SPLITK", 1);
         // ... with ONE exception, the interactive regime (reference inference.py:187-209 runs B = 1 + test-time augmentation): for B = 1 and
         // for B = 2..4 the nominal batch is 1 / 4 -- a single panorama gives ghc3.0 four tiles of 64 rows x 8 column tiles on 256 CUs
         // (505 us for 9.7 GFLOP); bits are the same within a regime, and differ between regimes only in the float32 summation order
         const long nominal = d.B == 1 ? 1 : (d.B <= 4 ? 4 : 32);
         const long t32 = (long)hn_cdiv(nominal * d.Ho * d.Wo, 64) * (d.Cout / 128);
-        int S = t32 >= 192 ? 1 : (int)(256 / t32);
-        if (S > 8) S = 8;
-        while (S > 1 && a.nk / S < 16) --S;
+        // a slice walks its chunks one load latency at a time (two LDS stages: ~1.8 us per 32-channel chunk when the chip is nearly empty), so
+        // in the interactive regime slices are SHORT (>= 4 chunks, up to 16 slices): 16-chunk slices put a 29 us floor under every small conv
+        const int smax = nominal < 32 ? 16 : 8, cmin = nominal < 32 ? 4 : 16;
+        int S = t32 >= 192 ? 1 : (int)(256 / t32);       // (512 / t32 in the interactive regime measured the same: 3.87 vs 3.91 ms at B = 1)
+        if (S > smax) S = smax;
+        while (S > 1 && a.nk / S < cmin) --S;
         if (!sk_on) S = 1;
         if (S > 1 && (size_t)S * a.M * d.Cout <= d.splitk_ws_floats) {
             ConvArgs b = a;
@@ -806,12 +811,13 @@ int hn_launch_conv(const ConvDesc& d, hipStream_t s)
             b.y = d.splitk_ws;
             b.relu = 0;
             b.ldy = d.Cout;
+            b.res = nullptr;                 // (added once, by the reduce)
             if (int rc = launch_cfg<64, 128, 2, 2, false>(b, s)) return rc;
             const long MN4 = (long)a.M * d.Cout / 4;
             long g = (MN4 + 255) / 256;
             if (g > 4096) g = 4096;
             hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((unsigned)g), dim3(256), 0, s, d.splitk_ws, d.scale, d.shift, d.y, MN4, d.Cout / 4,
-                               (long)a.M * d.Cout, S, d.relu);
+                               (long)a.M * d.Cout, S, d.relu, d.res);
             HN_LAUNCH_CHECK();
             return 0;
         }

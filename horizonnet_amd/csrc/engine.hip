@@ -131,7 +131,7 @@ constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 8 * 128 * 256;   // up to 8 slices 
 // ... but never less than 8 slices of the largest tile set the interactive regime (B <= 4) splits: layer4's 3x3 convs / ghc3.0 at 4 panoramas
 inline size_t splitk_ws_floats(int B)
 {
-    const size_t per = SPLITK_WS_FLOATS_PER_PANO * (size_t)B, floor_ = (size_t)8 * 4 * 512 * 512;
+    const size_t per = SPLITK_WS_FLOATS_PER_PANO * (size_t)B, floor_ = (size_t)16 * 4 * 512 * 512;       // 16 slices of layer4's 3x3 tile set at B = 4
     return per > floor_ ? per : floor_;
 }
 
@@ -458,7 +458,7 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
                                                      P + cd.scale_off, P + cd.shift_off, out, B, H, Wd, c3.cin, Hin, Win, cd.cin, stride,
                                                      c3.cout, s)))
                     return rc;
-            } else if ((rc = run_conv(e, P, c3, W + pl.t2, out, idt, B, H, Wd, 1, 1, 1, s)))
+            } else if ((rc = run_conv(e, P, c3, W + pl.t2, out, idt, B, H, Wd, 1, 1, 1, s, sk, skf)))
                 return rc;
             cur = out;
         }
