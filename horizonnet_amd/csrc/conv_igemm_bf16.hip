@@ -1633,7 +1633,11 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
             return 0;
         }
     }
-    if (!d.mask_out) {       // (the mask store lives in the 4-wave kernel's epilogue only)
+    if (d.mask_out) {        // (the mask store lives in the 4-wave and the ping-pong kernels' epilogues)
+        const char* ppe = getenv("HN_FOLD_PP");          // 0: 4-wave kernel everywhere (A/B runs)
+        const long t256 = d.Cout % 256 == 0 ? (long)hn_cdiv(a.M, 256) * (d.Cout / 256) : 0;
+        if (!(ppe && ppe[0] == '0') && d.KH == 1 && d.KW == 1 && t256 >= 224 && a.nk >= 2) return hn_launch_conv_bf16_pp(a, 0, 0, s);
+    } else {
         bool taken = false;
         const int rc = out_f32 ? dispatch_w8<true>(a, d.Cout, s, &taken) : dispatch_w8<false>(a, d.Cout, s, &taken);
         if (taken) return rc;

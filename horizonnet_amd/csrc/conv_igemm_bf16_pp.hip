@@ -355,6 +355,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
                         o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                         o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
                         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + colg) = o;
+                        if (p.mask_out) {      // (wave-uniform; the training forward's fused BatchNorm + ReLU, see conv_igemm_bf16_kernel) -- one more store per row:
+                                               //  the hand-counted vmcnt waits only ever see MORE operations outstanding than they assume, i.e. they over-wait
+                            unsigned mk = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) mk |= (v0[k] > 0.f ? 1u : 0u) << k | (v1[k] > 0.f ? 1u : 0u) << (8 + k);
+                            *reinterpret_cast<unsigned short*>(p.mask_out + (((size_t)m * p.ldy + colg) >> 2)) = (unsigned short)mk;
+                        }
                     }
                 }
             }

@@ -1059,7 +1059,8 @@ def test_train_step_bf16_b16_vs_reference(golden_dir):
         # measured (round 5): folded form loss 3e-5 rel, outputs 9.1e-3, norms: total 0.9968, median 1.2e-3, worst 6.6e-2 (the stem's weight: the end of
         # the backward chain); classical form total 0.9943, worst 1.4e-1 -- the folded adjoint is the MORE accurate of the two (it never rounds z
         # or dz to bf16).  Bounds = ~1.3 x measured.
-        worst_b, tot_b = (0.09, 0.005) if fold else (0.19, 0.008)
+        # (float atomics in the adjoint: the worst tensor moved 6.0e-2 .. 7.4e-2 (folded) and 9.7e-2 .. 1.4e-1 (classical) between runs)
+        worst_b, tot_b = (0.11, 0.006) if fold else (0.19, 0.008)
         ok &= abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) and d_out <= 0.012
         ok &= abs(tot - 1.0) <= tot_b and float(rel[big].max()) <= worst_b and float(np.median(rel[big])) <= 1.6e-3
     assert ok
