@@ -297,15 +297,25 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_bf16_kernel(WgradArgsH p)
                 const bf16x8 ga = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(grow + 32 * ks));
                 ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wfr[ks], ca, 0, 0, 0);
             }
-            // accumulator r of lane l: row (r & 3) + 8 (r >> 2) + 4 (l / 32), column l % 32 -> 32 lanes store 64 contiguous bytes of one row
-            u16* ao = p.a_out + (size_t)mc * TK + wave * 32 + (lane & 31);
+            // accumulator r of lane l: row (r & 3) + 8 (r >> 2) + 4 (l / 32), column l % 32 -> through the wave's private 2 KiB of LDS ([32 rows][32 bf16])
+            // and out as 16-byte pieces (two store instructions per wave instead of sixteen 2-byte ones)
+            u16* ws_ = reinterpret_cast<u16*>(hsmem + 2 * IMG_N + 2 * IMG_K + wave * 2048);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 unsigned pk;
                 asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(ca[r]), "v"(0.f));
-                if (mc + row < mhi) ao[(size_t)row * TK] = (u16)(pk & 0xffffu);
+                ws_[row * 32 + (lane & 31)] = (u16)(pk & 0xffffu);
             }
+            __builtin_amdgcn_wave_barrier();                 // (one wave: its LDS operations execute in issue order; this only pins the compiler)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pc = lane + 64 * h, row = pc >> 2, q = pc & 3;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ws_ + row * 32 + q * 8);
+                if (mc + row < mhi) *reinterpret_cast<u32x4*>(p.a_out + (size_t)(mc + row) * TK + wave * 32 + q * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int s = 0; s < WCHB / 16; ++s) {
@@ -584,7 +594,7 @@ int launch_wgrad_h_w(WgradArgsH a, hipStream_t s, long target)
     mchunk = (mchunk + WCHB - 1) / WCHB * WCHB;
     split = (a.M + mchunk - 1) / mchunk;
     a.mchunk = (int)mchunk;
-    const size_t lds = 2 * (size_t)WCHB * (pitch_of(TN) + pitch_of(TK));
+    const size_t lds = 2 * (size_t)WCHB * (pitch_of(TN) + pitch_of(TK)) + (FUSEA ? 4096 : 0);      // FUSEA: + two wave-private 2 KiB output slabs
     auto kern = conv_wgrad_bf16_kernel<TN, TK, WCHB, NW, STEM, FOLD, FUSEA>;
     if (lds > 65536) {
         static bool attr_done[64] = {};   // per instantiation, per device
