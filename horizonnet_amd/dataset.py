@@ -261,19 +261,25 @@ class DeviceBatcher:
     def batch(self, indices, rng=np.random):
         return self.device_half(*self.host_half(indices, rng))
 
-    def stream(self, index_batches, rng=np.random, depth=2):
+    def stream(self, index_batches, rng=np.random, depth=2, side_stream=True):
         """Iterate over batches with the host half running `depth` batches AHEAD in a background thread -- the role of
         the reference's DataLoader workers (train.py:153-160).  `index_batches`: an iterable of index arrays; the thread
         consumes it and `rng` in order, so a seeded run draws exactly what the unthreaded loop draws.  The engine's
-        forward / backward are single foreign calls (GIL released), so the thread genuinely overlaps with them."""
-        return _BatchStream(self, index_batches, rng, depth)
+        forward / backward are single foreign calls (GIL released), so the thread genuinely overlaps with them.
+        side_stream: the device half (augmentation gather, label rasterisation, uploads: ~1.5 ms of device time at B = 64) is enqueued on a
+        stream of its own and the caller's stream only waits for its event -- the host runs about a step ahead of the GPU, so the launches of
+        batch i + 1 execute beside the tail of step i (the recurrence's adjoint leaves most compute units idle) instead of behind it."""
+        return _BatchStream(self, index_batches, rng, depth, side_stream)
 
 
 class _BatchStream:
-    def __init__(self, owner, index_batches, rng, depth):
+    def __init__(self, owner, index_batches, rng, depth, side_stream=True):
         import queue
         import threading
         self.owner = owner
+        self.side = None
+        self.use_side = (bool(side_stream) and os.environ.get("HN_BATCH_SIDE_STREAM", "1") != "0"          # (0: A/B runs)
+                         and isinstance(getattr(owner, "data", None), torch.Tensor) and owner.data.is_cuda)
         self.q = queue.Queue(maxsize=max(1, int(depth)))
         self.stop = threading.Event()
 
@@ -305,7 +311,21 @@ class _BatchStream:
             raise StopIteration
         if isinstance(item, BaseException):
             raise item
-        return self.owner.device_half(*item)
+        if not self.use_side:
+            return self.owner.device_half(*item)
+        dev = self.owner.data.device
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self.side):
+            out = self.owner.device_half(*item)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        main.wait_event(done)
+        for t in out:                      # allocated on the side stream, consumed on the caller's: the allocator must not recycle them early
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
+        return out
 
     def close(self):
         self.stop.set()
