@@ -30,6 +30,14 @@ struct ConvArgsH {
     int sh_log2, sw_log2;
     int ca, cb, cHo, cWo;
     int tdh[3], tdw[3], ntdh, ntdw;
+    // optional (4-wave kernel, bf16 output; the training adjoint's conv B, train.hip: bn_fold_dgrad): the stored rows are the gradient dy of a
+    // BatchNorm + ReLU unit whose z / bit mask / saved mean / invstd are given -- the epilogue also takes that unit's reduce pass: per tile
+    // sum_m g and sum_m g * zhat (g = dy * mask) into bn_slab[tile row][2][Cout] (plain stores; hn_launch_slab_colsum adds the tiles in order)
+    const u16* bn_z;
+    const unsigned char* bn_mask;
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* bn_slab;
     unsigned char* mask_out;   // optional (4-wave kernel, bf16 output, ReLU): the ReLU bit mask of the stored rows, 4 bits per byte (element e -> byte e >> 2)
 #ifdef HN_CONV_TRACE
     unsigned long long* trace = nullptr;   // throw-away measurement builds only (tools/conv_trace.py): 8 stamps per workgroup / tile

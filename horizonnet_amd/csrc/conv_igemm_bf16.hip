@@ -272,6 +272,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
             }
         }
         f32x4 st1a = {0.f, 0.f, 0.f, 0.f}, st1b = st1a, st2a = st1a, st2b = st1a;     // BN statistics of this thread's 8 columns
+        // bn_z: the reduce pass of the unit whose gradient these rows are (zhat = z * za + zb, as bn_bwd_reduce_h8_kernel)
+        f32x4 za0 = st1a, za1 = st1a, zb0 = st1a, zb1 = st1a;
+        const bool bn_red = !OUT_F32 && !TR && p.bn_z != nullptr;
+        if (bn_red) {
+            za0 = *reinterpret_cast<const f32x4*>(p.bn_invstd + n0 + ccol);
+            za1 = *reinterpret_cast<const f32x4*>(p.bn_invstd + n0 + ccol + 4);
+            zb0 = -*reinterpret_cast<const f32x4*>(p.bn_mean + n0 + ccol) * za0;
+            zb1 = -*reinterpret_cast<const f32x4*>(p.bn_mean + n0 + ccol + 4) * za1;
+        }
         const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol);
         const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.scale + n0 + ccol + 4);
         const f32x4 sf0 = *reinterpret_cast<const f32x4*>(p.shift + n0 + ccol);
@@ -330,6 +339,24 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                         o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                         o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
                         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + out_pix(m) * p.ldy + n0 + ccol) = o;
+                        if (bn_red) {           // (wave-uniform) g = stored (rounded) dy where the unit's ReLU passed; sums of g and g * zhat
+                            const size_t e = (size_t)m * p.Cout + n0 + ccol;
+                            const u32x4 zv = *reinterpret_cast<const u32x4*>(p.bn_z + e);
+                            const unsigned mm = *reinterpret_cast<const unsigned short*>(p.bn_mask + (e >> 2));
+                            const unsigned mk8 = (mm & 0xfu) | ((mm >> 4) & 0xf0u);
+                            f32x4 g0, g1, z0, z1;
+                            g0[0] = bf16_lo(o[0]); g0[1] = bf16_hi(o[0]); g0[2] = bf16_lo(o[1]); g0[3] = bf16_hi(o[1]);
+                            g1[0] = bf16_lo(o[2]); g1[1] = bf16_hi(o[2]); g1[2] = bf16_lo(o[3]); g1[3] = bf16_hi(o[3]);
+                            z0[0] = bf16_lo(zv[0]); z0[1] = bf16_hi(zv[0]); z0[2] = bf16_lo(zv[1]); z0[3] = bf16_hi(zv[1]);
+                            z1[0] = bf16_lo(zv[2]); z1[1] = bf16_hi(zv[2]); z1[2] = bf16_lo(zv[3]); z1[3] = bf16_hi(zv[3]);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                g0[k] = ((mk8 >> k) & 1u) ? g0[k] : 0.f;
+                                g1[k] = ((mk8 >> (4 + k)) & 1u) ? g1[k] : 0.f;
+                            }
+                            st1a += g0; st1b += g1;
+                            st2a += g0 * (z0 * za0 + zb0); st2b += g1 * (z1 * za1 + zb1);
+                        }
                         if (p.mask_out) {        // (wave-uniform) the training forward's fused BatchNorm + ReLU: the adjoint's bit mask, v > 0 as affine_act_kernel has it
                             unsigned mk = 0;
 #pragma unroll
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
             }
             HN_TR_STAMP(tr_wg, 3 + h);
         }
-        if (p.stat_sum) {        // see conv_igemm_f32.hip: per-channel sums of the stored tile -> one f64 atomic per channel
+        if (p.stat_sum || bn_red) {        // see conv_igemm_f32.hip: per-channel sums of the stored tile -> one f64 atomic per channel
             __syncthreads();
             float* red = cs;                         // [2][RPP][BN]
             if (crow < RPP) {
@@ -359,6 +386,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsH p)
                     a2 += red[(RPP + r) * BN + tid];
                 }
             }
+            if (bn_red) {            // per-tile partials, plain stores: [tile row mt][S1 | S2][Cout]
+                if (tid < BN) {
+                    p.bn_slab[((size_t)mt * 2) * p.Cout + n0 + tid] = a1;
+                    p.bn_slab[((size_t)mt * 2 + 1) * p.Cout + n0 + tid] = a2;
+                }
+            } else
             hn_stat_commit(p.stat_sum, p.stat_sq, p.stat_rep, p.Cout, n0, BN, tid, a1, a2);
         }
     };
@@ -1524,6 +1557,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
     }
 }
 
+// the 4-wave kernel a conv with the fused BatchNorm reduce runs on (its epilogue holds the sums): 128-row tiles, 128 or 64 columns
+inline int dispatch_bn(const ConvArgsH& a, int Cout, hipStream_t s)
+{
+    if (Cout % 128 == 0) return launch_cfg_h<128, 128, 2, 2, false, false, false>(a, s);
+    return launch_cfg_h<128, 64, 2, 2, false, false, false>(a, s);
+}
+
+// out[i] += sum over this block's share of the tiles of slab[t][i] (double; out zeroed by the caller): blockIdx.y = tile range, 16 elements x 16
+// tile lanes per workgroup, eight loads in flight per lane
+__global__ __launch_bounds__(256) void slab_colsum_kernel(const float* __restrict__ slab, int tiles, int n, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int per = (tiles + gridDim.y - 1) / gridDim.y;
+    const int t0 = blockIdx.y * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    for (int b = blockIdx.x; b * 16 < n; b += gridDim.x) {
+        const int i = b * 16 + il;
+        double t = 0.0;
+        if (i < n) {
+            int q = t0 + sl;
+            for (; q + 7 * 16 < t1; q += 8 * 16) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(q + 16 * u) * n + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += (double)v[u];
+            }
+            for (; q < t1; q += 16) t += (double)slab[(size_t)q * n + i];
+        }
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (sl == 0 && i < n) {
+            for (int u = 1; u < 16; ++u) t += red[u * 16 + il];
+            atomicAdd(out + i, t);
+        }
+        __syncthreads();
+    }
+}
+
 inline unsigned grid_for(long total, long cap = 256L * 16)
 {
     long g = (total + 255) / 256;
@@ -1538,6 +1610,19 @@ inline unsigned grid_for(long total, long cap = 256L * 16)
 static unsigned long long* g_conv_trace = nullptr;
 extern "C" int hn_debug_conv_trace(void* buf) { g_conv_trace = static_cast<unsigned long long*>(buf); return 0; }
 #endif
+
+int hn_conv_bf16_bn_tile_rows(int Cout, long M) { (void)Cout; (void)M; return 128; }
+
+int hn_launch_slab_colsum(const float* slab, int tiles, int n, double* out, hipStream_t s)
+{
+    int g = (n + 15) / 16;
+    if (g > 4096) g = 4096;
+    int gy = tiles / 128;                  // >= 128 tiles (8 per lane) per block
+    gy = gy < 1 ? 1 : (gy > 128 ? 128 : gy);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3((unsigned)g, (unsigned)gy), dim3(256), 0, s, slab, tiles, n, out);
+    HN_LAUNCH_CHECK();
+    return 0;
+}
 
 // d.x / d.w / d.res / d.y are reinterpreted as bf16 buffers (d.y as f32 when out_f32)
 int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
@@ -1558,6 +1643,10 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.sh_log2 = a.sw_log2 = a.ca = a.cb = a.cHo = a.cWo = a.ntdh = a.ntdw = 0;
     for (int i = 0; i < 3; ++i) a.tdh[i] = a.tdw[i] = 0;
     a.mask_out = d.mask_out;
+    a.bn_z = reinterpret_cast<const u16*>(d.bn_z); a.bn_mask = d.bn_mask; a.bn_mean = d.bn_mean; a.bn_invstd = d.bn_invstd; a.bn_slab = d.bn_slab;
+    HN_REQUIRE(!d.bn_z || (!out_f32 && d.bn_mask && d.bn_mean && d.bn_invstd && d.bn_slab && !d.stat_sum && !d.stem && !d.mask_out && d.KH == 1 && d.KW == 1 &&
+                           d.sh == 1 && d.sw == 1 && a.ldy == d.Cout && d.Cout % 64 == 0),
+               "conv bf16: the fused BatchNorm reduce goes with a dense 1x1 bf16 conv");
     HN_REQUIRE(!d.mask_out || (!out_f32 && d.relu && !d.stem && !d.stat_sum && d.Cout % 8 == 0), "conv bf16: mask_out goes with a bf16 ReLU output");
 #ifdef HN_CONV_TRACE
     a.trace = g_conv_trace;
@@ -1579,6 +1668,7 @@ int hn_launch_conv_bf16(const ConvDesc& d, int out_f32, hipStream_t s)
     a.K = d.KH * d.KW * d.Cin;
     a.nk = a.K / BKE;
     HN_REQUIRE(256.0 * a.K * 2.0 < 2147483648.0, "conv bf16: K too large");
+    if (d.bn_z) return dispatch_bn(a, d.Cout, s);
     // Split-K on the dw-reuse kernel for the 3x3 convs that give a 256-CU part only 64 .. 160 tiles of 256 x 256 at the nominal batch
     // (ghc3.0 / ghc3.1 / ghc2.1, layer4.*.conv2): 2 or 4 K slices of whole (channel chunk, filter row) steps as float32 partial
     // tiles + the ordered reduce below.  The slice count is a function of the layer's shape at the nominal batch of 32 ONLY (never of

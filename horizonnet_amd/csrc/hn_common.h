@@ -87,6 +87,11 @@ struct ConvDesc {
                          // memory side (0.06-0.25 ms per layer1 conv).  0 / 1: straight into [sum | sq].  The slot must be zero at launch.
     float* splitk_ws;    // optional scratch for split-K partial tiles (bf16 forward; see hn_launch_conv_bf16)
     size_t splitk_ws_floats;
+    const void* bn_z;          // bf16 convs only, see ConvArgsH: the reduce pass of the BatchNorm unit whose gradient this conv produces, in its epilogue
+    const unsigned char* bn_mask;
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* bn_slab;            // [ceil(M / tile rows)][2][Cout] floats; the tile-row count is returned by hn_conv_bf16_bn_tile_rows
     unsigned char* mask_out;   // bf16 convs only: also store the ReLU bit mask of the output (affine_act_kernel's format); forces the 4-wave kernel
     int transposed;      // 1 = data-gradient mode: x = dY [B][Hi][Wi][Cin(=Cout of the fwd conv)], y = dX [B][Ho][Wo][Cout(=Cin fwd)],
                          //     w packed [Cin_fwd][kh][kw][Cout_fwd]; sh/sw/ph/pw are the forward conv's
@@ -173,6 +178,8 @@ int hn_launch_conv_wgrad_bf16(const void* x_h, const void* dz_h, float* dw_packe
 int hn_launch_conv_wgrad_bf16_fold(const void* a_h, void* dy_h, float* p_out, long M, int Cin, int Cout, const unsigned char* bmask,
                                    double* colsum, hipStream_t s, int prezeroed, float* slab = nullptr, size_t slab_floats = 0,
                                    const void* wa = nullptr, void* a_out = nullptr, int write_back = 1);
+int hn_conv_bf16_bn_tile_rows(int Cout, long M);                                    // rows per tile of the kernel a bn_z conv is dispatched to
+int hn_launch_slab_colsum(const float* slab, int tiles, int n, double* out, hipStream_t s);   // out[i] += sum_t slab[t][i] in double (out zeroed by the caller)
 int hn_launch_bn_fold_wa(const void* w_h, const float* gamma, const float* invstd, void* wa, int N, int K, hipStream_t s);
 void* hn_bn_fold_wa_ptr(void* ws, int N, int K);
 size_t hn_bn_fold_scratch_bytes(int N, int K);      // backward scratch of one unit (its head of hn_bn_fold_zero_bytes must be zeroed)

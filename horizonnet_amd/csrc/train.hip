@@ -262,8 +262,10 @@ int bn_fold_forward(const Ctx& c, const Unit& u, const float* res_h, int relu, f
 // `pool_src` (bf16 [B][Hi/2][Wi/2][C], position words at pl.pidx) on the fly (hn_launch_bn_bwd_pool)
 // bn_done: the BatchNorm adjoint of this unit (its sums and its bf16 dz in staging slot dzh_slot) was already produced by
 // bn_backward_dual below; only the parameter gradients remain (dy / dz / dpre are not touched)
+// sums_done: S1 / S2 of this unit are already in its slots (the producing conv's epilogue took the reduce pass: bn_fold_dgrad); the apply pass and
+// the parameter gradients remain
 int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* ymask, float* dz, float* dpre, int dzh_slot = 0, int dy_bf16 = -1,
-                  const float* pool_src = nullptr, int bn_done = 0)
+                  const float* pool_src = nullptr, int bn_done = 0, int sums_done = 0)
 {
     if (dy_bf16 < 0) dy_bf16 = c.gh() ? 1 : 0;
     // bf16 mode: dz is also written as bf16 (slot 0 / 1 of the staging buffers) for this unit's data-gradient GEMM
@@ -289,7 +291,7 @@ int unit_backward(const Ctx& c, const Unit& u, const float* dy, const float* yma
                                         ds + C, dz_h, C, 0, c.s)))
             return rc;
     } else
-    if ((rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, dy_bf16, c.s))) return rc;
+    if (!sums_done && (rc = hn_launch_bn_bwd_reduce(dy, bmask, c.W + u.z, st, st + C, ds, ds + C, u.M, C, c.e->train_bf16, dy_bf16, c.s))) return rc;
     // S2 / S1 are the BatchNorm weight / bias gradients: double -> float into the flat gradient buffer, deferred to the
     // segment's one batched launch (the sums stay untouched until then) ...
     const bool defer = c.jobs != nullptr && !c.bn_eval(u);
@@ -466,7 +468,16 @@ int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* 
 
 // da = g (c1 * W) - a Q - r (+ add): two plain 1x1 convs; tmp and out are [M][K] bf16 gradient buffers (tmp != out)
 // a_done: tmp already holds g (c1 * W) (bn_fold_unit's a_part); conv B then also applies the shift -r
-int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g, float* tmp, float* out, int a_done = 0)
+// red_unit (HN_FOLD_REDUCE != 0): the BatchNorm + ReLU unit whose output gradient `out` is (conv2 of the block): conv B's epilogue also takes
+// that unit's reduce pass (sum g, sum g * zhat per tile into a slab behind `slab`, added by hn_launch_slab_colsum into the unit's zeroed slots)
+bool bn_fold_reduce_on()
+{
+    static const char* env = getenv("HN_FOLD_REDUCE");
+    return !(env && env[0] == '0');
+}
+
+int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g, float* tmp, float* out, int a_done = 0, const Unit* red_unit = nullptr,
+                  float* slab = nullptr)
 {
     const ConvLayer& cl = c.a.convs[u.ci];
     const int N = cl.cout, K = cl.cin;
@@ -480,6 +491,16 @@ int bn_fold_dgrad(const Ctx& c, const Unit& u, const FoldOut& f, const float* g,
     }
     d.x = c.W + u.xh; d.w = reinterpret_cast<const float*>(f.wb); d.shift = a_done ? f.shift_a : c.P + c.a.zeros_off; d.res = tmp; d.y = out;
     d.Cin = K; d.Cout = K; d.ldy = K;
+    if (red_unit) {
+        const Unit& r = *red_unit;
+        HN_REQUIRE(c.a.convs[r.ci].cout == K && r.M == u.M && r.relu && !c.bn_eval(r), "bn_fold_dgrad: the fused reduce is the block's conv2 unit's");
+        const float* rst = c.W + r.st;
+        d.bn_z = c.W + r.z; d.bn_mask = reinterpret_cast<const unsigned char*>(c.W + r.mk); d.bn_mean = rst; d.bn_invstd = rst + K; d.bn_slab = slab;
+        if (int rc = hn_launch_conv_bf16(d, 0, c.s)) return rc;
+        const int tiles = hn_cdiv(u.M, hn_conv_bf16_bn_tile_rows(K, u.M));
+        double* rds = reinterpret_cast<double*>(c.W + c.pl.dstat) + c.pl.stat_bwd_first + r.sb;
+        return hn_launch_slab_colsum(slab, tiles, 2 * K, rds, c.s);          // [S1 | S2] are adjacent in the unit's slot
+    }
     return hn_launch_conv_bf16(d, 0, c.s);
 }
 
@@ -933,8 +954,10 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
                 const bool keep_dy = ud && fa3 && fad;
                 if (LIVE && (rc = bn_fold_unit(c, u3, Ga, mk3, nullptr, W + pl.wsA, &f3, fa3 ? Gb : nullptr, keep_dy ? 0 : 1))) return rc;   // Ga: dOut -> g (unless keep_dy)
                 if (LIVE && ud && (rc = bn_fold_unit(c, *ud, Ga, keep_dy ? mk3 : nullptr, ds3, W + pl.wsB, &fd, fad ? Gc : nullptr, 0))) return rc;
-                if (LIVE && (rc = bn_fold_dgrad(c, u3, f3, Ga, Gb, Gd, fa3 ? 1 : 0))) return rc;             // d(t2) -> Gd
-                if (LIVE && (rc = unit_backward(c, u2, Gd, W + u2.y, Gc, nullptr))) return rc;  // dz2 -> staging slot 0 (bf16 step: Gc is not written)
+                // conv B's epilogue takes conv2's reduce pass (its slab: behind the fold scratch of wsA, which needs < 32 MB)
+                const bool red2 = bn_fold_reduce_on() && !c.bn_eval(u2) && (size_t)hn_cdiv(u3.M, 128) * 2 * a.convs[u2.ci].cout <= (size_t)1024 * 18432 - ((size_t)8 << 20);
+                if (LIVE && (rc = bn_fold_dgrad(c, u3, f3, Ga, Gb, Gd, fa3 ? 1 : 0, red2 ? &u2 : nullptr, W + pl.wsA + ((size_t)8 << 20)))) return rc;   // d(t2) -> Gd
+                if (LIVE && (rc = unit_backward(c, u2, Gd, W + u2.y, Gc, nullptr, 0, -1, nullptr, 0, red2 ? 1 : 0))) return rc;  // dz2 -> staging slot 0 (bf16 step: Gc is not written)
                 if (LIVE && (rc = unit_dgrad(c, u2, Gc, nullptr, Gb))) return rc;               // d(t1) -> Gb
                 if (LIVE && (rc = unit_backward(c, u1, Gb, W + u1.y, Gd, nullptr))) return rc;  // dz1 -> staging slot 0
                 if (ud) {
