@@ -60,7 +60,9 @@ constexpr int PP_STAMP_CHUNKS = 24;
 #define pp_bar() do { if (!(abl & 4)) pp_bar_raw(); else __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // PRIO: s_setprio(1) around the MFMA block of a phase (the partner wave is in its load block meanwhile)
-template <bool OUT_F32, bool PRIO>
+// MASK: the training forward's fused BatchNorm + ReLU conv (bn_fold_forward): one more 2-byte store per row piece -- its own instantiation, so the
+// inference kernel's code and register allocation are exactly what they were without it
+template <bool OUT_F32, bool PRIO, bool MASK = false>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
                         o[0] = pack_bf16(v0[0], v0[1]); o[1] = pack_bf16(v0[2], v0[3]);
                         o[2] = pack_bf16(v1[0], v1[1]); o[3] = pack_bf16(v1[2], v1[3]);
                         *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.y) + (size_t)m * p.ldy + colg) = o;
-                        if (p.mask_out) {      // (wave-uniform; the training forward's fused BatchNorm + ReLU, see conv_igemm_bf16_kernel) -- one more store per row:
+                        if (MASK) {            // (the training forward's fused BatchNorm + ReLU, see conv_igemm_bf16_kernel) -- one more store per row:
                                                //  the hand-counted vmcnt waits only ever see MORE operations outstanding than they assume, i.e. they over-wait
                             unsigned mk = 0;
 #pragma unroll
@@ -475,10 +477,10 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp_kernel(ConvArgsH p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus (out-of-range) pieces of the loader
 }
 
-template <bool OUT_F32, bool PRIO>
+template <bool OUT_F32, bool PRIO, bool MASK = false>
 int launch_pp(const ConvArgsH& a, hipStream_t s)
 {
-    auto kern = conv_igemm_bf16_pp_kernel<OUT_F32, PRIO>;
+    auto kern = conv_igemm_bf16_pp_kernel<OUT_F32, PRIO, MASK>;
     static bool attr_done[64] = {};   // per instantiation, per device
     static int n_cu[64] = {};
     int dev = 0;
@@ -503,6 +505,10 @@ int hn_launch_conv_bf16_pp(const ConvArgsH& a, int out_f32, int variant, hipStre
 {
     HN_REQUIRE(a.Cout % 256 == 0 && a.nk >= 2 && a.ksplit <= 1 && a.stat_sum == nullptr, "conv bf16 (ping-pong): Cout %% 256, K >= 128, forward only");
     HN_REQUIRE(!out_f32 || a.res == nullptr, "conv bf16 (ping-pong): no residual with float32 output");
+    if (a.mask_out) {
+        HN_REQUIRE(!out_f32 && a.relu, "conv bf16 (ping-pong): the ReLU bit mask goes with a bf16 ReLU output");
+        return launch_pp<false, false, true>(a, s);
+    }
     if (out_f32) return (variant & 1) ? launch_pp<true, true>(a, s) : launch_pp<true, false>(a, s);
     return (variant & 1) ? launch_pp<false, true>(a, s) : launch_pp<false, false>(a, s);
 }
