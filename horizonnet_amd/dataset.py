@@ -261,14 +261,18 @@ class DeviceBatcher:
     def batch(self, indices, rng=np.random):
         return self.device_half(*self.host_half(indices, rng))
 
-    def stream(self, index_batches, rng=np.random, depth=2, side_stream=True):
+    def stream(self, index_batches, rng=np.random, depth=2, side_stream=False):
         """Iterate over batches with the host half running `depth` batches AHEAD in a background thread -- the role of
         the reference's DataLoader workers (train.py:153-160).  `index_batches`: an iterable of index arrays; the thread
         consumes it and `rng` in order, so a seeded run draws exactly what the unthreaded loop draws.  The engine's
         forward / backward are single foreign calls (GIL released), so the thread genuinely overlaps with them.
         side_stream: the device half (augmentation gather, label rasterisation, uploads: ~1.5 ms of device time at B = 64) is enqueued on a
         stream of its own and the caller's stream only waits for its event -- the host runs about a step ahead of the GPU, so the launches of
-        batch i + 1 execute beside the tail of step i (the recurrence's adjoint leaves most compute units idle) instead of behind it."""
+        batch i + 1 execute beside the tail of step i (the recurrence's adjoint leaves most compute units idle) instead of behind it: +0.5 % on the
+        step.  OFF by default: the first torch side stream of a process creates torch's pool of 32 HIP streams, which re-maps every stream of the
+        process onto the (4) hardware queues -- the engine's trunk / branch / head streams of a LATER pipelined inference in the same process then
+        share queues and lose their overlap (bench.py: the layout leg behind the training leg 4900 -> 3900 panoramas/s, also after the stream was
+        released)."""
         return _BatchStream(self, index_batches, rng, depth, side_stream)
 
 
@@ -278,7 +282,7 @@ class _BatchStream:
         import threading
         self.owner = owner
         self.side = None
-        self.use_side = (bool(side_stream) and os.environ.get("HN_BATCH_SIDE_STREAM", "1") != "0"          # (0: A/B runs)
+        self.use_side = ((bool(side_stream) or os.environ.get("HN_BATCH_SIDE_STREAM", "0") == "1")          # (1: A/B runs)
                          and isinstance(getattr(owner, "data", None), torch.Tensor) and owner.data.is_cuda)
         self.q = queue.Queue(maxsize=max(1, int(depth)))
         self.stop = threading.Event()
@@ -328,6 +332,12 @@ class _BatchStream:
         return out
 
     def close(self):
+        if self.side is not None:
+            # blocks the side stream allocated stay in ITS pool of torch's caching allocator: whatever runs next on the caller's stream (a validation
+            # pass, inference) would have to hipMalloc afresh (bench.py: the layout leg behind the training leg lost 20 %).  Hand them back.
+            self.side.synchronize()
+            self.side = None
+            torch.cuda.empty_cache()
         self.stop.set()
         while self.thread.is_alive():
             try:
