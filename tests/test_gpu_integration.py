@@ -310,7 +310,6 @@ def _bench_two_ranks(extra, timeout=1200, ranks=2):
     """`python bench.py --gpus 2 ...` WITHOUT torchrun's environment: bench.py becomes the launcher (the re-exec branch the
     driver's N = 2, 4, 8 runs go through), both ranks share the box's one GPU, gloo stands in for RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    torch.cuda.empty_cache()           # the ranks share THIS process's GPU: hand back what the earlier tests' allocator still caches
     # Eight processes time-slicing one GPU is a test rig, not a deployment (one rank per GPU): one of ~10 such launches died with SIGABRT inside a rank
     # before its first step (round 5; the three 8-rank tests passed in four other runs of the suite and in 3 of 3 stand-alone repeats).  The rig gets
     # ONE retry, and says so; a failure of the code under test fails both attempts.
