@@ -454,6 +454,12 @@ def test_train_step_bf16_matrix_cores():
     # switching back restores the float32 path
     net.train_precision = "f32"
     b32, _ = net(x.to(DEV))
+    torch.cuda.synchronize()
+    assert net.hip_status(DEV) == 0
+    # (one full-suite run in round 5 saw this forward 0.12 off, never reproduced stand-alone: the repeat tells a deterministic wrong
+    # result from a timing-dependent one if it ever shows again)
+    b32_again, _ = net(x.to(DEV))
+    print("[parity] f32 train fwd after bf16: repeat differs by %.3e" % float((b32_again - b32).abs().max()))
     _, rbf, _ = _oracle_grads(sd, x, wb, wc, torch.float32)
     assert report("f32 train fwd after bf16", b32.detach().cpu().numpy(), rbf.numpy(), 1e-3)
 
