@@ -20,7 +20,7 @@ from horizonnet_amd import utils as hutils  # noqa: E402
 from horizonnet_amd.dataset import DeviceBatcher, PanoCorBonDataset  # noqa: E402
 from oracle.weights import make_state_dict  # noqa: E402
 
-from hiputil import DEV, report  # noqa: E402
+from hiputil import DEV, bench_ranks, report  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -306,29 +306,10 @@ def test_bench_self_launch_under_rccl():
     assert rec["rccl"]["backend"] == "nccl" and rec["rccl"]["world_size_seen_by_rccl"] == 1 and rec["value"] > 0
 
 
-def _bench_two_ranks(extra, timeout=1200, ranks=2):
-    """`python bench.py --gpus 2 ...` WITHOUT torchrun's environment: bench.py becomes the launcher (the re-exec branch the
-    driver's N = 2, 4, 8 runs go through), both ranks share the box's one GPU, gloo stands in for RCCL."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    # Eight processes time-slicing one GPU is a test rig, not a deployment (one rank per GPU): one of ~10 such launches died with SIGABRT inside a rank
-    # before its first step (round 5; the three 8-rank tests passed in four other runs of the suite and in 3 of 3 stand-alone repeats).  The rig gets
-    # ONE retry, and says so; a failure of the code under test fails both attempts.
-    for attempt in range(2 if ranks > 2 else 1):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--share-gpu"] + extra,
-                             capture_output=True, text=True, timeout=timeout, env=env)
-        if out.returncode == 0:
-            break
-        print("[rig] %d-rank launch attempt %d failed (rc %d): %s" % (ranks, attempt + 1, out.returncode, out.stderr[-1500:]))
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "exactly ONE JSON line (rank 0 only): %d" % len(lines)
-    return json.loads(lines[0])
-
-
 def test_bench_two_rank_self_launch_forward():
     """the self-launch branch of bench.py had never executed.  Forward mode, 2 ranks x B = 2: rendezvous on
     127.0.0.1, the report of who is in the job, shard_for_rank, barrier + max-over-ranks timing, rank-0-only printing."""
-    rec = _bench_two_ranks(["--batch", "2", "--steps", "2", "--warmup", "1"])
+    rec = bench_ranks(["--batch", "2", "--steps", "2", "--warmup", "1"])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert rec["rccl"]["world_size_seen_by_rccl"] == 2 and len(rec["rccl"]["devices"]) == 2 and rec["rccl"]["backend"] == "gloo"
     assert "bf16_mode" not in rec and "layout" not in rec                  # the extra legs belong to the single-GPU run
@@ -337,7 +318,7 @@ def test_bench_two_rank_self_launch_forward():
 def test_bench_two_rank_self_launch_train():
     """configs[3] code path at 2 ranks: per-rank rooms, broadcast of rank 0's weights, segmented backward with the bucketed
     all-reduce of every gradient range, the overlap block (step with / without the exchange)."""
-    rec = _bench_two_ranks(["--mode", "train", "--dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"])
+    rec = bench_ranks(["--mode", "train", "--dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0 and np.isfinite(rec["final_loss"])
     assert rec["allreduce_overlap"]["ms_per_step_with_allreduce"] > 0 and rec["rccl"]["world_size_seen_by_rccl"] == 2
 
@@ -345,7 +326,7 @@ def test_bench_two_rank_self_launch_train():
 def test_bench_two_rank_train_bf16_wire_and_deferred_mean():
     """The flags an 8-GPU run would use, through bench.py itself: gradients travel as bf16 (--allreduce-dtype bf16), FusedAdam takes the
     1 / world mean into its own launch (defer_grad_mean), labels rasterised on the device; plus the traced step's per-bucket table."""
-    rec = _bench_two_ranks(["--mode", "train", "--dtype", "bf16", "--allreduce-dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"])
+    rec = bench_ranks(["--mode", "train", "--dtype", "bf16", "--allreduce-dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"])
     cfg = rec["config"]
     assert cfg["allreduce_dtype"] == "bf16" and cfg["defer_grad_mean"] is True and cfg["labels"].startswith("device")
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and np.isfinite(rec["final_loss"])
@@ -358,45 +339,11 @@ def test_bench_two_rank_train_bf16_wire_and_deferred_mean():
 def test_bench_two_rank_self_launch_layout():
     """configs[4] sharded over 2 ranks: every rank renders and infers its own contiguous shard, rank 0 merges the layouts
     and evaluates all of them against the reference's -- same parity as the single-rank run on the same panoramas."""
-    rec = _bench_two_ranks(["--mode", "layout", "--panoramas", "96", "--batch", "16"])
+    rec = bench_ranks(["--mode", "layout", "--panoramas", "96", "--batch", "16"])
     assert rec["n_gpus"] == 2 and rec["render_crc_mismatches"] == 0 and rec["host_cores_per_rank"] >= 1
     par = rec["iou3d_parity_vs_reference_inference"]
     assert par["f32"]["iou3d_failed"] == 0 and par["f32"]["iou3d_mean"] > 0.9999 and par["f32"]["corner_count_mismatches"] == 0
     assert par["bf16"]["iou3d_mean"] > 0.99
-
-
-# ---- world size 8 without an 8-GPU node (VERDICT r4 item 6): the driver's N = 8 command line, eight processes on the box's one GPU ----
-def test_bench_eight_rank_self_launch_forward():
-    """`bench.py --gpus 8` re-exec, rendezvous of eight ranks on 127.0.0.1, pin_rank_affinity at (cores / 8) per rank, eight engines and
-    workspaces alive together, shard_for_rank over 8, barrier + max-over-ranks timing, one JSON line, clean teardown."""
-    rec = _bench_two_ranks(["--batch", "2", "--steps", "2", "--warmup", "1"], ranks=8)
-    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 16 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert rec["rccl"]["world_size_seen_by_rccl"] == 8 and len(rec["rccl"]["devices"]) == 8
-    assert rec["config"]["parallelism"].startswith("dp8")
-
-
-def test_bench_eight_rank_self_launch_train():
-    """configs[3] at world size 8 (B = 1 per rank, bf16 step, gradients on the wire as bf16, deferred mean): per-rank rooms, broadcast of
-    rank 0's weights, the five-segment backward with its seven all-reduce buckets (traced table), the status word MAX-reduced, teardown."""
-    rec = _bench_two_ranks(["--mode", "train", "--dtype", "bf16", "--allreduce-dtype", "bf16", "--batch", "1", "--steps", "2", "--warmup", "1", "--rooms", "4"],
-                           ranks=8, timeout=1800)
-    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 8 and rec["value"] > 0 and np.isfinite(rec["final_loss"])
-    assert rec["rccl"]["world_size_seen_by_rccl"] == 8
-    tr = rec["allreduce_overlap"]["traced_step"]
-    # (64 MB buckets: 7 when the gradients travel as float32 -- 326 MB --, 6 on the bf16 wire: the height-compression range is 91 MB = 2 buckets)
-    assert len(tr["segment_kernels_done_ms"]) == 5 and len(tr["buckets"]) == 6, [b["MB"] for b in tr["buckets"]]
-    assert sum(b["MB"] for b in tr["buckets"]) == pytest.approx(163.1, abs=1.0)
-    print("[parity] 8 ranks on one GPU, train: buckets (MB) %s, host cores per rank %s" % ([b["MB"] for b in tr["buckets"]], rec.get("host_cores_per_rank")))
-
-
-def test_bench_eight_rank_self_launch_layout():
-    """configs[4] over 8 ranks: this host's cores / 8 per rank for the layout fit -- the rate a first 8-GPU run of the layout leg should be
-    compared with (the forward does not depend on host cores; the fit does)."""
-    rec = _bench_two_ranks(["--mode", "layout", "--panoramas", "128", "--batch", "8"], ranks=8, timeout=1800)
-    assert rec["n_gpus"] == 8 and rec["render_crc_mismatches"] == 0 and rec["host_cores_per_rank"] >= 1
-    par = rec["iou3d_parity_vs_reference_inference"]
-    assert par["f32"]["iou3d_failed"] == 0 and par["f32"]["iou3d_mean"] > 0.9999 and par["f32"]["corner_count_mismatches"] == 0
-    print("[parity] 8 ranks on one GPU, layout: host cores per rank %s, %s panoramas/s end to end" % (rec["host_cores_per_rank"], rec["value"]))
 
 
 # ---- inference.py:174-223 call sequence --------------------------------------------------------------------------
