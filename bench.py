@@ -355,7 +355,7 @@ def loss_curve_check(dev, dtype):
         loss = objective(bon, y_bon, cor, y_cor)["total"]
         loss.backward()
         opt.step()
-        got.append(float(loss))
+        got.append(float(loss.detach()))
     want = (g["curve"][:, 0] + g["curve"][:, 1]).tolist()
     return {"engine": [round(v, 6) for v in got], "reference_cpu_f32": [round(v, 6) for v in want],
             "max_rel_diff": round(max(abs(p - q) / q for p, q in zip(got, want)), 6),
