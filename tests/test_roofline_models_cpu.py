@@ -1,0 +1,61 @@
+"""bench.py's roofline models (the denominators of every `roofline.frac` it prints) pinned on the CPU: the algorithmic work per panorama of
+SURVEY.md 8(d) / BASELINE.md, and the committed round-5 line (`profiles/r5_bench_default.json`) re-derived from the same functions -- a
+changed model can no longer move a reported fraction without this file noticing."""
+import json
+import os
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_forward_work_per_panorama_is_the_surveyed_figure():
+    # 142.9 GFLOP per 512x1024 panorama (convs + both LSTM layers), independent of the batch size
+    for B in (1, 32):
+        _, fl, _, _ = bench.f32_mixed_roofline(B)
+        assert fl / B == pytest.approx(142.9e9, rel=2e-3)
+    t16, fl16, by16, hbm16 = bench.bf16_mixed_roofline(32)
+    t32, fl32, by32, hbm32 = bench.f32_mixed_roofline(32)
+    assert fl16 == pytest.approx(fl32, rel=1e-12)                 # the same GEMMs ...
+    assert by16 < 0.6 * by32                                      # ... on half-width operands (the f32 gate pre-activations stay 4 bytes)
+    assert hbm16 > 0 and t16 < t32
+    # 53 convs of the ResNet-50 trunk + 16 of the height compression = the 69 conv launches of DESIGN.md section 4
+    assert len(bench.conv_table()) == 69
+
+
+def test_training_bounds_are_ordered_and_count_three_gemms_per_conv():
+    t, fl, by, t_hbm = bench.train_mixed_roofline(64)
+    tm, flm, bym, t_hbm_m = bench.train_mixed_roofline(64, fused_minimum=True)
+    assert flm == fl and bym < by and tm < t and t_hbm_m < t_hbm  # fusing BatchNorm passes removes bytes, never FLOP
+    _, f_fwd, _, _ = bench.bf16_mixed_roofline(64)
+    assert 2.9 < fl / f_fwd < 3.0                                 # forward + data gradient + weight gradient (the stem has no data gradient)
+    assert 0.70 < tm / t < 0.75                                   # the fused-minimum design bound is ~27 % below the round-4 bound
+
+
+def test_committed_round5_line_follows_from_the_models():
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")))
+    B = rec["config"]["global_batch"]
+    # headline: fp32 forward against the fp32 MFMA peak
+    r = rec["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == bench.PEAK_F32_MFMA_TFLOPS and r["unit"] == "TFLOP/s"
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    _, fl, _, _ = bench.f32_mixed_roofline(B)
+    assert r["achieved"] == pytest.approx(fl / (rec["ms_per_step"] * 1e-3) / 1e12, rel=2e-2)   # (HIP-event time vs the wall-clock step)
+    assert rec["value"] == pytest.approx(B / (rec["ms_per_step"] * 1e-3), rel=1e-3)
+    # bf16 forward against the mixed per-layer bound
+    b = rec["bf16_mode"]["roofline"]
+    t16, fl16, by16, _ = bench.bf16_mixed_roofline(32)
+    assert b["peak"] == pytest.approx(32 / t16, rel=1e-3) and b["frac"] == pytest.approx(b["achieved"] / b["peak"], rel=1e-3)
+    assert b["algorithmic_flop_per_batch"] == pytest.approx(fl16, rel=1e-9) and b["unfused_bytes_per_batch"] == pytest.approx(by16, rel=1e-9)
+    # bf16 training step against both of its bounds
+    tr = rec["train_bf16"]["roofline"]
+    t, fl, by, _ = bench.train_mixed_roofline(64)
+    tm, _, bym, _ = bench.train_mixed_roofline(64, fused_minimum=True)
+    assert tr["peak"] == pytest.approx(64 / t, rel=1e-3) and tr["fused_minimum"]["peak"] == pytest.approx(64 / tm, rel=1e-3)
+    assert tr["model_flop_per_step"] == pytest.approx(fl, rel=1e-9) and tr["model_bytes_per_step"] == pytest.approx(by, rel=1e-9)
+    assert tr["fused_minimum"]["model_bytes_per_step"] == pytest.approx(bym, rel=1e-9)
+    assert tr["frac"] == pytest.approx(rec["train_bf16"]["value"] / tr["peak"], rel=2e-3)
+    assert tr["fused_minimum"]["frac"] == pytest.approx(rec["train_bf16"]["value"] / tr["fused_minimum"]["peak"], rel=2e-3)
+    assert tr["traffic_stale"] is False and 0.9 < tr["traffic"] / by < 1.0      # counter bytes per step against the model's
