@@ -178,6 +178,10 @@ extern "C" int hn_create(hn_engine** out, int device)
                prop.multiProcessorCount);
     hn_engine* e = new hn_engine();
     e->device = device;
+    if (const char* pz = getenv("HN_POISON_WS")) {      // "1" / "ff": NaN bytes; "7f": huge finite values; "0": off (see hn_engine::poison)
+        if (pz[0] == '7') e->poison = 0x7F;
+        else if (pz[0] != '0' && pz[0] != 0) e->poison = 0xFF;
+    }
     {
         DeviceGuard guard(device);
         HN_REQUIRE(guard.ok, "hn_create: cannot select device %d", device);
@@ -260,6 +264,7 @@ extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
     if (strcmp(name, "chain_layer1") == 0) { e->chain_layer1 = value ? 1 : 0; return 0; }
     if (strcmp(name, "lstm_wide_rows") == 0) { e->wide_rows = value == 8 ? 8 : 16; return 0; }
     if (strcmp(name, "lstm_wide_xcds") == 0) { e->wide_xcds = value == 2 ? 2 : 1; return 0; }
+    if (strcmp(name, "poison_ws") == 0) { e->poison = value == 2 ? 0x7F : (value ? 0xFF : -1); return 0; }       // 0 off, 1 NaN bytes, 2 0x7F bytes
     HN_REQUIRE(false, "hn_set_option: unknown option '%s'", name);
 }
 
@@ -335,6 +340,7 @@ extern "C" int hn_pack_weights(hn_engine* e, void* packed, size_t packed_bytes, 
     auto get = [&](const std::string& k) { return reinterpret_cast<const float*>(e->bound.at(k)); };
     // one table-driven launch for all 69 conv packings + BatchNorm folds + the LSTM / head copies (multi_job.h); it used to be
     // ~150 launches, repeated after every optimiser step of a training loop
+    if (int rc = hn_poison(e, packed, hn_packed_bytes(), s)) return rc;
     std::vector<MJob> jobs;
     jobs.reserve(2 * a.convs.size() + 20);
     for (const auto& c : a.convs) {
@@ -557,6 +563,10 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
     float* W = reinterpret_cast<float*>(workspace);
     e->prof.clear();
     e->events_used = 0;
+    // (everything behind the sync page is dead at entry: the branch stream of the previous call was joined on s)
+    if (int rc = hn_poison(e, W + pl.xn, (pl.total - pl.xn) * sizeof(float), s)) return rc;
+    if (int rc = hn_poison(e, bon, (size_t)B * 2 * 1024 * sizeof(float), s)) return rc;
+    if (int rc = hn_poison(e, cor, (size_t)B * 1024 * sizeof(float), s)) return rc;
     if (int rc = run_trunk_f(e, x, B, C_in, W, pl, W + pl.seq, s)) return rc;
     const HeadBufsF hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y2};
     return run_head_f(e, B, hb, bon, cor, false, s);

@@ -131,6 +131,7 @@ extern "C" int hn_pack_weights_bf16(hn_engine* e, void* packed_h, size_t bytes, 
     // one table-driven launch (multi_job.h): the forward packings, the LSTM / input-GEMM weights, and the per-class
     // data-gradient packings the bf16 training step's backward pass reads (they used to be re-packed inside every backward
     // pass, ~90 launches; as weights they only change with the optimiser step that also triggers this call)
+    if (int rc = hn_poison(e, packed_h, hn_packed_bf16_bytes(), s)) return rc;
     std::vector<MJob> jobs;
     jobs.reserve(3 * a.convs.size() + 8);
     for (size_t i = 0; i < a.convs.size(); ++i) {
@@ -429,6 +430,12 @@ extern "C" int hn_forward_bf16(hn_engine* e, const float* x, int B, int C_in, fl
     char* W = reinterpret_cast<char*>(workspace);
     e->prof.clear();
     e->events_used = 0;
+    // (everything behind the sync page is dead at entry -- unless a chain of an earlier PIPELINED batch is still un-joined on the branch stream)
+    if (!(e->join_deferred[0] || e->join_deferred[1] || e->join_deferred[2] || e->join_deferred[3])) {
+        if (int rc = hn_poison(e, W + pl.xn, pl.total - pl.xn, s)) return rc;
+        if (int rc = hn_poison(e, bon, (size_t)B * 2 * 1024 * sizeof(float), s)) return rc;
+        if (int rc = hn_poison(e, cor, (size_t)B * 1024 * sizeof(float), s)) return rc;
+    }
     if (int rc = run_trunk_h(e, x, B, C_in, W, pl, W + pl.seq, s)) return rc;
     const HeadBufs hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y1h, W + pl.y2, W + pl.xch, nullptr};
     return run_head_h(e, B, hb, bon, cor, false, s);

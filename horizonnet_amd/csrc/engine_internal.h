@@ -96,6 +96,9 @@ struct hn_engine {
     int bf16_lstm = 1;                   // hn_forward_bf16: 1 = bf16 recurrence kernel (lstm_bf16.hip), 0 = the float32 one (lstm.hip)
     int use_branch_stream = 1;           // 0: everything on the caller's stream (hn_set_option "branch_stream")
     int train_bf16 = 0;                  // 1: train-mode convs (forward + data gradient) on the bf16 matrix cores (hn_set_train_precision)
+    int poison = -1;                     // debug instrument (env HN_POISON_WS / option "poison_ws"): -1 off, else the byte every workspace / scratch /
+                                         // packed-weight / gradient range is filled with BEFORE each engine entry writes it (0xFF = NaN in f32, bf16
+                                         // and f64; 0x7F = 3.4e38): a result that changes with the pattern is a read of memory the entry never wrote
     bool profiling = false;
     int debug_unit = -1;                 // training debug tap (hn_train_debug_set): unit whose dy / dz are copied out
     float* debug_dy = nullptr;
@@ -138,6 +141,13 @@ struct ProfScope {
     }
 };
 
+// hn_engine::poison: fill [p, p + bytes) with the poison byte on stream s (no-op when the instrument is off)
+inline int hn_poison(const hn_engine* e, void* p, size_t bytes, hipStream_t s)
+{
+    if (e->poison < 0 || p == nullptr || bytes == 0) return 0;
+    HN_HIP(hipMemsetAsync(p, e->poison, bytes, s));
+    return 0;
+}
 // creates the engine's head stream + its events on first use (hn_forward_submit / hn_forward_bf16_submit)
 int hn_ensure_head_stream(hn_engine* e);
 // element offset of conv `ci`'s packed bf16 weights inside the hn_pack_weights_bf16 buffer (engine_bf16.hip)

@@ -654,6 +654,9 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     float* W = c.W;
     hipStream_t s = c.s;
     int rc;
+    // debug instrument (hn_engine::poison): nothing behind the sync page survives from one training forward to the next
+    if ((rc = hn_poison(e, W + pl.xn, (pl.total - pl.xn) * sizeof(float), s))) return rc;
+    if ((rc = hn_poison(e, bon, (size_t)B * 2 * 1024 * sizeof(float), s)) || (rc = hn_poison(e, cor, (size_t)B * 1024 * sizeof(float), s))) return rc;
     HN_HIP(hipMemsetAsync(W + pl.sync, 0, HN_STATUS_WORD * sizeof(unsigned), s));   // arrival counters; the status word behind them is sticky (zeroed by the caller at allocation)
     HN_HIP(hipMemsetAsync(W + pl.dstat, 0, pl.stat_fwd_doubles * sizeof(double), s));   // every unit's batch-statistics slot
 
@@ -806,6 +809,20 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
     float* G3 = W + pl.G[3];
     double* ds = reinterpret_cast<double*>(W + pl.dstat) + pl.stat_lstm;      // LSTM bias-gradient sums (zeroed where used)
     if (seg_lo == 0) {    // the pass starts: every unit's [S1 | S2 | dbias] slot and every unit's weight-gradient scratch in one go each
+        // debug instrument (hn_engine::poison): the ranges the adjoint treats as outputs / scratch -- gradient tensors, bf16 dz staging, d(C_s),
+        // the two packed-weight scratches (the forward's Gram partials / LSTM staging are dead), the recurrent scratch, the gate buffer (the
+        // adjoint overwrites it with dg; the saved gates live in pl.save), the weight-gradient scratches and the caller's flat gradient buffer
+        if (e->poison >= 0) {
+            for (int i = 0; i < 4; ++i) if ((rc = hn_poison(e, W + pl.G[i], pl.gmax * sizeof(float), s))) return rc;
+            for (int i = 0; i < 2; ++i) if ((rc = hn_poison(e, W + pl.dzh[i], pl.gmax / 2 * sizeof(float), s))) return rc;
+            if ((rc = hn_poison(e, W + pl.DC[0], (pl.lxch - pl.DC[0]) * sizeof(float), s))) return rc;
+            if ((rc = hn_poison(e, W + pl.lxch, (pl.dstat - pl.lxch) * sizeof(float), s))) return rc;      // lxch, dhrec, dcrec, wsA, wsB
+            if ((rc = hn_poison(e, W + pl.gx, (size_t)rows * 4096 * sizeof(float), s))) return rc;
+            if ((rc = hn_poison(e, W + pl.dlin, ((size_t)rows * 12 + HN_HEAD_BWD_SCRATCH_FLOATS) * sizeof(float), s))) return rc;
+            if ((rc = hn_poison(e, W + pl.wg_first, pl.wg_floats * sizeof(float), s))) return rc;
+            if ((rc = hn_poison(e, reinterpret_cast<double*>(W + pl.dstat) + pl.stat_bwd_first, (pl.stat_bwd_doubles + 4096) * sizeof(double), s))) return rc;
+            if ((rc = hn_poison(e, grads, arch().grad_floats * sizeof(float), s))) return rc;
+        }
         HN_HIP(hipMemsetAsync(reinterpret_cast<double*>(W + pl.dstat) + pl.stat_bwd_first, 0, pl.stat_bwd_doubles * sizeof(double), s));
         HN_HIP(hipMemsetAsync(W + pl.wg_first, 0, pl.wg_floats * sizeof(float), s));
     }

@@ -69,16 +69,17 @@ def bench_ranks(extra, timeout=1200, ranks=2):
     """`python bench.py --gpus 2 ...` WITHOUT torchrun's environment: bench.py becomes the launcher (the re-exec branch the
     driver's N = 2, 4, 8 runs go through), both ranks share the box's one GPU, gloo stands in for RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    # Eight processes time-slicing one GPU is a test rig, not a deployment (one rank per GPU): one of ~10 such launches died with SIGABRT inside a rank
-    # before its first step (round 5; the three 8-rank tests passed in four other runs of the suite and in 3 of 3 stand-alone repeats).  The rig gets
-    # ONE retry, and says so; a failure of the code under test fails both attempts.
-    for attempt in range(2 if ranks > 2 else 1):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--share-gpu"] + extra,
-                             capture_output=True, text=True, timeout=timeout, env=env)
-        if out.returncode == 0:
-            break
-        print("[rig] %d-rank launch attempt %d failed (rc %d): %s" % (ranks, attempt + 1, out.returncode, out.stderr[-1500:]))
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    # the child processes need the device memory this process's allocator is sitting on (and the parent's later allocations then come from
+    # fresh mappings the children left their data in: tests/conftest.py poisons them before the next test)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    # no retry: a rank that aborts is a failure of the code under test; its stderr is the evidence
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--share-gpu"] + extra,
+                         capture_output=True, text=True, timeout=timeout, env=env)
+    if out.returncode != 0:
+        print("[rig] %d-rank launch failed (rc %d); stderr tail:\n%s" % (ranks, out.returncode, out.stderr[-6000:]))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-6000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly ONE JSON line (rank 0 only): %d" % len(lines)
     return json.loads(lines[0])
