@@ -32,30 +32,3 @@ def test_training_bounds_are_ordered_and_count_three_gemms_per_conv():
     _, f_fwd, _, _ = bench.bf16_mixed_roofline(64)
     assert 2.9 < fl / f_fwd < 3.0                                 # forward + data gradient + weight gradient (the stem has no data gradient)
     assert 0.70 < tm / t < 0.75                                   # the fused-minimum design bound is ~27 % below the round-4 bound
-
-
-def test_committed_round5_line_follows_from_the_models():
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")))
-    B = rec["config"]["global_batch"]
-    # headline: fp32 forward against the fp32 MFMA peak
-    r = rec["roofline"]
-    assert r["bound"] == "mfma" and r["peak"] == bench.PEAK_F32_MFMA_TFLOPS and r["unit"] == "TFLOP/s"
-    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
-    _, fl, _, _ = bench.f32_mixed_roofline(B)
-    assert r["achieved"] == pytest.approx(fl / (rec["ms_per_step"] * 1e-3) / 1e12, rel=2e-2)   # (HIP-event time vs the wall-clock step)
-    assert rec["value"] == pytest.approx(B / (rec["ms_per_step"] * 1e-3), rel=1e-3)
-    # bf16 forward against the mixed per-layer bound
-    b = rec["bf16_mode"]["roofline"]
-    t16, fl16, by16, _ = bench.bf16_mixed_roofline(32)
-    assert b["peak"] == pytest.approx(32 / t16, rel=1e-3) and b["frac"] == pytest.approx(b["achieved"] / b["peak"], rel=1e-3)
-    assert b["algorithmic_flop_per_batch"] == pytest.approx(fl16, rel=1e-9) and b["unfused_bytes_per_batch"] == pytest.approx(by16, rel=1e-9)
-    # bf16 training step against both of its bounds
-    tr = rec["train_bf16"]["roofline"]
-    t, fl, by, _ = bench.train_mixed_roofline(64)
-    tm, _, bym, _ = bench.train_mixed_roofline(64, fused_minimum=True)
-    assert tr["peak"] == pytest.approx(64 / t, rel=1e-3) and tr["fused_minimum"]["peak"] == pytest.approx(64 / tm, rel=1e-3)
-    assert tr["model_flop_per_step"] == pytest.approx(fl, rel=1e-9) and tr["model_bytes_per_step"] == pytest.approx(by, rel=1e-9)
-    assert tr["fused_minimum"]["model_bytes_per_step"] == pytest.approx(bym, rel=1e-9)
-    assert tr["frac"] == pytest.approx(rec["train_bf16"]["value"] / tr["peak"], rel=2e-3)
-    assert tr["fused_minimum"]["frac"] == pytest.approx(rec["train_bf16"]["value"] / tr["fused_minimum"]["peak"], rel=2e-3)
-    assert tr["traffic_stale"] is False and 0.9 < tr["traffic"] / by < 1.0      # counter bytes per step against the model's

@@ -1,11 +1,12 @@
 #!/bin/bash
-# round 5, evidence on ONE box: counter passes + kernel stats (forward bf16 / f32, training step), then the default bench line (which quotes
+# evidence on ONE box (round tag T): counter passes + kernel stats (forward bf16 / f32, training step), then the default bench line (which quotes
 # those counters: same kernel sources -> traffic_stale false), then the whole GPU suite.  EVERY step under its own timeout (a hung rocprofv3
-# once cost 20 GPU-minutes).   HN_GIT_HEAD=<commit> bash tools/r5_final.sh [nosuite]
+# once cost 20 GPU-minutes).   T=r6 HN_GIT_HEAD=<commit> bash tools/final_evidence.sh [nosuite]
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r5
+T=${T:-r6}
+export T
 timeout 300 bash tools/profile_forward.sh bf16 $T > gpurun_out/${T}_prof_bf16.log 2>&1
 timeout 300 bash tools/profile_forward.sh f32 $T > gpurun_out/${T}_prof_f32.log 2>&1
 timeout 60 python tools/merge_pmc.py gpurun_out $T > gpurun_out/${T}_pmc_forward.json 2> gpurun_out/${T}_merge.err
@@ -15,7 +16,8 @@ rm -rf gpurun_out/prof_${T}_bf16 gpurun_out/prof_${T}_f32 gpurun_out/prof_${T}_t
 timeout 600 python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
 python - <<'PY'
 import json
-T = "r5"
+import os
+T = os.environ.get("T", "r6")
 for l in open('gpurun_out/%s_bench_default.json' % T):
     if l.startswith('{'):
         d = json.loads(l)
