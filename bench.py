@@ -547,6 +547,46 @@ def traced_backward(net, step, dev):
                                     "done and the previous bucket has left RCCL's stream"}}
 
 
+def box_probe(dev):
+    """What THIS box sustains on the two rooflines ("re-derive from the box ... a measured MFMA micro-benchmark; report both"):
+    dense MFMA rate of the library's rate kernel (hn_probe_mfma, ~4 ms per dtype, every CU, 4 independent accumulator chains per wave) and the
+    bandwidth of a 1 GiB device copy.  Round 6 saw the same library at 849 (fp32 forward) on one box and 748 on another: the fraction of the
+    guide's peak is the contract's number, the fraction of the box's own rate says whether the CODE or the BOX moved."""
+    import ctypes
+    from horizonnet_amd import _lib
+    lib = _lib.load()
+    out = {}
+    wgs = 2048
+    scratch = torch.empty(wgs * 256, dtype=torch.float32, device=dev)
+    flop = ctypes.c_double()
+    with torch.cuda.device(dev):
+        for name, dt, iters in (("mfma_f32_tflops", 0, 4000), ("mfma_bf16_tflops", 1, 8000)):
+            best = 0.0
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(lib.hn_probe_mfma(dt, wgs, iters, _lib.ptr(scratch), ctypes.byref(flop), _lib.stream_ptr(dev)), "hn_probe_mfma")
+                e1.record()
+                torch.cuda.synchronize(dev)
+                best = max(best, flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+            out[name] = round(best, 1)
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        b = torch.empty_like(a)
+        best = 0.0
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            best = max(best, 2.0 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        out["hbm_copy_GBps"] = round(best, 0)
+        del a, b, scratch
+    out["note"] = ("measured on this box in this run (best of 3-4): dense v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16 issue rate on all CUs, "
+                   "read + write bytes of a 1 GiB device copy; the guide's peaks are 157.3 TF / ~2500 TF / ~8000 GB/s")
+    return out
+
+
 def max_over_ranks(value, dist, dev):
     """MAX over the ranks of a host scalar (the contract's max-over-ranks timing); device tensor for RCCL, host tensor for gloo."""
     if dist is None:
@@ -979,6 +1019,13 @@ def main():
                                                   "hbm_bound_layers_ms": round(t_hbm * 1e3, 3),
                                                   "note": "per layer max(flops / 157.3 TF, unfused float32 bytes / 8 TB/s), summed: the bound that also charges the "
                                                           "HBM-bound layer1 1x1 convs their bytes; `frac` above stays the pure-MFMA figure SURVEY 8(d) names"}
+        try:
+            box = box_probe(dev)
+            out["box"] = box
+            key = "mfma_f32_tflops" if args.dtype == "f32" else "mfma_bf16_tflops"
+            out["roofline"]["frac_of_box_measured_mfma"] = round(achieved_tflops / box[key], 4)
+        except Exception as exc:                          # noqa: BLE001  (a probe must never cost the headline line)
+            out["box"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if plain_rec is not None:
             out["plain_forward"] = plain_rec
         if rccl is not None:

@@ -62,6 +62,7 @@ SIGNATURES = {
     "hn_grad_floats": (_sz, []),
     "hn_loss_l1_bce": (_i, [_vp, _vp, _c.c_longlong, _vp, _vp, _c.c_longlong, _vp, _vp, _vp, _vp, _vp]),
     "hn_scale2": (_i, [_vp, _c.c_longlong, _vp, _c.c_longlong, _vp, _vp]),
+    "hn_probe_mfma": (_i, [_i, _i, _i, _vp, _c.POINTER(_c.c_double), _vp]),
     "hn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _c.c_longlong, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "hn_train_debug_unit": (_i, [_i, _i, _c.POINTER(_i64)]),
     "hn_train_debug_unit_yh": (_i64, [_i, _i]),

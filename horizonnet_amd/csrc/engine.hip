@@ -125,6 +125,9 @@ namespace {
 // ---- workspace plan ----------------------------------------------------------------------------
 struct Plan {
     size_t sync, xn, stem, pool, p0, p1, t1, t2, ds, g0, g1, seq, gx, y1, y2, sk, total;   // float offsets
+    size_t c[4];      // C1..C4 (the stage outputs) in buffers of their own: the height-compression chain of scale li reads C_li on the engine's
+                      // branch stream while the next stage already ping-pongs p0 / p1 on the caller's
+    size_t sk2;       // split-K scratch of the caller's stream (interactive regime: the stages' deep-K convs); `sk` belongs to the branch stream
 };
 
 constexpr size_t SPLITK_WS_FLOATS_PER_PANO = 8 * 128 * 256;   // up to 8 slices of the largest split layer per panorama
@@ -157,11 +160,34 @@ Plan make_plan(int B)
     p.y1 = take((size_t)T_COLS * b * 1024);
     p.y2 = take((size_t)T_COLS * b * 1024);
     p.sk = take(splitk_ws_floats((int)b));           // split-K partial tiles (conv_igemm_f32.hip)
+    for (int li = 0; li < 4; ++li) p.c[li] = take(b * (128 >> li) * (256 >> li) * (size_t)(256 << li));
+    p.sk2 = take(splitk_ws_floats((int)b));
     p.total = off;
     return p;
 }
 
 }  // namespace
+
+// Engine-owned streams: plain non-blocking HIP streams of NORMAL priority.
+// Round 6 (tools/stream_pool_probe.py): up to round 5 the head stream was created with the highest priority ("the few workgroups of the recurrence
+// must win the dispatcher's arbitration").  The HIP runtime keeps a separate small pool of hardware queues per priority, and a process that had
+// run ONE RCCL collective before the engine existed then lost 26 % of the pipelined bf16 forward (5129 -> 3776 panoramas/s at B = 32; 11 % in
+// float32; unchanged by GPU_MAX_HW_QUEUES = 8 / 16, by 36 idle or 4 used torch pool streams, by destroying the process group; gone when the
+// collective came AFTER the engine's first forward).  With a normal-priority head stream the same process runs at 5258 panoramas/s and a clean one
+// at 5181 (5106-5129 with the priority): the priority bought nothing and made the engine's overlap depend on what the process did first.
+// HN_HEAD_PRIO=high restores it (A/B runs).
+int hn_make_stream(hipStream_t* out, bool high_priority)
+{
+    static const char* hp = getenv("HN_HEAD_PRIO");
+    if (high_priority && hp && hp[0] == 'h') {
+        int least = 0, greatest = 0;
+        HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HN_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest));
+    } else {
+        HN_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    }
+    return 0;
+}
 
 // ---- engine API --------------------------------------------------------------------------------
 extern "C" int hn_create(hn_engine** out, int device)
@@ -185,14 +211,8 @@ extern "C" int hn_create(hn_engine** out, int device)
     {
         DeviceGuard guard(device);
         HN_REQUIRE(guard.ok, "hn_create: cannot select device %d", device);
-        {
-            // the height-compression branches' stream.  HN_BRANCH_PRIORITY=low|high for A/B runs (default: the same priority as the trunk)
-            const char* bp = getenv("HN_BRANCH_PRIORITY");
-            int least = 0, greatest = 0;
-            HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            if (bp && (bp[0] == 'l' || bp[0] == 'h')) HN_HIP(hipStreamCreateWithPriority(&e->branch_stream, hipStreamNonBlocking, bp[0] == 'l' ? least : greatest));
-            else HN_HIP(hipStreamCreateWithFlags(&e->branch_stream, hipStreamNonBlocking));
-        }
+        // the height-compression branches' stream (engine-owned, see hn_make_stream)
+        if (int rc = hn_make_stream(&e->branch_stream, /*high_priority=*/false)) { delete e; return rc; }
         for (int i = 0; i < 4; ++i) {
             HN_HIP(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming));
             HN_HIP(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
@@ -412,7 +432,13 @@ struct HeadBufsF {
 };
 
 // The convolutional trunk of hn_forward (model.py:248-252,73-81,123-179) on stream s, writing the column features to `seq`.
-int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const Plan& pl, float* seq, hipStream_t s)
+// The height-compression chain of scale li (model.py:138-156) depends only on C_li: like the bf16 trunk (engine_bf16.hip: run_trunk_h) it is
+// forked onto the engine's branch stream and runs beside the ResNet stages that follow -- the chains are matrix-bound (ghc*.0: 4.8 GMAC each at
+// 125-139 TF) with low-occupancy tails (ghc*.2 / *.3 and their split-K reduces), the stages carry the HBM-bound 1x1 convs: the two streams fill
+// each other's idle matrix cycles.  defer_join (pipelined entry): the caller's stream does not wait for the chains at the end -- the recurrent
+// head does -- so the NEXT batch's stem / layer1 (HBM-bound in float32) run beside this batch's last chain (ghc3: 3.2 ms of deep-K matrix work).
+int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const Plan& pl, float* seq, hipStream_t s, bool defer_join = false,
+                bool* forked = nullptr)
 {
     const Arch& a = arch();
     const float* P = e->packed;
@@ -432,16 +458,28 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
     const float* cur = W + pl.pool;
     int H = 128, Wd = 256;
     const int nblk[4] = {3, 4, 6, 3};
+    // Measured in round 6 (B = 32, one box): 846.5 panoramas/s on one stream, 843.3 forked + joined, 849.8 forked + deferred join: unlike bf16 (whose
+    // stages are HBM-bound) every float32 launch already fills the matrix pipes of every compute unit, two workgroups of 64 KiB LDS each per CU,
+    // so a second stream has nothing to fill.  Off by default (HN_F32_BRANCH=1 switches it on for A/B runs).
+    static const char* fenv = getenv("HN_F32_BRANCH");
+    const bool fork = e->use_branch_stream && !e->profiling && e->branch_stream != nullptr && fenv && fenv[0] == '1';
+    hipStream_t sb = fork ? e->branch_stream : s;
+    if (forked) *forked = fork;
     for (int li = 0; li < 4; ++li) {
+        // C_li is about to be overwritten: a chain of an EARLIER batch that was not joined (deferred) must have finished reading it
+        if (e->join_deferred[li]) {
+            HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
+            e->join_deferred[li] = false;
+        }
         for (int j = 0; j < nblk[li]; ++j) {
             const int stride = (j == 0 && li > 0) ? 2 : 1;
             const ConvLayer& c1 = a.convs[a.block_first[li][j]];
             const ConvLayer& c2 = a.convs[a.block_first[li][j] + 1];
             const ConvLayer& c3 = a.convs[a.block_first[li][j] + 2];
-            float* out = (cur == W + pl.p0) ? W + pl.p1 : W + pl.p0;
+            float* out = (j == nblk[li] - 1) ? W + pl.c[li] : ((cur == W + pl.p0) ? W + pl.p1 : W + pl.p0);
             // interactive regime (B <= 4): the deep-K convs of the stages give a 256-CU part 32 .. 128 tiles -- split-K like the height-compression
-            // tails (same scratch: everything here is on stream s); at larger batches nothing changes
-            float* sk = B <= 4 ? W + pl.sk : nullptr;
+            // tails (a scratch of the caller's stream's own: the chains on the branch stream use pl.sk); at larger batches nothing changes
+            float* sk = B <= 4 ? W + pl.sk2 : nullptr;
             const size_t skf = B <= 4 ? splitk_ws_floats(B) : 0;
             if ((rc = run_conv(e, P, c1, cur, W + pl.t1, nullptr, B, H, Wd, 1, 1, 1, s, sk, skf))) return rc;
             if ((rc = run_conv(e, P, c2, W + pl.t1, W + pl.t2, nullptr, B, H, Wd, stride, stride, 1, s, sk, skf))) return rc;
@@ -473,23 +511,34 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
             if ((rc = e->tap(cname[li], cur, (size_t)B * H * Wd * (256 << li) * sizeof(float), s))) return rc;
         }
         // GlobalHeightConv for this scale
+        if (fork) {
+            HN_HIP(hipEventRecord(e->ev_fork[li], s));
+            HN_HIP(hipStreamWaitEvent(sb, e->ev_fork[li], 0));
+        }
         const float* gin = cur;
         int gh = H;
         float* gbuf[2] = {W + pl.g0, W + pl.g1};
         for (int k = 0; k < 4; ++k) {
             const ConvLayer& gc = a.convs[a.ghc_first[li] + k];
             float* gout = gbuf[k & 1];
-            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, s, W + pl.sk, splitk_ws_floats(B)))) return rc;
+            if ((rc = run_conv(e, P, gc, gin, gout, nullptr, B, gh, Wd, 2, 1, 1, sb, W + pl.sk, splitk_ws_floats(B)))) return rc;
             gin = gout;
             gh /= 2;
         }
         const int cq = a.convs[a.ghc_first[li] + 3].cout;
         {
-            ProfScope ps(e, s, "upsample_flatten." + std::to_string(li), 0.0);
-            if ((rc = hn_launch_upsample_flatten(gin, seq, B, gh, Wd, cq, 256 * li, s))) return rc;
+            ProfScope ps(e, sb, "upsample_flatten." + std::to_string(li), 0.0);
+            if ((rc = hn_launch_upsample_flatten(gin, seq, B, gh, Wd, cq, 256 * li, sb))) return rc;
+        }
+        if (fork) HN_HIP(hipEventRecord(e->ev_join[li], sb));
+    }
+    if (fork) {
+        if (defer_join) {
+            for (int li = 0; li < 4; ++li) e->join_deferred[li] = true;
+        } else {
+            for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(s, e->ev_join[li], 0));
         }
     }
-
     return 0;
 }
 
@@ -563,10 +612,12 @@ extern "C" int hn_forward(hn_engine* e, const float* x, int B, int C_in, float* 
     float* W = reinterpret_cast<float*>(workspace);
     e->prof.clear();
     e->events_used = 0;
-    // (everything behind the sync page is dead at entry: the branch stream of the previous call was joined on s)
-    if (int rc = hn_poison(e, W + pl.xn, (pl.total - pl.xn) * sizeof(float), s)) return rc;
-    if (int rc = hn_poison(e, bon, (size_t)B * 2 * 1024 * sizeof(float), s)) return rc;
-    if (int rc = hn_poison(e, cor, (size_t)B * 1024 * sizeof(float), s)) return rc;
+    // (everything behind the sync page is dead at entry -- unless a chain of an earlier PIPELINED batch is still un-joined on the branch stream)
+    if (!(e->join_deferred[0] || e->join_deferred[1] || e->join_deferred[2] || e->join_deferred[3])) {
+        if (int rc = hn_poison(e, W + pl.xn, (pl.total - pl.xn) * sizeof(float), s)) return rc;
+        if (int rc = hn_poison(e, bon, (size_t)B * 2 * 1024 * sizeof(float), s)) return rc;
+        if (int rc = hn_poison(e, cor, (size_t)B * 1024 * sizeof(float), s)) return rc;
+    }
     if (int rc = run_trunk_f(e, x, B, C_in, W, pl, W + pl.seq, s)) return rc;
     const HeadBufsF hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y2};
     return run_head_f(e, B, hb, bon, cor, false, s);
@@ -582,9 +633,7 @@ extern "C" size_t hn_workspace_pipelined_bytes(int B)
 int hn_ensure_head_stream(hn_engine* e)
 {
     if (e->head_stream != nullptr) return 0;
-    int least = 0, greatest = 0;          // highest priority: the few workgroups of the recurrence must win the dispatcher's
-    HN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));       // arbitration against the thousands of the next batch's convolutions
-    HN_HIP(hipStreamCreateWithPriority(&e->head_stream, hipStreamNonBlocking, greatest));
+    if (int rc = hn_make_stream(&e->head_stream, /*high_priority=*/true)) return rc;       // (normal priority unless HN_HEAD_PRIO=high: see hn_make_stream)
     for (int k = 0; k < 2; ++k) {
         HN_HIP(hipEventCreateWithFlags(&e->ev_trunk[k], hipEventDisableTiming));
         HN_HIP(hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
@@ -614,9 +663,14 @@ extern "C" int hn_forward_submit(hn_engine* e, const float* x, int B, int C_in, 
     if (slot == 0) hb = {W + pl.sync, W + pl.seq, W + pl.gx, W + pl.y1, W + pl.y2};
     else hb = {W + pp.sync1, W + pp.seq1, W + pp.gx1, W + pp.y11, W + pp.y21};
     if (e->head_pending[slot]) HN_HIP(hipStreamWaitEvent(s, e->ev_head[slot], 0));   // this slot's seq was last read by the head of two submits ago
-    if (int rc = run_trunk_f(e, x, B, C_in, W, pl, hb.seq, s)) return rc;
+    static const char* djenv = getenv("HN_F32_DEFER_JOIN");      // "0": the caller's stream joins the four chains at the end of every trunk (A/B runs)
+    const bool defer = !(djenv && djenv[0] == '0');
+    bool forked = false;
+    if (int rc = run_trunk_f(e, x, B, C_in, W, pl, hb.seq, s, defer, &forked)) return rc;
     HN_HIP(hipEventRecord(e->ev_trunk[slot], s));
     HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_trunk[slot], 0));
+    if (forked && defer)
+        for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_join[li], 0));
     if (int rc = run_head_f(e, B, hb, bon, cor, true, e->head_stream)) return rc;
     HN_HIP(hipEventRecord(e->ev_head[slot], e->head_stream));
     e->head_pending[slot] = true;

@@ -148,6 +148,8 @@ inline int hn_poison(const hn_engine* e, void* p, size_t bytes, hipStream_t s)
     HN_HIP(hipMemsetAsync(p, e->poison, bytes, s));
     return 0;
 }
+// an engine-owned stream with a hardware queue of its own (engine.hip)
+int hn_make_stream(hipStream_t* out, bool high_priority);
 // creates the engine's head stream + its events on first use (hn_forward_submit / hn_forward_bf16_submit)
 int hn_ensure_head_stream(hn_engine* e);
 // element offset of conv `ci`'s packed bf16 weights inside the hn_pack_weights_bf16 buffer (engine_bf16.hip)

@@ -238,9 +238,11 @@ class DeviceBatcher:
             # The host half predicts which outlines the kernel cannot close (`on_host` rows, rasterised there and copied in above); a row the
             # KERNEL flags but the host did not predict would carry a wrong boundary label silently.  Counted on the device (no sync here),
             # read once per epoch by the training loop (unexpected_label_flags), which refuses to go on.
-            unexpected = status.clone()
-            if y_cor:
-                unexpected[torch.tensor(sorted(y_cor.keys()), dtype=torch.long, device=dev)] = 0
+            unexpected = status
+            if y_cor:                                   # (rare: a clone and a masked fill only for batches that have host-rasterised rows)
+                keep = torch.ones(B, dtype=torch.int32)
+                keep[sorted(y_cor.keys())] = 0
+                unexpected = status * keep.pin_memory().to(dev, non_blocking=True)
             self._unexpected_flags = unexpected.sum() if self._unexpected_flags is None else self._unexpected_flags + unexpected.sum()
             return x, d_bon, d_cor
         slot["bon"][:B].copy_(torch.from_numpy(bon))
@@ -277,7 +279,7 @@ class DeviceBatcher:
 
 
 class _BatchStream:
-    def __init__(self, owner, index_batches, rng, depth, side_stream=True):
+    def __init__(self, owner, index_batches, rng, depth, side_stream=False):
         import queue
         import threading
         self.owner = owner

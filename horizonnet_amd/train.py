@@ -97,6 +97,10 @@ class _FusedObjective(torch.autograd.Function):
     def backward(ctx, g_total, _g_parts):
         from . import _lib
         dbon, dcor = ctx.saved_tensors
+        if getattr(ctx, "consumed", False):      # hn_scale2 scales the saved gradients IN PLACE: a second pass would multiply them by g again
+            raise RuntimeError("horizonnet_amd.train.objective: backward through the fused objective ran twice (retain_graph=True / a loss-scaling "
+                               "wrapper that replays the graph); call objective() again, or use the two torch losses of reference train.py:53-56")
+        ctx.consumed = True
         g = g_total.contiguous().float()
         with torch.cuda.device(dbon.device):
             _lib.check(_lib.load().hn_scale2(_lib.ptr(dbon), dbon.numel(), _lib.ptr(dcor), dcor.numel(), _lib.ptr(g), _lib.stream_ptr(dbon.device)),
@@ -106,7 +110,7 @@ class _FusedObjective(torch.autograd.Function):
 
 def objective(y_bon_, y_bon, y_cor_, y_cor):
     """-> {"bon", "cor", "total"} of reference train.py:53-56; "total" carries the gradient.  Float32 ROCm tensors go through the fused HIP
-    objective (a second backward through the same graph is not supported: it scales its saved gradients in place); anything else (the outputs
+    objective (a second backward through the same graph raises: it scales its saved gradients in place); anything else (the outputs
     under torch.autocast arrive in the autocast dtype; CPU tensors in the host-side tests) through the reference's two torch calls."""
     if (y_bon_.is_cuda and y_bon_.dtype == torch.float32 and y_cor_.dtype == torch.float32 and y_bon.dtype == torch.float32 and y_cor.dtype == torch.float32
             and y_bon.shape == y_bon_.shape and y_cor.shape == y_cor_.shape and y_bon.device == y_bon_.device and y_cor.device == y_bon_.device):
@@ -257,14 +261,17 @@ def main(argv=None):
         torch.cuda.synchronize(device)
         status = int(net.hip_status(device) != 0)
         bad_labels = train.unexpected_label_flags() if hasattr(train, "unexpected_label_flags") else 0
-        if bad_labels:                                      # (same exit path as the status word: every rank leaves together)
+        if bad_labels:                                      # (same exit path as the status word: every rank leaves together; status 2 = labels)
             print("horizonnet_amd.train: %d panoramas of epoch %d were rasterised on the device with an uncovered column the host half had not "
                   "predicted (labels.device_label_record vs csrc/labels.hip disagree)" % (bad_labels, epoch), flush=True)
-            status = 1
+            status = 2
         if world > 1:                                       # EVERY rank must leave together: the collectives below would otherwise
             flag = torch.tensor([status], dtype=torch.int32, device=device)       # block the healthy ranks until the process-group time-out
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
             status = int(flag.item())
+        if status == 2:
+            raise RuntimeError("horizonnet_amd.train: a rank's device label rasterisation flagged panoramas the host half had not predicted in epoch %d "
+                               "(boundary labels of those rows would be wrong); refusing to go on -- see the rank's message above" % epoch)
         if status != 0:                                     # a timed-out persistent LSTM kernel produced garbage this epoch:
             raise RuntimeError("horizonnet_amd.train: the engine's status word is non-zero after epoch %d; refusing to "
                                "validate / checkpoint weights updated from invalid activations" % epoch)

@@ -445,6 +445,12 @@ int hn_conv2d_wgrad_nhwc_bf16(const float* x, const float* dz, float* dw_oihw, f
 int hn_conv2d_wgrad_nhwc(const float* x, const float* dz, float* dw_oihw, float* scratch, int B, int Hi, int Wi, int Cin,
                          int Cout, int KH, int KW, int sh, int sw, int stem, void* stream);
 
+/* Box characterisation for the bench (no reference counterpart; SURVEY.md 8(d) "re-derive from the box ... a measured MFMA micro-benchmark;
+ * report both"): launches a dense-MFMA rate kernel (dtype 0 = float32 v_mfma_f32_32x32x2_f32, 1 = bf16 v_mfma_f32_32x32x16_bf16) on
+ * `workgroups` x 4 waves, `iters` rounds of 4 independent accumulator chains; *flop_out = the FLOP of the launch (time it with events on
+ * `stream`).  scratch: workgroups * 256 floats. */
+int hn_probe_mfma(int dtype, int workgroups, int iters, float* scratch, double* flop_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
