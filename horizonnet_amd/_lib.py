@@ -88,6 +88,7 @@ SIGNATURES = {
     "hn_fold_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "hn_conv2d_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hn_stem": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hn_stem_pool_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hn_upsample_flatten": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "hn_lstm_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "hn_linear_head": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

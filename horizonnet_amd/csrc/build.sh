@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=${HN_BUILD_OUT:-../libhorizonnet_hip.so}      # HN_BUILD_OUT / HN_BUILD_FLAGS / HN_BUILD_OBJ: throw-away measurement builds (tools/ab_lib.sh)
 OBJDIR=${HN_BUILD_OBJ:-../../build/obj}
-SRCS="engine.hip engine_bf16.hip train.hip conv_igemm_f32.hip conv_wgrad_f32.hip conv_wgrad_bf16.hip bn_fold.hip conv_igemm_bf16.hip conv_igemm_bf16_pp.hip conv3x3_dwr_bf16.hip conv3x3_dwr64_bf16.hip stem_pool_bf16.hip elementwise.hip train_ops.hip lstm.hip lstm_wide_f32.hip lstm_bf16.hip panostretch.hip augment.hip labels.hip peaks.hip multi_job.hip layout_fit.hip probe.hip"
+SRCS="engine.hip engine_bf16.hip train.hip conv_igemm_f32.hip conv_wgrad_f32.hip conv_wgrad_bf16.hip bn_fold.hip conv_igemm_bf16.hip conv_igemm_bf16_pp.hip conv3x3_dwr_bf16.hip conv3x3_dwr64_bf16.hip stem_pool_bf16.hip stem_pool_f32.hip elementwise.hip train_ops.hip lstm.hip lstm_wide_f32.hip lstm_bf16.hip panostretch.hip augment.hip labels.hip peaks.hip multi_job.hip layout_fit.hip probe.hip"
 mkdir -p $OBJDIR
 OBJS=""
 for f in $SRCS; do

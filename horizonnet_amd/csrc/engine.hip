@@ -447,8 +447,13 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
     {
         const ConvLayer& c = a.convs[a.stem];
         ProfScope ps(e, s, "stem(prep+conv7x7+maxpool)", 2.0 * B * 256 * 512 * 64.0 * 147);
-        if ((rc = hn_stem(x, B, C_in, IMG_H, IMG_W, P + c.w_off, P + c.scale_off, P + c.shift_off, W + pl.xn, W + pl.stem,
-                          W + pl.pool, (void*)s)))
+        // one kernel (stem_pool_f32.hip: normalise + conv + BN + ReLU + max-pool out of an LDS ring of input rows) unless a parity tap
+        // wants the 2.1 GB stem activation itself, which only the three-launch form writes (option "fuse_stem_pool", HN_F32_STEM_POOL=0: A/B)
+        static const char* fsp = getenv("HN_F32_STEM_POOL");
+        if (e->fuse_stem_pool && e->taps.empty() && !(fsp && fsp[0] == '0')) {
+            if ((rc = hn_launch_stem_pool_f32(x, C_in, P + c.w_off, P + c.scale_off, P + c.shift_off, W + pl.pool, B, s))) return rc;
+        } else if ((rc = hn_stem(x, B, C_in, IMG_H, IMG_W, P + c.w_off, P + c.scale_off, P + c.shift_off, W + pl.xn, W + pl.stem,
+                                 W + pl.pool, (void*)s)))
             return rc;
     }
     if ((rc = e->tap("stem", W + pl.stem, (size_t)B * 256 * 512 * 64 * sizeof(float), s))) return rc;
@@ -772,6 +777,13 @@ extern "C" int hn_stem(const float* x_nchw, int B, int C_in, int H, int W, const
     d.Ho = H / 2; d.Wo = W / 2; d.relu = 1; d.ldy = 64; d.stem = 1;
     if ((rc = hn_launch_conv(d, s))) return rc;
     return hn_launch_maxpool(stem_out, pool_out, B, H / 2, W / 2, 64, s);
+}
+
+extern "C" int hn_stem_pool_f32(const float* x_nchw, int B, int C_in, const float* w_packed, const float* scale, const float* shift, float* pool_out,
+                                void* stream)
+{
+    HN_REQUIRE(x_nchw && w_packed && scale && shift && pool_out, "hn_stem_pool_f32: null pointer");
+    return hn_launch_stem_pool_f32(x_nchw, C_in, w_packed, scale, shift, pool_out, B, (hipStream_t)stream);
 }
 
 extern "C" int hn_upsample_flatten(const float* in, float* seq, int B, int hq, int Wq, int cq, int col0, void* stream)

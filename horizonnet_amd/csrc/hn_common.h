@@ -199,6 +199,7 @@ int hn_launch_prep_nhwc4_bf16(const float* x, void* out, int B, int C_in, int H,
 int hn_launch_maxpool_bf16(const void* in, void* out, int B, int Hi, int Wi, int C, hipStream_t s);
 int hn_launch_stem_pool_bf16(const float* x, int C_in, const void* wpk, const float* scale, const float* shift, void* y, int B, hipStream_t s,
                              const void* w1 = nullptr, const float* scale1 = nullptr, const float* shift1 = nullptr, void* t1 = nullptr);
+int hn_launch_stem_pool_f32(const float* x, int C_in, const float* wpk, const float* scale, const float* shift, float* y, int B, hipStream_t s);
 int hn_launch_upsample_flatten_bf16(const void* in, void* seq, int B, int hq, int Wq, int cq, int col0, hipStream_t s);
 int hn_launch_conv1x1_dual_f32(const float* t2, const float* w1, const float* scale1, const float* shift1, const float* x, const float* w2,
                                const float* scale2, const float* shift2, float* y, int B, int Ho, int Wo, int K1, int Hi2, int Wi2, int K2,

@@ -398,6 +398,13 @@ int hn_stem(const float* x_nchw, int B, int C_in, int H, int W, const float* w_p
             const float* scale, const float* shift, float* tmp_nhwc4, float* stem_out,
             float* pool_out, void* stream);
 
+/* The same stem as ONE kernel (csrc/stem_pool_f32.hip; what hn_forward runs unless a parity tap asks for the un-pooled stem activation):
+ * x NCHW [B][C_in >= 3][512][1024] float32 -> pool_out [B][128][256][64] float32.  w_packed: the stem matrix hn_pack_conv_weight(64, 3, 7, 7)
+ * produces, scale / shift: folded BatchNorm [64].  Agrees with hn_stem to float32 rounding (a different summation order over the 147 taps).
+ * (reference model.py:248-252,73-76) */
+int hn_stem_pool_f32(const float* x_nchw, int B, int C_in, const float* w_packed, const float* scale, const float* shift, float* pool_out,
+                     void* stream);
+
 /* Circular linear up-sampling along W to 256 columns + (c,h) flatten into the sequence
  * matrix (reference model.py:151-155,175-178).  in: [B][hq][Wq][cq]; seq: [256*B][1024] with
  * row = t*B + b and column = col0 + c*hq + h. */

@@ -112,6 +112,40 @@ def test_stem_stage(B, H, W, cin):
     assert ok1 and ok2
 
 
+@pytest.mark.parametrize("B,cin", [(1, 3), (2, 4), (5, 3), (33, 3)])
+def test_stem_pool_f32_fused_stage(B, cin):
+    """hn_stem_pool_f32 (csrc/stem_pool_f32.hip: normalise + 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in one kernel, what hn_forward runs)
+    against torch float32 (reference model.py:248-252,73-76) at the full 512 x 1024, every band height the launcher picks (B = 1: 2 pooled
+    rows per workgroup ... B = 33: 16), and against the three-launch form hn_stem (same values up to the summation order of the 147 taps).
+    The output buffer starts as NaN: every pooled pixel must be written."""
+    L = lib()
+    sd = make_state_dict(3, "random")
+    enc = "feature_extractor.encoder."
+    H, W = 512, 1024
+    x = torch.rand((B, cin, H, W), generator=torch.Generator().manual_seed(19))
+    if B <= 5:
+        xn = horizonnet_ref.prepare_x(x)
+        y = torch.relu(horizonnet_ref._bn(horizonnet_ref._conv(xn, sd, enc + "conv1.1", 2, 7), sd, enc + "bn1"))
+        want_pool = torch.nn.functional.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    w = sd[enc + "conv1.1.weight"].to(DEV)
+    wp = torch.empty(L.hn_packed_conv_weight_floats(64, 3, 7, 7), device=DEV)
+    _lib.check(L.hn_pack_conv_weight(P(w), P(wp), 64, 3, 7, 7, sp()), "pack")
+    g, b, m, v = (sd[enc + "bn1." + k].to(DEV) for k in ("weight", "bias", "running_mean", "running_var"))
+    scale, shift = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    _lib.check(L.hn_fold_bn(P(g), P(b), P(m), P(v), None, P(scale), P(shift), 64, sp()), "fold")
+    xd = x.to(DEV)
+    pool = torch.full((B, H // 4, W // 4, 64), float("nan"), device=DEV)
+    _lib.check(L.hn_stem_pool_f32(P(xd), B, cin, P(wp), P(scale), P(shift), P(pool), sp()), "stem_pool_f32")
+    tmp = torch.empty((B, H, W, 4), device=DEV)
+    stem3 = torch.empty((B, H // 2, W // 2, 64), device=DEV)
+    pool3 = torch.full((B, H // 4, W // 4, 64), float("nan"), device=DEV)
+    _lib.check(L.hn_stem(P(xd), B, cin, H, W, P(wp), P(scale), P(shift), P(tmp), P(stem3), P(pool3), sp()), "stem")
+    torch.cuda.synchronize()
+    assert report("fused f32 stem vs three launches B=%d" % B, pool.cpu().numpy(), pool3.cpu().numpy(), 2e-5)
+    if B <= 5:
+        assert report("fused f32 stem vs torch B=%d" % B, pool.cpu().numpy(), want_pool.numpy(), 3e-5)
+
+
 @pytest.mark.parametrize("hq,Wq,cq,col0", [(8, 256, 32, 0), (4, 128, 64, 256), (2, 64, 128, 512), (1, 32, 256, 768)])
 def test_upsample_flatten_stage(hq, Wq, cq, col0):
     B = 3
