@@ -89,7 +89,10 @@ struct hn_engine {
     int fuse_stem_bnpool = 1;            // bf16 training forward: the stem's BatchNorm + ReLU + max-pool in one pass ("fuse_stem_bnpool")
     int fuse_bn_dual = 1;                // bf16 training backward: block 0's bn3 and downsample BatchNorm adjoints in one reduce + one apply pass ("fuse_bn_dual")
     int fuse_bn_fold = 1;                // bf16 training backward: conv3 / stride-1 downsample units through the BatchNorm-folded adjoint (bn_fold.hip, "fuse_bn_fold"; 1 = forward and adjoint, 2 = adjoint only)
-    std::vector<unsigned char> fold_fwd; // per training unit: 1 = the last hn_train_forward ran it through bn_fold_forward (no z stored)
+    // per training WORKSPACE (the record travels with the forward whose activations a backward reads: two forwards on two workspaces -- different batch
+    // sizes, or options changed in between -- do not overwrite each other's), per training unit: 1 = that hn_train_forward ran the unit through
+    // bn_fold_forward (no z stored)
+    std::unordered_map<const void*, std::vector<unsigned char>> fold_fwd;
     int fuse_stem_poolbwd = 1;           // bf16 training backward: the stem's BatchNorm adjoint gathers the max-pool adjoint itself ("fuse_stem_poolbwd")
     int fuse_stem_pool = 1;              // hn_forward_bf16: 7x7 conv + BN + ReLU + max-pool in one kernel ("fuse_stem_pool"; taps use the two-kernel form)
     int chain_layer1 = 1;                // hn_forward_bf16: layer1.1.conv3 (+ residual) chained into layer1.2.conv1 ("chain_layer1")

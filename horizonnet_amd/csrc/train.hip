@@ -411,7 +411,8 @@ int bn_backward_dual(const Ctx& c, const Unit& ua, const Unit& ub, const float* 
 bool fwd_folded(const Ctx& c, const Unit& u)
 {
     const size_t i = (size_t)(&u - c.pl.units.data());
-    return i < c.e->fold_fwd.size() && c.e->fold_fwd[i] != 0;
+    auto it = c.e->fold_fwd.find(c.W);
+    return it != c.e->fold_fwd.end() && i < it->second.size() && it->second[i] != 0;
 }
 
 struct FoldOut {
@@ -703,7 +704,9 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
     // backbone + height compression
     static const char* fold_env = getenv("HN_BN_FOLD");
     const bool fold_fwd_on = !(fold_env && fold_env[0] == 'b') && e->fuse_bn_fold == 1;       // "b" / option value 2: classical forward (z stored), folded adjoint
-    e->fold_fwd.assign(pl.units.size(), 0);
+    if (e->fold_fwd.size() > 64 && e->fold_fwd.find(workspace) == e->fold_fwd.end()) e->fold_fwd.clear();     // (re-allocated workspaces: keep the table small)
+    std::vector<unsigned char>& fold_fwd = e->fold_fwd[workspace];
+    fold_fwd.assign(pl.units.size(), 0);
     for (int li = 0; li < 4; ++li) {
         for (int j = 0; j < kBlocks[li]; ++j) {
             const int i1 = pl.blk[li][j];
@@ -720,13 +723,13 @@ extern "C" int hn_train_forward(hn_engine* e, const float* x, int B, int C_in, f
                 const Unit& ud = pl.units[pl.dsu[li]];
                 if (fold3) {
                     if ((rc = bn_fold_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
-                    e->fold_fwd[pl.dsu[li]] = 1;
+                    fold_fwd[pl.dsu[li]] = 1;
                 } else if ((rc = conv_z(c, ud)) || (rc = bn_forward(c, ud, nullptr, 0, bn_momentum))) return rc;
                 idt = e->train_bf16 ? W + ud.yh : W + ud.y;
             }
             if (fold3) {
                 if ((rc = bn_fold_forward(c, u3, idt, 1, bn_momentum))) return rc;
-                e->fold_fwd[i1 + (j == 0 ? 3 : 2)] = 1;
+                fold_fwd[i1 + (j == 0 ? 3 : 2)] = 1;
             } else
             if ((rc = conv_z(c, u3)) || (rc = bn_forward(c, u3, idt, 1, bn_momentum, e->train_bf16))) return rc;
         }
@@ -961,6 +964,8 @@ static int train_backward_impl(hn_engine* e, const float* dbon, const float* dco
             const bool fold3 = bn_fold_ok(c, u3) && (j > 0 || bn_fold_ok(c, pl.units[pl.dsu[li]]));
             HN_REQUIRE(fold3 || !fwd_folded(c, u3), "hn_train_backward: the forward ran %s through the BatchNorm-folded form (no z stored) but the adjoint "
                        "cannot (a debug tap or an option changed in between): set the option fuse_bn_fold = 0 BEFORE the forward", a.convs[u3.ci].wkey.c_str());
+            HN_REQUIRE(fold3 || j > 0 || !fwd_folded(c, pl.units[pl.dsu[li]]), "hn_train_backward: the forward ran %s through the BatchNorm-folded form (no z "
+                       "stored) but the adjoint cannot: set the option fuse_bn_fold = 0 BEFORE the forward", a.convs[pl.units[pl.dsu[li]].ci].wkey.c_str());
             if (fold3) {
                 FoldOut f3, fd;
                 const Unit* ud = j == 0 ? &pl.units[pl.dsu[li]] : nullptr;
