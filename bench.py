@@ -496,7 +496,7 @@ def train_roofline(dtype, B, s_per_step, achieved_tflops, peak):
                 "note": "per GPU, against the dense fp32 matrix peak (157.3 TF)"}
     t_mixed, fl, by, t_hbm = train_mixed_roofline(B)
     traffic = stale = note = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_train.json", "r4_pmc_train.json")) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r6_pmc_train.json", "r5_pmc_train.json", "r4_pmc_train.json")) if os.path.exists(q)), "")
     if B == 64 and tpath:
         from horizonnet_amd import _lib as _l
         rec = json.load(open(tpath))
@@ -960,7 +960,7 @@ def main():
         traffic, traffic_note = None, None               # HBM-side bytes per forward from the committed PMC passes of the newest round's kernels
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         traffic_stale = None
-        for tname in ("r5_pmc_forward.json", "r4_pmc_forward.json", "r3_pmc_forward.json", "r2_pmc_forward.json"):
+        for tname in ("r6_pmc_forward.json", "r5_pmc_forward.json", "r4_pmc_forward.json", "r3_pmc_forward.json", "r2_pmc_forward.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if B == 32 and os.path.exists(tpath):
                 whole = json.load(open(tpath))

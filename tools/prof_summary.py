@@ -21,7 +21,7 @@ def family(name):
     if "multi_job" in n:
         return "pack_multi_job"                         # weight packing, once per engine
     for key in ("conv3x3_dwr64_bf16", "conv3x3_dwr_bf16", "conv_igemm_bf16_pp", "bn_bwd_reduce", "bn_bwd_apply", "affine_act_bn", "adam_flat", "labels_rasterise", "conv_igemm_bf16_w8", "conv1x1_dual_bf16", "conv1x1_chain_bf16", "conv1x1_dual_f32", "conv_igemm_bf16", "conv_igemm_kernel", "conv_wgrad",
-                "splitk_reduce", "stem_pool_bf16", "lstm_layer_bf16", "lstm_layer",
+                "splitk_reduce", "stem_pool_bf16", "stem_pool_f32", "mfma_rate", "lstm_layer_bf16", "lstm_layer",
                 "maxpool", "prep_nhwc", "upsample_flatten", "linear_head", "f32_to_bf16", "pack_", "fold_bn", "find_peaks", "pano_stretch",
                 "augment"):
         if key in n:
