@@ -284,7 +284,8 @@ int hn_launch_bn_fold_finish(float* P, float* keep, int wg_ready, const double* 
     if (!wg_ready)
         if (int rc = gemm_wg(p.Wf, keep_G(keep, K), WG, N, K, ones, zeros, s)) return rc;
     // Q[k][j] = sum_n eW[n][k] Wf[n][j]   (the float32 weight-gradient GEMM with the channel index n as its reduction index)
-    if (int rc = hn_launch_conv_wgrad(p.Wf, p.eW, Qf, 1, 1, N, K, K, 1, 1, 1, 1, 0, 0, 0, s, /*prezeroed=*/1)) return rc;
+    // (at most two row splits: two float partials commute, so Q -- and with it the data gradient of every unit upstream -- repeats bit for bit)
+    if (int rc = hn_launch_conv_wgrad(p.Wf, p.eW, Qf, 1, 1, N, K, K, 1, 1, 1, 1, 0, 0, 0, s, /*prezeroed=*/1, /*max_split=*/2)) return rc;
     const long nk = (long)N * K;
     long gx = (nk + 255) / 256;
     if (gx > 2048) gx = 2048;

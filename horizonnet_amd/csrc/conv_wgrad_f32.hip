@@ -268,13 +268,16 @@ __global__ __launch_bounds__(256) void pack_conv_dgrad_kernel(const float* __res
 }
 
 template <int TN, int TK, bool STEM>
-int launch_wgrad(WgradArgs a, hipStream_t s)
+int launch_wgrad(WgradArgs a, hipStream_t s, int max_split = 0)
 {
     const int NT = (a.Cout + TN - 1) / TN, KT = a.K / TK;
     // split the reduction so that ~2048 workgroups exist, each with >= 8 chunks
     static const long target = getenv("HN_WGRAD_WGS") ? atol(getenv("HN_WGRAD_WGS")) : 2048;
     long split = target / ((long)NT * KT);
     if (split < 1) split = 1;
+    // max_split = 2: at most two partial tiles meet in the float atomics of an output element, and 0 + a + b == 0 + b + a: a run-to-run
+    // reproducible result (the folded BatchNorm adjoint's Q, which feeds the data gradient: bn_fold.hip)
+    if (max_split > 0 && split > max_split) split = max_split;
     long mchunk = (a.M + split - 1) / split;
     if (mchunk < 8 * WCH) mchunk = 8 * WCH;
     mchunk = (mchunk + WCH - 1) / WCH * WCH;
@@ -298,7 +301,7 @@ int launch_wgrad(WgradArgs a, hipStream_t s)
 
 // dw_packed must hold hn_packed_conv_weight_floats() floats; it is zeroed here (unless `prezeroed`) and accumulated by the kernel.
 int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed)
+                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed, int max_split)
 {
     WgradArgs a;
     a.x = x; a.dz = dz; a.dw = dw_packed;
@@ -319,11 +322,11 @@ int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int 
     HN_REQUIRE(Cin % 64 == 0 && Cout % 32 == 0, "wgrad: Cin=%d must be a multiple of 64, Cout=%d of 32", Cin, Cout);
     a.K = KH * KW * Cin;
     if (!prezeroed) HN_HIP(hipMemsetAsync(dw_packed, 0, (size_t)Cout * a.K * sizeof(float), s));
-    if (Cout % 64 != 0) return launch_wgrad<64, 64, false>(a, s);
-    if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad<128, 128, false>(a, s);
-    if (Cout % 128 == 0) return launch_wgrad<128, 64, false>(a, s);
-    if (Cin % 128 == 0) return launch_wgrad<64, 128, false>(a, s);
-    return launch_wgrad<64, 64, false>(a, s);
+    if (Cout % 64 != 0) return launch_wgrad<64, 64, false>(a, s, max_split);
+    if (Cout % 128 == 0 && Cin % 128 == 0) return launch_wgrad<128, 128, false>(a, s, max_split);
+    if (Cout % 128 == 0) return launch_wgrad<128, 64, false>(a, s, max_split);
+    if (Cin % 128 == 0) return launch_wgrad<64, 128, false>(a, s, max_split);
+    return launch_wgrad<64, 64, false>(a, s, max_split);
 }
 
 // packed_rows: dh rows per output channel in `wp` (KH for the forward packing, 8 for the stem's wgrad scratch)

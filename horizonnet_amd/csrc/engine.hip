@@ -281,6 +281,7 @@ extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
     if (strcmp(name, "fuse_stem_poolbwd") == 0) { e->fuse_stem_poolbwd = value ? 1 : 0; return 0; }
     if (strcmp(name, "fuse_bn_dual") == 0) { e->fuse_bn_dual = value ? 1 : 0; return 0; }
     if (strcmp(name, "fuse_bn_fold") == 0) { e->fuse_bn_fold = value == 2 ? 2 : (value ? 1 : 0); return 0; }      // 2: folded adjoint over a classical forward
+    if (strcmp(name, "fold_deterministic") == 0) { e->fold_deterministic = value ? 1 : 0; return 0; }
     if (strcmp(name, "chain_layer1") == 0) { e->chain_layer1 = value ? 1 : 0; return 0; }
     if (strcmp(name, "lstm_wide_rows") == 0) { e->wide_rows = value == 8 ? 8 : 16; return 0; }
     if (strcmp(name, "lstm_wide_xcds") == 0) { e->wide_xcds = value == 2 ? 2 : 1; return 0; }

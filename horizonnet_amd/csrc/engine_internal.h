@@ -93,6 +93,8 @@ struct hn_engine {
     // sizes, or options changed in between -- do not overwrite each other's), per training unit: 1 = that hn_train_forward ran the unit through
     // bn_fold_forward (no z stored)
     std::unordered_map<const void*, std::vector<unsigned char>> fold_fwd;
+    int fold_deterministic = 1;          // bf16 training backward: the folded units' P-GEMM (g^T a, which feeds S2, dW AND the data-gradient weights) through the
+                                         // reproducible slab reduce instead of float atomics in arrival order ("fold_deterministic"; HN_FOLD_SLAB=0: atomics, A/B)
     int fuse_stem_poolbwd = 1;           // bf16 training backward: the stem's BatchNorm adjoint gathers the max-pool adjoint itself ("fuse_stem_poolbwd")
     int fuse_stem_pool = 1;              // hn_forward_bf16: 7x7 conv + BN + ReLU + max-pool in one kernel ("fuse_stem_pool"; taps use the two-kernel form)
     int chain_layer1 = 1;                // hn_forward_bf16: layer1.1.conv3 (+ residual) chained into layer1.2.conv1 ("chain_layer1")

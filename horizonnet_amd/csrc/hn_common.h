@@ -164,7 +164,7 @@ int hn_launch_pack_conv(const float* w, float* out, int Cout, int Cin, int KH, i
 int hn_launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                       float* scale, float* shift, int C, hipStream_t s);
 int hn_launch_conv_wgrad(const float* x, const float* dz, float* dw_packed, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
-                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed = 0);
+                         int sh, int sw, int xstride, int dzstride, int stem, hipStream_t s, int prezeroed = 0, int max_split = 0);
 int hn_launch_unpack_conv(const float* wp, float* w_oihw, int Cout, int Cin, int KH, int KW, int packed_rows, hipStream_t s);
 int hn_launch_stem_conv_train_bf16(const float* x, int C_in, const void* wpk, void* z, double* stat_sum, double* stat_sq, int B, hipStream_t s);
 int hn_launch_stem_wgrad_bf16(const void* x4_h, const void* dz_h, float* dw_packed, int B, int Hi, int Wi, hipStream_t s, int prezeroed);

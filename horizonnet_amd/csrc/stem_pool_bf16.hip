@@ -354,9 +354,12 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
         }
     }
     if (TRAIN) {
-        // per channel: the 32 pixel lanes of a half wave (xor butterfly), then one LDS atomic per (wave, half, channel), then one
-        // float64 atomic per channel and workgroup
-        float* red = reinterpret_cast<float*>(smem + SC_OFF);            // [64] sums, [64] sums of squares (zeroed at the start)
+        // per channel: the 32 pixel lanes of a half wave (xor butterfly), then the eight waves' partials through LDS in WAVE ORDER (round 6: they
+        // used to meet in float LDS atomics, i.e. in arrival order -- the one float-order dependence of the training forward: 1 % of B = 3
+        // forwards took a different bf16 rounding path downstream, tools/soak_determinism.py), then one float64 atomic per channel and workgroup
+        // (a double sum of float partials of similar magnitude is exact, so its order does not matter)
+        float* part = reinterpret_cast<float*>(smem + H_OFF);             // [8 waves][128]: sums, sums of squares (the pooling strip is free now)
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -369,14 +372,16 @@ __global__ __launch_bounds__(512) void stem_pool_bf16_kernel(const float* __rest
                 }
                 if (fr == 0) {
                     const int ch = 32 * j + 8 * (q >> 2) + 4 * half + (q & 3);
-                    atomicAdd(red + ch, a);
-                    atomicAdd(red + 64 + ch, c2);
+                    part[wave * 128 + ch] = a;
+                    part[wave * 128 + 64 + ch] = c2;
                 }
             }
         __syncthreads();
-        if (tid < 64) {
-            atomicAdd(stat_sum + tid, (double)red[tid]);
-            atomicAdd(stat_sq + tid, (double)red[64 + tid]);
+        if (tid < 128) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += (double)part[w * 128 + tid];
+            atomicAdd((tid < 64 ? stat_sum : stat_sq) + (tid & 63), t);
         }
     }
 }

@@ -447,7 +447,9 @@ int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* 
     int rc;
     const int fwd = fwd_folded(c, u);            // the forward of this step was folded too: G, A, Wf, WG are in the unit's keep storage
     HN_HIP(hipMemsetAsync(ws, 0, hn_bn_fold_zero_bytes(K), c.s));      // Q
-    if (!fwd && (rc = hn_launch_bn_fold_gram(c.W + u.xh, u.M, K, keep, c.s))) return rc;
+    static const char* slab_env = getenv("HN_FOLD_SLAB");
+    const bool det = c.e->fold_deterministic && !(slab_env && slab_env[0] == '0');
+    if (!fwd && (rc = hn_launch_bn_fold_gram(c.W + u.xh, u.M, K, keep, c.s, det ? c.W + c.pl.dzh[1] : nullptr, det ? c.pl.gmax / 2 : 0))) return rc;
     // P = g^T a into the unit's weight-gradient scratch (zeroed with all the others at the start of the pass)
     float* P = c.W + u.wg;
     const void* wh = reinterpret_cast<const unsigned short*>(c.e->packed_h) + hn_bf16_conv_offset(u.ci);
@@ -456,7 +458,12 @@ int bn_fold_unit(const Ctx& c, const Unit& u, float* g_io, const unsigned char* 
         wa_early = hn_bn_fold_wa_ptr(ws, N, K);
         if ((rc = hn_launch_bn_fold_wa(wh, c.bound(cl.bnkey + ".weight"), st + N, wa_early, N, K, c.s))) return rc;
     }
-    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, g_io, P, u.M, K, N, bmask, s1_src ? nullptr : ds, c.s, 1, nullptr, 0, wa_early, a_part, write_back)))
+    // Round 6: P feeds S2, dW and BOTH data-gradient weight matrices, so float atomics in arrival order here made every gradient UPSTREAM of a folded
+    // unit differ from run to run (worst gradient norm +-1e-2 on the seeded B = 1 net; the classical adjoint, whose only float atomics end in leaf
+    // dW tensors, repeats to 1e-8).  Default: the slab form (per-split partial tiles with plain stores + an ordered double-precision reduce,
+    // conv_wgrad_bf16.hip) in the second dz staging buffer, which no folded block uses (need <= 2.2 M floats per panorama, the buffer holds 4.2 M).
+    if ((rc = hn_launch_conv_wgrad_bf16_fold(c.W + u.xh, g_io, P, u.M, K, N, bmask, s1_src ? nullptr : ds, c.s, 1, det ? c.W + c.pl.dzh[1] : nullptr,
+                                             det ? c.pl.gmax / 2 : 0, wa_early, a_part, write_back)))
         return rc;
     if ((rc = hn_launch_bn_fold_finish(P, keep, fwd, s1_src ? s1_src : ds, ds, ds + N, wh, st, st + N, c.bound(cl.bnkey + ".weight"), (double)u.M, N, K, ws,
                                        c.P + c.a.ones_off, c.P + c.a.zeros_off, &out->wa, &out->shift_a, &out->wb, c.s)))

@@ -1065,13 +1065,25 @@ def test_train_step_bf16_b16_vs_reference(golden_dir):
               "worst rel %.3e (%s), median %.3e; sampled gradient entries worst %.3e of the tensor's max" % (
                   B, fold, float(loss), float(g["loss"]), d_out, tot, float(rel[big].max()), names[int(np.argmax(np.where(big, rel, 0)))],
                   float(np.median(rel[big])), samp))
-        # measured (round 5): folded form loss 3e-5 rel, outputs 9.1e-3, norms: total 0.9968, median 1.2e-3, worst 6.6e-2 (the stem's weight: the end of
-        # the backward chain); classical form total 0.9943, worst 1.4e-1 -- the folded adjoint is the MORE accurate of the two (it never rounds z
-        # or dz to bf16).  Bounds = ~1.3 x measured.
-        # (float atomics in the adjoint: the worst tensor moved 6.0e-2 .. 7.4e-2 (folded) and 9.7e-2 .. 1.4e-1 (classical) between runs)
-        worst_b, tot_b = (0.11, 0.006) if fold else (0.19, 0.008)
-        ok &= abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) and d_out <= 0.012
-        ok &= abs(tot - 1.0) <= tot_b and float(rel[big].max()) <= worst_b and float(np.median(rel[big])) <= 1.6e-3
+        # Round 6: the step is run-to-run REPRODUCIBLE (the stem's statistics meet in wave order, the folded units' P-GEMM goes through the ordered
+        # slab reduce, their Q GEMM has at most two commuting partials; what is left are float atomics that END in leaf weight gradients, 1e-8 of a
+        # norm): a second forward + backward on the same net must give the same output bits and the same gradient norms to 1e-6.  Up to round 5 the
+        # worst tensor moved 6.0e-2 .. 7.4e-2 (folded) / 9.7e-2 .. 1.4e-1 (classical) between runs and the bounds below were sized to that noise.
+        net.zero_grad(set_to_none=True)
+        bon2, cor2 = net(x)
+        (F.l1_loss(bon2, y_bon) + F.binary_cross_entropy_with_logits(cor2, y_cor)).backward()
+        torch.cuda.synchronize()
+        gn2 = np.array([float(params[k].grad.double().norm()) for k in names])
+        rep = float((np.abs(gn2 - gn) / np.maximum(gn, 1e-30))[big].max())
+        same_bits = bool(torch.equal(bon2, bon) and torch.equal(cor2, cor))
+        print("[parity] bf16 train step B=%d (fold=%d) repeated: outputs bit-identical %s, worst gradient-norm change %.3e" % (B, fold, same_bits, rep))
+        ok &= same_bits and rep <= 1e-6
+        # measured (round 6, deterministic): folded form loss 3e-5 rel, outputs 1.10e-2, norms: total 0.9970, median 1.18e-3, worst 6.1e-2 (the stem's
+        # weight: the end of the backward chain); classical form outputs 8.8e-3, total 0.9943, median 1.19e-3, worst 1.40e-1 -- the folded adjoint is
+        # the MORE accurate of the two (it never rounds z or dz to bf16).  Bounds = ~1.1 x measured: the arithmetic, no longer the atomics.
+        worst_b, tot_b = (0.068, 0.0035) if fold else (0.155, 0.0064)
+        ok &= abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) and d_out <= 0.0122
+        ok &= abs(tot - 1.0) <= tot_b and float(rel[big].max()) <= worst_b and float(np.median(rel[big])) <= 1.32e-3
     assert ok
 
 

@@ -128,6 +128,11 @@ def main():
               % (name, base_name, len(diff), d32, d32b, gd))
         if diff:
             print("[hunt]    first differing: %s" % ", ".join(diff[:12]))
+        rels = sorted(((abs(r["_gradnorm"][k] - base["_gradnorm"][k]) / (base["_gradnorm"][k] + 1e-30), k) for k in base["_gradnorm"]), reverse=True)
+        names = list(base["_gradnorm"].keys())
+        last = [k for k in names if abs(r["_gradnorm"][k] - base["_gradnorm"][k]) / (base["_gradnorm"][k] + 1e-30) > 1e-6]
+        print("[hunt]    gradient norms that moved by > 1e-6: %d of %d; the LAST such tensor in state_dict order (= the first the backward produces): %s; top: %s"
+              % (len(last), len(names), last[-1] if last else "-", ", ".join("%s %.1e" % (k[-40:], v) for v, k in rels[:3])))
         det = [k for k in diff if k.startswith("f32") or k.startswith("bf16.y") or k in ("bf16.bon", "bf16.cor")]
         bad = bad or bool(det)
     print("[hunt] RESULT: %s" % ("DIFFERENCES in deterministic tensors" if bad else "all deterministic tensors bit-identical across poison patterns"))
