@@ -828,7 +828,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+            # NOT bound with device_id=: torch's eager communicator init costs the HBM-bound bf16 legs 4-5 % and the B = 1 bf16 latency 0.4 ms on this
+            # part (tools/stream_pool_probe.py nccl_bench vs nccl_bench_nodev); torch.cuda.set_device(dev) above tells RCCL the device
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         rccl = rccl_report(dist, dev, world, rank, mbytes=326 if args.backend == "nccl" else 8)   # who is in the job + all-reduce bandwidth
@@ -1066,6 +1068,23 @@ def main():
             if "layout" in legs:                          # configs[4]: 1000 panoramas, end to end, IoU vs the reference's inference()
                 timed_leg("layout", lambda: layout_leg(dev, args.panoramas, 32, rooms["layout"], pool))
             out["leg_seconds"] = dict(leg_s, render_rooms=rooms.get("render_s"))
+            # the same legs against the rooflines THIS box measured in this run (out["box"]): the contract's fractions above use the guide's peaks
+            # (2.5 PF, 8 TB/s); a device copy reaches 5.2-5.5 TB/s and the dense bf16 MFMA rate 2.4 PF on the boxes of round 6
+            bx = out.get("box") or {}
+            if "mfma_bf16_tflops" in bx and "hbm_copy_GBps" in bx:
+                pf, bw = bx["mfma_bf16_tflops"] * 1e12, bx["hbm_copy_GBps"] * 1e9
+                r = (out.get("bf16_mode") or {}).get("roofline")
+                if isinstance(r, dict):
+                    tb = bf16_mixed_roofline(B, pf, bw)[0]
+                    r["frac_of_box_measured_mixed"] = round(out["bf16_mode"]["value"] / (B / tb), 4)
+                r = (out.get("train_bf16") or {}).get("roofline")
+                if isinstance(r, dict) and isinstance(out["train_bf16"].get("ms_per_step"), (int, float)):
+                    st_ = out["train_bf16"]["ms_per_step"] * 1e-3
+                    r["frac_of_box_measured_mixed"] = round(train_mixed_roofline(64, pf, bw)[0] / st_, 4)
+                    r["fused_minimum"]["frac_of_box_measured"] = round(train_mixed_roofline(64, pf, bw, fused_minimum=True)[0] / st_, 4)
+                ps_ = out.get("pano_stretch")
+                if isinstance(ps_, dict) and isinstance(ps_.get("roofline"), dict):
+                    ps_["roofline"]["frac_of_box_copy_rate"] = round(ps_["roofline"]["achieved"] / bx["hbm_copy_GBps"], 4)
         print(json.dumps(out))
     if pool is not None:
         pool.close()

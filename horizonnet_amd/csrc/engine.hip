@@ -281,6 +281,7 @@ extern "C" int hn_set_option(hn_engine* e, const char* name, int value)
     if (strcmp(name, "fuse_stem_poolbwd") == 0) { e->fuse_stem_poolbwd = value ? 1 : 0; return 0; }
     if (strcmp(name, "fuse_bn_dual") == 0) { e->fuse_bn_dual = value ? 1 : 0; return 0; }
     if (strcmp(name, "fuse_bn_fold") == 0) { e->fuse_bn_fold = value == 2 ? 2 : (value ? 1 : 0); return 0; }      // 2: folded adjoint over a classical forward
+    if (strcmp(name, "f32_branch") == 0) { e->f32_branch = value ? 1 : 0; return 0; }
     if (strcmp(name, "fold_deterministic") == 0) { e->fold_deterministic = value ? 1 : 0; return 0; }
     if (strcmp(name, "chain_layer1") == 0) { e->chain_layer1 = value ? 1 : 0; return 0; }
     if (strcmp(name, "lstm_wide_rows") == 0) { e->wide_rows = value == 8 ? 8 : 16; return 0; }
@@ -468,7 +469,7 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
     // stages are HBM-bound) every float32 launch already fills the matrix pipes of every compute unit, two workgroups of 64 KiB LDS each per CU,
     // so a second stream has nothing to fill.  Off by default (HN_F32_BRANCH=1 switches it on for A/B runs).
     static const char* fenv = getenv("HN_F32_BRANCH");
-    const bool fork = e->use_branch_stream && !e->profiling && e->branch_stream != nullptr && fenv && fenv[0] == '1';
+    const bool fork = e->use_branch_stream && !e->profiling && e->branch_stream != nullptr && (e->f32_branch || (fenv && fenv[0] == '1'));
     hipStream_t sb = fork ? e->branch_stream : s;
     if (forked) *forked = fork;
     for (int li = 0; li < 4; ++li) {

@@ -100,6 +100,8 @@ struct hn_engine {
     int chain_layer1 = 1;                // hn_forward_bf16: layer1.1.conv3 (+ residual) chained into layer1.2.conv1 ("chain_layer1")
     int bf16_lstm = 1;                   // hn_forward_bf16: 1 = bf16 recurrence kernel (lstm_bf16.hip), 0 = the float32 one (lstm.hip)
     int use_branch_stream = 1;           // 0: everything on the caller's stream (hn_set_option "branch_stream")
+    int f32_branch = 0;                  // float32 forward: 1 = the height-compression chains on the branch stream too (measured in round 6: no gain, DESIGN 6e.3;
+                                         // option "f32_branch", env HN_F32_BRANCH=1)
     int train_bf16 = 0;                  // 1: train-mode convs (forward + data gradient) on the bf16 matrix cores (hn_set_train_precision)
     int poison = -1;                     // debug instrument (env HN_POISON_WS / option "poison_ws"): -1 off, else the byte every workspace / scratch /
                                          // packed-weight / gradient range is filled with BEFORE each engine entry writes it (0xFF = NaN in f32, bf16

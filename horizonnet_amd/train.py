@@ -180,8 +180,9 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # generous collective time-out: a validation pass on rank 0 may outlast RCCL's default watchdog
-        dist.init_process_group(backend=os.environ.get("HN_DIST_BACKEND", "nccl"), device_id=device if os.environ.get("HN_DIST_BACKEND", "nccl") == "nccl" else None,
-                                timeout=datetime.timedelta(hours=2))
+        # (no device_id=: torch's eager RCCL init bound to the device costs the engine's HBM-bound bf16 kernels 4-5 %; the device is
+        #  selected with torch.cuda.set_device before the first collective)
+        dist.init_process_group(backend=os.environ.get("HN_DIST_BACKEND", "nccl"), timeout=datetime.timedelta(hours=2))
     np.random.seed(args.seed + rank)
     torch.manual_seed(args.seed + rank)
     ckpt_dir = os.path.join(args.ckpt, args.id)

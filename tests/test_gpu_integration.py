@@ -529,3 +529,25 @@ def test_fused_adam_drives_the_engine_like_torch_adam():
     with torch.no_grad():
         b1, _ = nets[1](x)
     assert bool(torch.isfinite(b1).all())
+
+
+def test_rccl_collective_before_the_engine_does_not_cost_the_pipelined_forward():
+    """VERDICT r5 item 5.  Up to round 5 the engine's head stream had the highest priority; a process that ran ONE RCCL collective before the engine's
+    first forward then lost 26 % of the pipelined bf16 forward (the recurrent head and the next batch's trunk in one in-order hardware queue;
+    tools/stream_pool_probe.py).  Two fresh processes -- nothing before the engine / 36 pool streams + a collective first -- must now
+    agree (the measured difference after the fix is +1.5 %; 8 % leaves room for run-to-run noise of a 40-batch timing)."""
+    import re
+    import subprocess
+    import sys
+    rates = {}
+    for mode in ("clean", "nccl_first"):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env["MASTER_PORT"] = "29547"
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_pool_probe.py"), mode, "bf16", "40"], capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        m = re.search(r": ([0-9.]+) panoramas/s", out.stdout)
+        assert m, out.stdout[-2000:]
+        rates[mode] = float(m.group(1))
+    print("[streams] pipelined bf16 forward: clean %.1f, after an RCCL collective %.1f panoramas/s" % (rates["clean"], rates["nccl_first"]))
+    assert rates["nccl_first"] >= 0.92 * rates["clean"]

@@ -614,6 +614,62 @@ def test_forward_async_f32_pipelined_matches_forward_and_golden(golden_dir):
     assert report("pipelined f32 forward vs reference golden (cor)", cor.cpu().numpy(), g["cor"], 2e-5)
 
 
+def test_f32_branch_stream_option_is_bit_identical():
+    """Option "f32_branch" (the float32 height-compression chains on the engine's branch stream, deferred join in the pipelined entry;
+    measured without gain in round 6 and off by default): same kernels, so the same bits as the one-stream forward, plain and pipelined,
+    several batches in flight."""
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(5, "random"))
+    net = net.to(DEV).eval()
+    gen = torch.Generator().manual_seed(79)
+    xs = [torch.rand(6, 3, 512, 1024, generator=gen).to(DEV) for _ in range(4)]
+
+    def run_all():
+        with torch.no_grad():
+            plain = [tuple(t.clone() for t in net(x)) for x in xs]
+            piped, pend = [], None
+            for x in xs:
+                p_ = net.forward_async(x)
+                if pend is not None:
+                    piped.append(tuple(t.clone() for t in pend.result()))
+                pend = p_
+            piped.append(tuple(t.clone() for t in pend.result()))
+            torch.cuda.synchronize()
+        assert net.hip_status(DEV) == 0
+        return plain, piped
+
+    base_plain, base_piped = run_all()
+    net.set_engine_option("f32_branch", 1)
+    fork_plain, fork_piped = run_all()
+    net.set_engine_option("f32_branch", 0)
+    for a, b in zip(base_plain + base_piped, fork_plain + fork_piped):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_engine_poison_does_not_change_results(precision):
+    """hn_engine::poison (option "poison_ws" / HN_POISON_WS): every range an entry is about to write is filled with NaN bytes (1) or 0x7F bytes (2)
+    first.  A forward that reads nothing but what it wrote gives the same bits with the instrument off, on, and on with the other pattern."""
+    net = HorizonNet("resnet50", True)
+    net.load_state_dict(make_state_dict(6, "random"))
+    net = net.to(DEV).eval()
+    net.precision = precision
+    x = torch.rand(3, 3, 512, 1024, generator=torch.Generator().manual_seed(80)).to(DEV)
+    outs = []
+    for mode in (0, 1, 2, 0):
+        net.set_engine_option("poison_ws", mode)
+        for st in net._hip_states.values():               # force a re-pack: the packed buffers are poisoned before the pack as well
+            st.signature = None
+            st.signature_h = None
+        with torch.no_grad():
+            bon, cor = net(x)
+        torch.cuda.synchronize()
+        assert net.hip_status(DEV) == 0 and bool(torch.isfinite(bon).all()) and bool(torch.isfinite(cor).all())
+        outs.append((bon.clone(), cor.clone()))
+    for b, c in outs[1:]:
+        assert torch.equal(b, outs[0][0]) and torch.equal(c, outs[0][1])
+
+
 def test_pano_stretch_symmetric_kernel_equals_per_pixel_kernel():
     """pano_stretch_sym3_kernel (one arctangent per four mirror-image pixels, power-of-two H x W x 3) against the per-pixel
     kernel: same bits for every pixel, with the kernel's own column terms and with numpy's tables, for random stretch factors
