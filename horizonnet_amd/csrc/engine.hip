@@ -465,11 +465,14 @@ int run_trunk_f(hn_engine* e, const float* x, int B, int C_in, float* W, const P
     const float* cur = W + pl.pool;
     int H = 128, Wd = 256;
     const int nblk[4] = {3, 4, 6, 3};
-    // Measured in round 6 (B = 32, one box): 846.5 panoramas/s on one stream, 843.3 forked + joined, 849.8 forked + deferred join: unlike bf16 (whose
-    // stages are HBM-bound) every float32 launch already fills the matrix pipes of every compute unit, two workgroups of 64 KiB LDS each per CU,
-    // so a second stream has nothing to fill.  Off by default (HN_F32_BRANCH=1 switches it on for A/B runs).
+    // Measured in round 6 (one box).  B = 32: 846.5 panoramas/s on one stream, 843.3 forked + joined, 849.8 forked + deferred join -- unlike bf16 (whose
+    // stages are HBM-bound) every float32 launch already fills the matrix pipes of every compute unit, two workgroups of 64 KiB LDS each per CU, so a
+    // second stream has nothing to fill.  The interactive regime is different: at B <= 4 a launch is 32 .. 128 tiles on 256 CUs and the chains
+    // (0.77 of 3.7 ms at B = 1) run beside the stages: plain forward 3.79 -> 3.57 ms (B = 1), 5.55 -> 5.16 (B = 2), 7.11 -> 6.9 (B = 4), 12.0 -> 11.9
+    // (B = 8), 20.4 -> 20.7 (B = 16).  So: forked for B <= 4, one stream above (option "f32_branch" / HN_F32_BRANCH=1: forked at any batch size;
+    // option "branch_stream" = 0: never).
     static const char* fenv = getenv("HN_F32_BRANCH");
-    const bool fork = e->use_branch_stream && !e->profiling && e->branch_stream != nullptr && (e->f32_branch || (fenv && fenv[0] == '1'));
+    const bool fork = e->use_branch_stream && !e->profiling && e->branch_stream != nullptr && (B <= 4 || e->f32_branch || (fenv && fenv[0] == '1'));
     hipStream_t sb = fork ? e->branch_stream : s;
     if (forked) *forked = fork;
     for (int li = 0; li < 4; ++li) {
@@ -678,6 +681,7 @@ extern "C" int hn_forward_submit(hn_engine* e, const float* x, int B, int C_in, 
     HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_trunk[slot], 0));
     if (forked && defer)
         for (int li = 0; li < 4; ++li) HN_HIP(hipStreamWaitEvent(e->head_stream, e->ev_join[li], 0));
+    // (the 256-workgroup recurrence beside the next trunk instead of the 64-CU wide one was re-measured in round 6: 861-863 panoramas/s either way)
     if (int rc = run_head_f(e, B, hb, bon, cor, true, e->head_stream)) return rc;
     HN_HIP(hipEventRecord(e->ev_head[slot], e->head_stream));
     e->head_pending[slot] = true;

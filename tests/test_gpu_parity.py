@@ -615,16 +615,16 @@ def test_forward_async_f32_pipelined_matches_forward_and_golden(golden_dir):
 
 
 def test_f32_branch_stream_option_is_bit_identical():
-    """Option "f32_branch" (the float32 height-compression chains on the engine's branch stream, deferred join in the pipelined entry;
-    measured without gain in round 6 and off by default): same kernels, so the same bits as the one-stream forward, plain and pipelined,
-    several batches in flight."""
+    """The float32 height-compression chains on the engine's branch stream (deferred join in the pipelined entry): default at B <= 4 (the
+    interactive regime, where it is worth 3-7 % of the forward's latency), option "f32_branch" at any batch size (measured without gain at
+    B = 32), option "branch_stream" = 0 never.  Same kernels, so the same bits as the one-stream forward -- plain and pipelined, several
+    batches in flight."""
     net = HorizonNet("resnet50", True)
     net.load_state_dict(make_state_dict(5, "random"))
     net = net.to(DEV).eval()
     gen = torch.Generator().manual_seed(79)
-    xs = [torch.rand(6, 3, 512, 1024, generator=gen).to(DEV) for _ in range(4)]
 
-    def run_all():
+    def run_all(xs):
         with torch.no_grad():
             plain = [tuple(t.clone() for t in net(x)) for x in xs]
             piped, pend = [], None
@@ -636,14 +636,18 @@ def test_f32_branch_stream_option_is_bit_identical():
             piped.append(tuple(t.clone() for t in pend.result()))
             torch.cuda.synchronize()
         assert net.hip_status(DEV) == 0
-        return plain, piped
+        return plain + piped
 
-    base_plain, base_piped = run_all()
-    net.set_engine_option("f32_branch", 1)
-    fork_plain, fork_piped = run_all()
+    for B, on, off in ((3, ("branch_stream", 1), ("branch_stream", 0)), (6, ("f32_branch", 1), ("f32_branch", 0))):
+        xs = [torch.rand(B, 3, 512, 1024, generator=gen).to(DEV) for _ in range(4)]
+        net.set_engine_option(*off)
+        base = run_all(xs)
+        net.set_engine_option(*on)
+        fork = run_all(xs)
+        for a, b in zip(base, fork):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     net.set_engine_option("f32_branch", 0)
-    for a, b in zip(base_plain + base_piped, fork_plain + fork_piped):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    net.set_engine_option("branch_stream", 1)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
