@@ -18,7 +18,7 @@ carries the other BASELINE configs as extra keys (`--legs` selects them): `bf16_
 against the bf16 MFMA peak AND the per-layer mixed roofline), `latency_b1` (configs[0]: demo.png through inference()),
 `train_bf16` (configs[2]: with a MIXED compute + HBM roofline of the whole step, `train_mixed_roofline`, and the HBM-side bytes of
 the committed counter passes), `layout` (configs[4]: 1000 panoramas, 3D IoU vs the reference's own inference()),
-`pano_stretch`, `augment_pipeline`.  `roofline.traffic` / `train_bf16.roofline.traffic` come from profiles/r4_pmc_*.json and
+`pano_stretch`, `augment_pipeline`.  `roofline.traffic` / `train_bf16.roofline.traffic` come from the newest profiles/rN_pmc_*.json and
 carry `traffic_stale` = (the kernel sources those counters were taken on != the sources this run was built from).
 `--mode train --gpus N` adds `allreduce_overlap` (step with / without the exchange, a traced step with every all-reduce bucket's
 start / end against the backward's kernels) and `--allreduce-dtype bf16` sends the gradients as bf16.

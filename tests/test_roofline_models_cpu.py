@@ -1,6 +1,6 @@
 """bench.py's roofline models (the denominators of every `roofline.frac` it prints) pinned on the CPU: the algorithmic work per panorama of
-SURVEY.md 8(d) / BASELINE.md, and the committed round-5 line (`profiles/r5_bench_default.json`) re-derived from the same functions -- a
-changed model can no longer move a reported fraction without this file noticing."""
+SURVEY.md 8(d) / BASELINE.md, and the ordering / three-GEMMs-per-conv structure of the training bounds -- a changed model can no longer move a
+reported fraction without this file noticing."""
 import json
 import os
 
