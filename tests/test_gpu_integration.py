@@ -551,3 +551,15 @@ def test_rccl_collective_before_the_engine_does_not_cost_the_pipelined_forward()
         rates[mode] = float(m.group(1))
     print("[streams] pipelined bf16 forward: clean %.1f, after an RCCL collective %.1f panoramas/s" % (rates["clean"], rates["nccl_first"]))
     assert rates["nccl_first"] >= 0.92 * rates["clean"]
+
+
+def test_box_probe_reports_plausible_rates():
+    """bench.py's box characterisation (hn_probe_mfma + a 1 GiB device copy): the dense-MFMA rates and the copy bandwidth it puts into the bench
+    line are finite and in the range of an MI355X (guide: 157.3 TF fp32, ~2500 TF bf16, 8 TB/s HBM; measured on the round's boxes: 137-139, 2350-2450,
+    5200-5500) -- a probe that returned nonsense would turn every `frac_of_box_*` of the line into nonsense."""
+    import bench
+    box = bench.box_probe(torch.device(DEV))
+    print("[box]", {k: v for k, v in box.items() if k != "note"})
+    assert 80.0 < box["mfma_f32_tflops"] < 160.0
+    assert 1200.0 < box["mfma_bf16_tflops"] < 2600.0
+    assert 2500.0 < box["hbm_copy_GBps"] < 8000.0
